@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the fine-tuning hot path on MI355X (contract: task prompt section 4).
+
+A "step" = one optimisation step of depth_fine_tuning.py's loop body on one batch of BS=4
+synthetic 384x224 frame pairs per GPU: hourglass forward (train-mode BN, 8 images), fused HIP
+geometric-consistency loss (+ analytic backward), CNN backward, [RCCL all-reduce], HIP Adam.
+Inputs are resident in HBM before the timed region.  value = frame pairs / second over all ranks.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
+
+Extra objects in the JSON line:
+  roofline          fused loss kernel at an HBM-saturating launch (--loss-batch pairs, working set
+                    well beyond the 256 MB Infinity Cache), HIP events on the launch stream
+  roofline_in_step  the same kernel as launched inside the timed steps (B = 4: 13.8 MB, cache
+                    resident and latency bound -- reported for honesty, not an HBM measurement)
+  cpu_baseline      the reference step restated on the host CPU (oracle/cpu_step.py), rank 0, N=1
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x2 (fp32), SURVEY.md 8d
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-size", type=int, default=4)
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=224)
+    ap.add_argument("--backend", default=os.environ.get("CD_AMD_MC_BACKEND", "torch"), choices=["torch", "hip"])
+    ap.add_argument("--pool", type=int, default=6, help="distinct synthetic batches cycled through")
+    ap.add_argument("--loss-batch", type=int, default=256, help="pairs per launch of the roofline micro-benchmark")
+    ap.add_argument("--loss-iters", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loss-microbench", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def make_pool(n, B, H, W, seed, device):
+    from consistent_depth_amd import synthetic
+    pool = []
+    for i in range(n):
+        b = synthetic.make_pair_batch(B, H, W, seed=seed * 1000 + i)
+        rng = np.random.default_rng(seed * 1000 + i)
+        images = rng.random((B, 2, 3, H, W), dtype=np.float32)
+        t = lambda a: torch.tensor(a, device=device)  # noqa: E731
+        meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
+                "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
+        from consistent_depth_amd.loss.consistency_loss import mask_sums
+        meta["geometry_consistency"]["mask_sums"] = mask_sums(*meta["geometry_consistency"]["masks"])
+        pool.append((t(images), meta, b, images))
+    return pool
+
+
+def profile_collect(lib, cap):
+    ms = (ctypes.c_float * cap)()
+    bs = (ctypes.c_int * cap)()
+    n = ctypes.c_int(0)
+    rc = lib.cd_profile_end(ms, bs, cap, ctypes.byref(n))
+    assert rc == 0
+    return np.array(ms[:n.value]), np.array(bs[:n.value])
+
+
+def loss_microbench(lib, B, H, W, iters, device):
+    """Fused loss kernel at an HBM-saturating batch: per-launch ms from HIP events on the stream."""
+    from consistent_depth_amd import synthetic
+    from consistent_depth_amd.loss import consistency_loss as CL
+    base = synthetic.make_pair_batch(8, H, W, seed=99)
+    rep = (B + 7) // 8
+    t = lambda a: torch.tensor(a, device=device).repeat((rep,) + (1,) * (a.ndim - 1))[:B].contiguous()  # noqa: E731
+    depth = torch.log(t(base["depth"]))
+    # de-duplicate content a little so repeated pairs are not bit-identical
+    depth += 0.01 * torch.randn_like(depth)
+    flows, masks = [t(f) for f in base["flows"]], [t(m) for m in base["masks"]]
+    intr, extr = t(base["intrinsics"]), t(base["extrinsics"])
+    msum = CL.mask_sums(masks[0], masks[1])
+    depth.requires_grad_(True)
+    for _ in range(2):
+        CL.consistency_loss(depth, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=CL.DEPTH_EXP)
+    torch.cuda.synchronize()
+    assert lib.cd_profile_begin(iters) == 0
+    for _ in range(iters):
+        CL.consistency_loss(depth, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=CL.DEPTH_EXP)
+    torch.cuda.synchronize()
+    ms, _ = profile_collect(lib, iters)
+    return ms
+
+
+def main():
+    args = parse()
+    from consistent_depth_amd import _native, parallel
+    from consistent_depth_amd.engine import FineTuneStep
+    from consistent_depth_amd.monodepth.depth_model_registry import get_depth_model
+    import torch.distributed as dist
+
+    rank, local_rank, world = parallel.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    lib = _native.lib()
+    B, H, W = args.batch_size, args.height, args.width
+
+    params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0,
+                                learning_rate=4e-4, optimizer="Adam")
+    torch.backends.cudnn.benchmark = True
+    model = get_depth_model("mc")(backend=args.backend, seed=0)
+    model.train()
+    step = FineTuneStep(model, params, world=world)
+    pool = make_pool(args.pool, B, H, W, seed=rank + 1, device=device)
+
+    def run(n, offset=0):
+        last = None
+        for i in range(n):
+            images, meta, _, _ = pool[(offset + i) % len(pool)]
+            last, _ = step(images, meta)
+        return last
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    assert lib.cd_profile_begin(args.steps + 8) == 0
+    t0 = time.perf_counter()
+    last_loss = run(args.steps, offset=args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms_step, _ = profile_collect(lib, args.steps + 8)
+    if world > 1:
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = te.item()
+    pairs_per_s = B * world * args.steps / elapsed
+
+    out = {
+        "metric": "frame-pairs/sec fine-tuning @384x224 BS4; warp+loss HBM GB/s vs peak",
+        "value": round(pairs_per_s, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"mc hourglass (random init, seed 0) test-time fine-tuning step, {H}x{W}, "
+                               f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{2 if args.backend == 'hip' else 1}])",
+                   "conv_backend": args.backend, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "last_loss": float(last_loss.item())},
+    }
+
+    if rank == 0:
+        px = H * W
+        in_step_ms = float(np.mean(ms_step)) if len(ms_step) else None
+        if in_step_ms:
+            ach = LOSS_BYTES_PER_PAIR_PX * px * B / (in_step_ms * 1e-3) / 1e9
+            out["roofline_in_step"] = {"kernel": "loss_main_kernel", "bound": "hbm", "achieved": round(ach, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                       "traffic": None, "launch_pairs": B, "avg_ms": round(in_step_ms, 5),
+                                       "note": "13.8 MB per launch: cache resident, launch-latency bound"}
+        if not args.no_loss_microbench:
+            ms = loss_microbench(lib, args.loss_batch, H, W, args.loss_iters, device)
+            avg = float(np.mean(ms))
+            ach = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch / (avg * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "loss_main_kernel", "bound": "hbm", "achieved": round(ach, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                               "traffic": None, "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
+                               "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_step  # checker only: the CPU restatement of the reference step
+            cores = os.cpu_count()
+            torch.set_num_threads(cores)
+            _, _, b_np, images_np = pool[0]
+            sd = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
+            sec = cpu_step.time_steps(sd, images_np, b_np, n_steps=args.cpu_steps, warmup=1, threads=cores)
+            out["cpu_baseline"] = {"value": round(B / sec, 4), "unit": "frame-pairs/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": f"{args.cpu_steps} full steps (+1 warm-up) of the same BS{B} {H}x{W} workload, "
+                                             f"torch CPU fp32 hourglass fwd+bwd + C oracle loss + torch Adam, {sec:.2f} s/step"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

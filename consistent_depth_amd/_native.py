@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI library (include/consistent_depth_amd.h).
+
+The product path has NO fallback: if libcd_amd.so is missing or a tensor is not a
+contiguous fp32 tensor on the HIP device, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # imported first on purpose: libcd_amd.so then binds to torch's libamdhip64
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "libcd_amd.so")
+ABI_VERSION = 1
+
+_lib = None
+
+c_f, c_i, c_p, c_sz = ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes): exactly the declarations of include/consistent_depth_amd.h
+SIGNATURES = {
+    "cd_abi_version": (c_i, []),
+    "cd_build_info": (ctypes.c_char_p, []),
+    "cd_consistency_loss_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "cd_mask_sums": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "cd_consistency_loss_fwd_bwd": (c_i, [c_p] * 8 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 4 + [c_p, c_sz, c_p]),
+    "cd_consistency_loss_fwd": (c_i, [c_p] * 8 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 3 + [c_p, c_sz, c_p]),
+    "cd_profile_begin": (c_i, [c_i]),
+    "cd_profile_end": (c_i, [c_p, c_p, c_i, c_p]),
+    "cd_sample_bilinear_border": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "cd_adam_step_flat": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "cd_adam_step_flat_guarded": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p]),
+    "cd_l1_distance_workspace_bytes": (c_sz, [c_sz]),
+    "cd_l1_distance": (c_i, [c_p, c_p, c_sz, c_p, c_p, c_sz, c_p]),
+}
+
+STATUS = {0: "CD_OK", -1: "CD_ERR_INVALID_ARG", -2: "CD_ERR_WORKSPACE", -3: "CD_ERR_LAUNCH", -4: "CD_ERR_UNSUPPORTED"}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libcd_amd.so (once).  Raises NativeLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise NativeLibraryError(
+            f"{SO_PATH} is missing: build it with `python -m consistent_depth_amd.build_native` "
+            "(hipcc --offload-arch=gfx950).  consistent_depth_amd has no CPU/PyTorch fallback.")
+    l = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{SO_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    if l.cd_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI mismatch: library {l.cd_abi_version()} != binding {ABI_VERSION}; rebuild")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {STATUS.get(rc, rc)}")
+
+
+def dev_ptr(t: torch.Tensor, name: str = "tensor") -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must live on the HIP device (got {t.device}); "
+                           "consistent_depth_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_workspaces: dict = {}
+
+
+def workspace(key, nbytes: int, device) -> torch.Tensor:
+    """Persistent per-(key, device) scratch buffer, grown on demand (never shrunk)."""
+    k = (key, str(device))
+    buf = _workspaces.get(k)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _workspaces[k] = buf
+    return buf

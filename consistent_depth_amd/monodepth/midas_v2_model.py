@@ -1,0 +1,49 @@
+"""`midas2` depth model plugin (reference: /root/reference/monodepth/midas_v2_model.py:12-73).
+
+Class attributes (:14-16), ImageNet normalisation (:45-48,58-59) and the disparity->depth
+reciprocal (:67) follow the reference.  The MidasNet source is an un-vendored submodule
+(.gitmodules:7-9) and its weights are unreachable; the backbone is restated in
+consistent_depth_amd/monodepth/midas_net.py (ResNeXt-101 32x8d encoder + 4 feature-fusion
+blocks, random init) -- "parity unpinned" for real checkpoints.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..loss.consistency_loss import DEPTH_RECIPROCAL
+from .depth_model import DepthModel
+
+
+class MidasV2Model(DepthModel):
+    align = 32
+    learning_rate = 0.0001
+    lambda_view_baseline = 0.0001
+    depth_mode = DEPTH_RECIPROCAL  # depth = 1 / disparity, :67
+
+    def __init__(self, support_cpu: bool = False, pretrained: bool = False, seed: int = 0):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError("MidasV2Model needs the HIP device (no CPU path in consistent_depth_amd)")
+        from .midas_net import MidasNet
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        st = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.model = MidasNet(non_negative=True)
+        torch.random.set_rng_state(st)
+        self.model.to(self.device)
+        self.register_buffer("norm_mean", torch.tensor([0.485, 0.456, 0.406]).reshape(1, -1, 1, 1).to(self.device))
+        self.register_buffer("norm_stdev", torch.tensor([0.229, 0.224, 0.225]).reshape(1, -1, 1, 1).to(self.device))
+
+    def estimate_raw(self, images):
+        shape = images.shape
+        C, H, W = shape[-3:]
+        x = images.reshape(-1, C, H, W).to(self.device)
+        x = (x - self.norm_mean) / self.norm_stdev
+        out = self.model(x)
+        return out.reshape(shape[:-3] + out.shape[-2:])
+
+    def estimate_depth(self, images):
+        return self.estimate_raw(images).reciprocal()
+
+    def save(self, file_name):
+        torch.save(self.model.state_dict(), file_name)

@@ -1,0 +1,145 @@
+/*
+ * consistent_depth_amd -- C ABI of the MI355X-native (gfx950) fine-tuning hot path.
+ *
+ * This is the drop-in boundary for the depth_fine_tuning.py step of
+ * facebookresearch/consistent_depth.  The reference has no FFI of its own (it is pure
+ * Python on stock PyTorch ops); each entry point below replaces
+ * the chain of ATen ops the cited reference lines launch.  Conventions:
+ *
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (NCHW / row-major) unless
+ *     the parameter says otherwise; nothing is allocated inside the library -- the
+ *     caller passes workspaces sized by the matching *_workspace_bytes() call;
+ *   - `stream` is the caller's hipStream_t (as void*); all work is enqueued on it and
+ *     nothing synchronises the device;
+ *   - return value: 0 = ok, negative = cd_status error; no exceptions cross the boundary;
+ *   - no torch / C++ types appear in any signature.
+ */
+#ifndef CONSISTENT_DEPTH_AMD_H
+#define CONSISTENT_DEPTH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cd_status {
+    CD_OK = 0,
+    CD_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, bad enum           */
+    CD_ERR_WORKSPACE = -2,   /* workspace_bytes smaller than *_workspace_bytes()      */
+    CD_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after a launch        */
+    CD_ERR_UNSUPPORTED = -4  /* shape outside what the kernels were built for         */
+} cd_status;
+
+/* How the `depth` argument of the loss relates to the network output (the reference
+ * applies these as separate ATen ops before the loss; here they are fused into it and
+ * the returned gradient is w.r.t. the tensor that was passed in):
+ *   CD_DEPTH_IDENTITY    depth = x                      (loss/consistency_loss.py:210 contract)
+ *   CD_DEPTH_EXP         depth = exp(x)                 (monodepth/mannequin_challenge_model.py:66)
+ *   CD_DEPTH_RECIPROCAL  depth = 1/x                    (monodepth/midas_v2_model.py:67)        */
+typedef enum cd_depth_mode {
+    CD_DEPTH_IDENTITY = 0,
+    CD_DEPTH_EXP = 1,
+    CD_DEPTH_RECIPROCAL = 2
+} cd_depth_mode;
+
+/* ABI version, bumped on any signature change. */
+int cd_abi_version(void);
+/* Human-readable build string ("gfx950 hipcc x.y ..."); static storage. */
+const char* cd_build_info(void);
+
+/* ------------------------------------------------------------------------------------
+ * Geometric-consistency loss  (reference: loss/consistency_loss.py:98-253 +
+ * utils/geometry.py:9-128,201-208; closed form in SURVEY.md appendix A.1)
+ * ---------------------------------------------------------------------------------- */
+
+/* Bytes of scratch the loss entry points need for a batch of B pairs of HxW frames. */
+size_t cd_consistency_loss_workspace_bytes(int B, int H, int W);
+
+/* Per-pair, per-direction mask sums S[b,k] = sum(mask_k[b])  (weighted_mean_loss,
+ * loss/consistency_loss.py:85).  They depend only on the dataset, so a caller may
+ * compute them once per pair and pass them to the loss; mask_sum is [B,2] fp32. */
+int cd_mask_sums(const float* mask_fwd, const float* mask_bwd, int B, int H, int W,
+                 float* mask_sum, void* stream);
+
+/*
+ * Fused forward + analytic backward of ConsistencyLoss.__call__ in one pass over the
+ * frame pairs (replaces geometry.py pixel_grid/pixels_to_points/reproject_points/
+ * project/sample, the two weighted_mean_loss reductions per direction and the whole
+ * autograd backward of that chain).
+ *
+ *   depth      [B,2,H,W]  network output for the two frames of each pair (see depth_mode)
+ *   flow_fwd   [B,2,H,W]  metadata["geometry_consistency"]["flows"][0]  (dx,dy) px, frame0->frame1
+ *   flow_bwd   [B,2,H,W]  ...["flows"][1], frame1->frame0
+ *   mask_fwd   [B,1,H,W]  ...["masks"][0]  fp32 {0,1};  mask_bwd = ["masks"][1]
+ *   mask_sum   [B,2] or NULL  precomputed cd_mask_sums(); NULL = computed here (one extra
+ *                          read of the masks)
+ *   intr       [B,2,4]    fx,fy,cx,cy per frame      (metadata["intrinsics"])
+ *   extr       [B,2,3,4]  [R|t] camera-to-world      (metadata["extrinsics"])
+ *   lambda_r / lambda_b   opt.lambda_reprojection / opt.lambda_view_baseline; a term whose
+ *                          lambda <= 0 is skipped and reported as zeros (consistency_loss.py:169,176,198,204)
+ * outputs
+ *   reproj[B], disp[B]    batch_losses["reprojection"], ["disparity"] (lambda-weighted, :194-205)
+ *   total[1]              mean_b(reproj + disp)                         (:208)
+ *   grad_in [B,2,H,W]     d total / d depth-argument (chain rule through depth_mode included)
+ */
+int cd_consistency_loss_fwd_bwd(
+    const float* depth, const float* flow_fwd, const float* flow_bwd,
+    const float* mask_fwd, const float* mask_bwd, const float* mask_sum,
+    const float* intr, const float* extr,
+    float lambda_r, float lambda_b, int depth_mode, int B, int H, int W,
+    float* reproj, float* disp, float* total, float* grad_in,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Forward only (validation sweep, depth_fine_tuning.py:312-406 under no_grad). */
+int cd_consistency_loss_fwd(
+    const float* depth, const float* flow_fwd, const float* flow_bwd,
+    const float* mask_fwd, const float* mask_bwd, const float* mask_sum,
+    const float* intr, const float* extr,
+    float lambda_r, float lambda_b, int depth_mode, int B, int H, int W,
+    float* reproj, float* disp, float* total,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement hook (bench.py): while active, every loss call brackets ITS FUSED PASS (the
+ * loss_main kernel only, not prep/finalize) with a pair of HIP events recorded on the caller's
+ * stream.  cd_profile_end waits for them and returns per-launch milliseconds and the batch
+ * size of each launch (negative = forward-only launch); it ends the session. */
+int cd_profile_begin(int max_records);
+int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out);
+
+/* utils/geometry.py:201-208 `sample`: bilinear, border padding, align_corners=False on an
+ * align_corners=True style normalisation.  data [B,C,H,W], uv [B,2,H,W] px -> out [B,C,H,W]. */
+int cd_sample_bilinear_border(const float* data, const float* uv, int B, int C, int H, int W,
+                              float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser (reference: optimizer/__init__.py:16-17 -> torch.optim.Adam,
+ * depth_fine_tuning.py:231-236,283; betas (0.9,0.999), eps 1e-8, no weight decay)
+ * ---------------------------------------------------------------------------------- */
+
+/* One Adam step over a flat parameter buffer.  `step` is 1-based.  grad_scale multiplies
+ * every gradient first (1/world_size after a sum all-reduce; 1.0 otherwise). */
+int cd_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                      size_t n, float lr, float beta1, float beta2, float eps, int step,
+                      float grad_scale, void* stream);
+
+/* The same step with the reference's NaN guard (depth_fine_tuning.py:278-280: a NaN loss skips
+ * backward() and step()) and the step counter kept on the device, so the training loop needs
+ * no host synchronisation: if loss[0] is NaN nothing is updated and *step_counter (device int,
+ * number of steps taken so far) is not advanced; otherwise the step uses *step_counter + 1 and
+ * the counter is advanced.  loss may be NULL (no guard). */
+int cd_adam_step_flat_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                              size_t n, float lr, float beta1, float beta2, float eps,
+                              int* step_counter, const float* loss, float grad_scale, void* stream);
+
+/* sum_i |p_i - p0_i|  (loss/parameter_loss.py:14-18, lambda applied by the caller);
+ * out[1]; workspace of cd_l1_distance_workspace_bytes(n). */
+size_t cd_l1_distance_workspace_bytes(size_t n);
+int cd_l1_distance(const float* p, const float* p0, size_t n, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONSISTENT_DEPTH_AMD_H */

@@ -1,0 +1,53 @@
+"""TEST INFRASTRUCTURE ONLY -- the reference's fine-tuning step restated on the CPU
+(bench.py `cpu_baseline` leg, kind "port"; tests use it as the step-level reference).
+
+One step = depth_fine_tuning.py:264-283 of the reference: hourglass forward (oracle/hourglass_ref,
+train-mode BN) -> depth = exp(pred) -> geometric-consistency loss + d loss/d depth (plain-C oracle,
+cd_oracle.c) -> backward through the CNN (torch autograd, all host threads) -> torch.optim.Adam.
+Nothing here is reachable from consistent_depth_amd/.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import hourglass_ref, oracle
+
+
+class CpuFineTuner:
+    def __init__(self, state_dict, lr=4e-4, lambda_r=1.0, lambda_b=0.1, dtype=torch.float32):
+        self.dtype = dtype
+        self.state = {k: v.detach().clone().to("cpu", dtype if v.is_floating_point() else v.dtype)
+                      for k, v in state_dict.items()}
+        self.param_keys = [k for k in self.state if k.endswith(".weight") or k.endswith(".bias")]
+        for k in self.param_keys:
+            self.state[k].requires_grad_(True)
+        self.opt = torch.optim.Adam([self.state[k] for k in self.param_keys], lr, betas=(0.9, 0.999))
+        self.lambda_r, self.lambda_b = lambda_r, lambda_b
+
+    def step(self, images, batch):
+        """images (B,2,3,H,W) numpy/tensor; batch: dict with flows/masks/intrinsics/extrinsics (numpy)."""
+        np_dtype = np.float64 if self.dtype == torch.float64 else np.float32
+        x = torch.as_tensor(images, dtype=self.dtype).reshape((-1,) + tuple(images.shape[-3:]))
+        pred, _ = hourglass_ref.forward(self.state, x, training=True, update_running_stats=True)
+        B = images.shape[0]
+        depth = torch.exp(pred).reshape(B, 2, *pred.shape[-2:])
+        out = oracle.consistency_loss(depth.detach().numpy(), batch["flows"], batch["masks"], batch["intrinsics"],
+                                      batch["extrinsics"], self.lambda_r, self.lambda_b, dtype=np_dtype)
+        self.opt.zero_grad()
+        if not np.isnan(out["total"][0]):
+            depth.backward(torch.as_tensor(out["grad_depth"]))
+            self.opt.step()
+        return out, depth.detach()
+
+
+def time_steps(state_dict, images, batch, n_steps=2, warmup=1, threads=None):
+    if threads:
+        torch.set_num_threads(threads)
+    ft = CpuFineTuner(state_dict)
+    for _ in range(warmup):
+        ft.step(images, batch)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        ft.step(images, batch)
+    return (time.perf_counter() - t0) / n_steps
