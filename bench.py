@@ -33,6 +33,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x2 (fp32), SURVEY.md 8d
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing printed on stdout)."""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss-microbench", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="torch backend only: let MIOpen benchmark-search every conv (minutes of start-up)")
     return ap.parse_args()
 
 
@@ -118,7 +128,11 @@ def main():
 
     params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0,
                                 learning_rate=4e-4, optimizer="Adam")
-    torch.backends.cudnn.benchmark = True
+    # the reference sets cudnn.benchmark=True (depth_fine_tuning.py:220-221); MIOpen's exhaustive
+    # find over the 157 conv shapes x {fwd, dgrad, wgrad} takes many minutes, so the default here
+    # is MIOpen's immediate (heuristic) mode
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    log(f"rank {rank}/{world} building mc model, conv backend {args.backend}")
     model = get_depth_model("mc")(backend=args.backend, seed=0)
     model.train()
     step = FineTuneStep(model, params, world=world)
@@ -131,8 +145,11 @@ def main():
             last, _ = step(images, meta)
         return last
 
-    run(args.warmup)
-    torch.cuda.synchronize()
+    log("pool ready; warm-up")
+    for i in range(args.warmup):
+        run(1, offset=i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -150,6 +167,7 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     pairs_per_s = B * world * args.steps / elapsed
+    log(f"timed region: {args.steps} steps in {elapsed:.3f}s -> {pairs_per_s:.2f} pairs/s")
 
     out = {
         "metric": "frame-pairs/sec fine-tuning @384x224 BS4; warp+loss HBM GB/s vs peak",
@@ -172,6 +190,7 @@ def main():
                                        "traffic": None, "launch_pairs": B, "avg_ms": round(in_step_ms, 5),
                                        "note": "13.8 MB per launch: cache resident, launch-latency bound"}
         if not args.no_loss_microbench:
+            log("loss kernel micro-benchmark")
             ms = loss_microbench(lib, args.loss_batch, H, W, args.loss_iters, device)
             avg = float(np.mean(ms))
             ach = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch / (avg * 1e-3) / 1e9
@@ -180,6 +199,7 @@ def main():
                                "traffic": None, "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline")
             from oracle import cpu_step  # checker only: the CPU restatement of the reference step
             cores = os.cpu_count()
             torch.set_num_threads(cores)

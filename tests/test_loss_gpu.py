@@ -91,9 +91,12 @@ def test_forward_only_and_cached_mask_sums(torch_cuda):
     with torch.no_grad():
         b = CL.consistency_loss(depth, d["flows"], d["masks"], d["intrinsics"], d["extrinsics"], 1.0, 0.1)
     c = CL.consistency_loss(depth, d["flows"], d["masks"], d["intrinsics"], d["extrinsics"], 1.0, 0.1, mask_sums=msum)
-    for x, y in ((a, b), (a, c)):
-        for u, v in zip(x, y):
-            assert torch.equal(u.detach(), v.detach())
+    # forward-only and forward+backward are different template instantiations (different FMA
+    # contraction), so they agree to fp32 rounding, not bitwise; cached sums are bit-identical
+    for u, v in zip(a, b):
+        torch.testing.assert_close(u.detach(), v.detach(), rtol=2e-6, atol=0)
+    for u, v in zip(a, c):
+        assert torch.equal(u.detach(), v.detach())
     assert not b[0].requires_grad and a[0].requires_grad
 
 
