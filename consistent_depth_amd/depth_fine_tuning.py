@@ -1,0 +1,221 @@
+"""Test-time fine-tuning driver on the MI355X engine.
+
+Same surface as /root/reference/depth_fine_tuning.py: `DepthFineTuningParams.add_arguments`
+(:28-63, same flags/defaults), `make_tag` (:130-136), `DepthFineTuner(range_dir, frames, params)`
+with `.out_dir`, `.save_depth(dir, frames)` (:164-199), `.fine_tune(writer=None)` (:201-310) and
+`.eval_and_save(...)` (:312-406); same output files:
+
+    <out_dir>/checkpoints/%04d.pth                      netG.state_dict()
+    <out_dir>/eval/depth_%06d_e%04d_iter%06d.raw        inverse depth, first sighting of a frame
+    <out_dir>/eval/loss_e%04d_iter%06d.json             {loss_name: {"[i, j]": v}, "mean": {...}}
+    <dir>/depth/frame_%06d.raw                          inverse depth (save_depth)
+
+What differs, by design (MI355X-first):
+  * the whole frame-pair dataset lives in HBM (loaders/pair_store.py) -- no DataLoader workers;
+  * one process per GPU: the pair list is sharded over ranks (parallel.shard_indices), gradients
+    are summed by ONE RCCL all-reduce of the flat buffer, per-GPU batch stays params.batch_size
+    (the reference multiplies batch_size by the GPU count for nn.DataParallel, :155-159 --
+    same global batch);
+  * no per-step host synchronisation: the NaN-skip (:278-280) runs inside the Adam kernel,
+    losses are fetched only every `print_freq` steps and at validation;
+  * shuffling uses a seeded numpy permutation (the reference is unseeded); `--seed` is an
+    extension flag.
+PNG visualisations and tensorboard images are cosmetic and out of scope (SURVEY.md section 2
+row 12); scalars are written if a `writer` with add_scalar() is passed.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from os.path import join as pjoin
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import optimizer, parallel
+from .engine import FineTuneStep
+from .loaders.pair_store import PairStore
+from .loaders.video_dataset import VideoFrameDataset
+from .loss.loss_params import LossParams
+from .monodepth.depth_model_registry import get_depth_model
+from .utils import image_io
+
+
+class DepthFineTuningParams:
+    """Fine-tuning flags (names and defaults of the reference, :36-61)."""
+
+    @staticmethod
+    def add_arguments(parser):
+        LossParams.add_arguments(parser)
+        parser.add_argument("--optimizer", default="Adam", choices=list(optimizer.OPTIMIZER_NAMES),
+                            help="optimizer to train the network")
+        parser.add_argument("--val_epoch_freq", type=int, default=1, help="validation epoch frequency.")
+        parser.add_argument("--learning_rate", type=float, default=0,
+                            help="<= 0 selects the default of the chosen depth model")
+        parser.add_argument("--batch_size", type=int, default=4, help="frame pairs per step PER GPU")
+        parser.add_argument("--num_epochs", type=int, default=20)
+        parser.add_argument("--log_dir", help="folder to log tensorboard summary")
+        parser.add_argument("--display_freq", type=int, default=100)
+        parser.add_argument("--print_freq", type=int, default=1)
+        parser.add_argument("--save_epoch_freq", type=int, default=1)
+        return parser
+
+
+def make_tag(params) -> str:
+    return (LossParams.make_str(params) + f"_LR{params.learning_rate}" + f"_BS{params.batch_size}"
+            + f"_O{params.optimizer.lower()}")
+
+
+def log_loss_stats(writer, name_prefix: str, loss_meta: Dict[str, torch.Tensor], n: int, log_histogram=False):
+    for sub, value in loss_meta.items():
+        full = f"{name_prefix}/{sub}"
+        writer.add_scalar(full + "/max", value.max(), n)
+        writer.add_scalar(full + "/min", value.min(), n)
+        writer.add_scalar(full + "/mean", value.mean(), n)
+        if log_histogram and hasattr(writer, "add_histogram"):
+            writer.add_histogram(full, value, n)
+
+
+class DepthFineTuner:
+    def __init__(self, range_dir, frames, params, store: PairStore = None):
+        self.frames = frames
+        self.params = params
+        self.base_dir = params.path
+        self.range_dir = range_dir
+        self.out_dir = pjoin(range_dir, make_tag(params))
+        self.checkpoints_dir = pjoin(self.out_dir, "checkpoints")
+        self.rank, self.local_rank, self.world = parallel.env_world()
+        if self.rank == 0:
+            os.makedirs(self.checkpoints_dir, exist_ok=True)
+            print(f"Fine-tuning directory: '{self.out_dir}'")
+        self.model = get_depth_model(params.model_type)()
+        print(f"Using {self.world} GPUs (one process each); global batch {params.batch_size * self.world}.")
+        self.store = store
+        self.seed = getattr(params, "seed", 0)
+
+    # ------------------------------------------------------------------ depth export (:164-199)
+    @torch.no_grad()
+    def save_depth(self, dir: str = None, frames=None):
+        dir = dir or self.out_dir
+        frames = frames if frames is not None else self.frames
+        depth_dir = pjoin(dir, "depth")
+        os.makedirs(depth_dir, exist_ok=True)
+        self.model.eval()
+        if self.store is not None:
+            rows = {f: r for r, f in enumerate(self.store.frame_ids)}
+            get = lambda f: self.store.color[rows[f]][None]  # noqa: E731
+        else:
+            ds = VideoFrameDataset(pjoin(self.base_dir, "color_down", "frame_{:06d}.raw"), frames)
+            lookup = {f: i for i, f in enumerate(frames)}
+            get = lambda f: ds[lookup[f]][0][None]  # noqa: E731
+        for f in frames:
+            depth = self.model.forward(get(f)).detach().float().cpu().numpy().squeeze()
+            image_io.save_raw_float32_image(pjoin(depth_dir, f"frame_{f:06d}.raw"), 1.0 / depth)
+
+    # ------------------------------------------------------------------ training (:201-310)
+    def fine_tune(self, writer=None):
+        p = self.params
+        if self.store is None:
+            self.store = PairStore.from_directory(self.base_dir, pjoin(self.range_dir, "metadata_scaled.npz"))
+        store = self.store
+        step = FineTuneStep(self.model, p, world=self.world)
+        self._step = step
+        if self.rank == 0:
+            os.makedirs(pjoin(self.out_dir, "eval"), exist_ok=True)
+        self.model.train()
+
+        def validate(epoch, niters):
+            loss_meta = self.eval_and_save(step, f"_e{epoch:04d}_iter{niters:06d}")
+            if writer is not None and self.rank == 0:
+                log_loss_stats(writer, "validation", loss_meta, epoch, log_histogram=True)
+            if self.rank == 0:
+                print(f"Done Validation for epoch {epoch} ({niters} iterations)")
+
+        validate(0, 0)
+        total_iters = 0
+        for epoch in range(p.num_epochs):
+            t0 = time.perf_counter()
+            plan = parallel.shard_indices(len(store), epoch, self.seed, self.rank, self.world, p.batch_size)
+            for it, ids in enumerate(plan):
+                images, metadata = store.batch(ids)
+                loss, loss_meta = step(images, metadata)
+                total_iters += len(ids) * self.world
+                if p.print_freq > 0 and (it % max(1, p.print_freq) == 0) and self.rank == 0:
+                    pairs = metadata["geometry_consistency"]["indices"].tolist()
+                    lv = loss.item()  # the only host sync, every print_freq steps
+                    print(f"Epoch = {epoch}, pairs = {pairs}, loss = {lv}")
+                    if lv != lv:
+                        print("Loss is NaN. Skipping.")  # already skipped on the device
+                    if writer is not None:
+                        writer.add_scalar("Train/loss", lv, total_iters)
+                        log_loss_stats(writer, "Train/loss", loss_meta, total_iters)
+            torch.cuda.synchronize()
+            if self.rank == 0:
+                print(f"Epoch {epoch} took {time.perf_counter() - t0:.2f}s.")
+            if (epoch + 1) % p.val_epoch_freq == 0:
+                validate(epoch + 1, total_iters)
+            if (epoch + 1) % p.save_epoch_freq == 0 and self.rank == 0:
+                self.model.save(pjoin(self.checkpoints_dir, f"{epoch + 1:04d}.pth"))
+        if p.num_epochs % p.val_epoch_freq != 0:
+            validate(p.num_epochs, total_iters)
+        if self.rank == 0:
+            print("Finished Training")
+
+    # ------------------------------------------------------------------ validation (:312-406)
+    @torch.no_grad()
+    def eval_and_save(self, step: FineTuneStep, suf: str) -> Dict[str, torch.Tensor]:
+        """Full-dataset forward + loss in store order, BatchNorm left in train mode like the
+        reference (model.train() is set once, :241).  Ranks shard the unshuffled list; per-pair
+        losses are gathered on rank 0, which writes the files."""
+        store, p = self.store, self.params
+        plan = parallel.shard_indices(len(store), 0, 0, self.rank, self.world, p.batch_size, shuffle=False)
+        names, rows, saved = None, [], {}
+        for ids in plan:
+            images, metadata = store.batch(ids)
+            raw, _, parts = step.evaluate(images, metadata)
+            if names is None:
+                names = [n for n in parts if parts[n].numel() == len(ids)]
+            idx = metadata["geometry_consistency"]["indices"]
+            rows.append(torch.cat([idx.float()] + [parts[n].reshape(-1, 1).float() for n in names], 1))
+            depth = self._depth_from_raw(raw)
+            for b, pair in enumerate(idx.tolist()):
+                for k, f in enumerate(pair):
+                    if f not in saved:
+                        saved[f] = (1.0 / depth[b, k]).cpu().numpy()
+        table = torch.cat(rows, 0) if rows else torch.zeros(0, 2 + len(names or []), device=store.device)
+        if self.world > 1:
+            import torch.distributed as dist
+            n_loc = torch.tensor([table.shape[0]], device=table.device)
+            n_all = [torch.zeros_like(n_loc) for _ in range(self.world)]
+            dist.all_gather(n_all, n_loc)
+            mx = int(max(n.item() for n in n_all))
+            pad = torch.zeros(mx, table.shape[1], device=table.device)
+            pad[:table.shape[0]] = table
+            gathered = [torch.zeros_like(pad) for _ in range(self.world)]
+            dist.all_gather(gathered, pad)
+            table = torch.cat([g[:int(n.item())] for g, n in zip(gathered, n_all)], 0)
+        table = table.cpu().numpy()
+        for f, inv in saved.items():  # every rank writes the frames it saw first (disjoint enough; idempotent)
+            image_io.save_raw_float32_image(pjoin(self.out_dir, "eval", f"depth_{f:06d}{suf}.raw"), inv)
+        loss_dict = {n: {} for n in (names or [])}
+        for row in table:
+            key = str([int(row[0]), int(row[1])])
+            for c, n in enumerate(names):
+                loss_dict[n][key] = float(row[2 + c])
+        loss_meta = {n: torch.tensor(list(v.values())) for n, v in loss_dict.items()}
+        loss_dict["mean"] = {n: float(v.mean().item()) for n, v in loss_meta.items()}
+        if self.rank == 0:
+            with open(pjoin(self.out_dir, "eval", f"loss{suf}.json"), "w") as f:
+                json.dump(loss_dict, f)
+            print("Mean: " + ", ".join(f"{n}: {v:.6f}" for n, v in loss_dict["mean"].items()))
+        return loss_meta
+
+    def _depth_from_raw(self, raw):
+        from .loss.consistency_loss import DEPTH_EXP, DEPTH_RECIPROCAL
+        if self.model.depth_mode == DEPTH_EXP:
+            return torch.exp(raw)
+        if self.model.depth_mode == DEPTH_RECIPROCAL:
+            return raw.reciprocal()
+        return raw

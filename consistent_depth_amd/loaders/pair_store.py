@@ -1,0 +1,108 @@
+"""Device-resident frame-pair store.
+
+The reference reads ~3.5 MB of files per pair per step through 4 DataLoader worker processes
+(loaders/video_dataset.py:131-207, depth_fine_tuning.py:205-218).  At MI355X step rates that
+loader is the bottleneck, and 288 GB of HBM holds any realistic clip outright (244 frames at
+384x224: 0.25 GB of colour + 715 pairs x 2.06 MB of flow/mask = 1.7 GB; 1000 frames / 2979 pairs:
+7.2 GB).  So the whole dataset is uploaded ONCE and mini-batches are gathered on the GPU:
+
+    colour  (F,3,H,W) fp32      flows (P,2,2,H,W) fp32 [pair, direction, (dx,dy)]
+    masks   (P,2,1,H,W) fp32    mask_sums (P,2) fp32 (dataset constants, cached normalisers)
+    intrinsics (F,4), extrinsics (F,3,4), pair_frames (P,2) int64 (indices into F)
+
+`batch(pair_ids)` returns exactly what default_collate + to_device hand the reference's loop.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..loss.consistency_loss import mask_sums as _mask_sums
+
+
+class PairStore:
+    def __init__(self, color, flows, masks, intrinsics, extrinsics, pair_frames, frame_ids=None, device=None):
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)  # noqa: E731
+        self.device = dev
+        self.color = f32(color)
+        self.flows = f32(flows)
+        self.masks = f32(masks)
+        self.intrinsics = f32(intrinsics)
+        self.extrinsics = f32(extrinsics)
+        self.pair_frames = torch.as_tensor(np.asarray(pair_frames), dtype=torch.int64).to(dev)
+        # original frame numbers (for file names / logs); row r of colour is frame frame_ids[r]
+        self.frame_ids = list(frame_ids) if frame_ids is not None else list(range(self.color.shape[0]))
+        P = self.flows.shape[0]
+        assert self.masks.shape[0] == P and self.pair_frames.shape == (P, 2)
+        self.mask_sums = torch.empty(P, 2, dtype=torch.float32, device=dev)
+        for s in range(0, P, 256):
+            self.mask_sums[s:s + 256] = _mask_sums(self.masks[s:s + 256, 0].contiguous(), self.masks[s:s + 256, 1].contiguous())
+
+    def __len__(self):
+        return self.flows.shape[0]
+
+    @property
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.color, self.flows, self.masks))
+
+    def pair_indices(self):
+        """[[frame_i, frame_j], ...] in original frame numbering, store order."""
+        pf = self.pair_frames.cpu().numpy()
+        return [[self.frame_ids[a], self.frame_ids[b]] for a, b in pf]
+
+    def batch(self, pair_ids):
+        ids = torch.as_tensor(pair_ids, dtype=torch.int64, device=self.device)
+        fr = self.pair_frames[ids]                       # (B,2)
+        images = self.color[fr]                          # (B,2,3,H,W)
+        fl = self.flows[ids]                             # (B,2,2,H,W)
+        mk = self.masks[ids]                             # (B,2,1,H,W)
+        fid = torch.as_tensor(self.frame_ids, dtype=torch.int64, device=self.device)
+        metadata = {
+            "extrinsics": self.extrinsics[fr],
+            "intrinsics": self.intrinsics[fr],
+            "geometry_consistency": {
+                "indices": fid[fr],
+                "flows": [fl[:, 0].contiguous(), fl[:, 1].contiguous()],
+                "masks": [mk[:, 0].contiguous(), mk[:, 1].contiguous()],
+                "mask_sums": self.mask_sums[ids],
+            },
+        }
+        return images, metadata
+
+    @classmethod
+    def from_directory(cls, path: str, meta_file: str, device=None):
+        """Load the reference's on-disk layout (see loaders/video_dataset.py) into HBM."""
+        from . import video_dataset as vd
+        ds = vd.VideoDataset(path, meta_file)
+        pairs = sorted(tuple(p) for p in ds.flow_indices)
+        frames = sorted({f for p in pairs for f in p})
+        row = {f: r for r, f in enumerate(frames)}
+        color = np.stack([vd.load_color(ds.color_fmt.format(f)).numpy() for f in frames])
+        flows = np.stack([np.stack([vd.load_flow(ds.flow_fmt.format(a, b)).numpy() for a, b in ((i, j), (j, i))])
+                          for i, j in pairs])
+        masks = np.stack([np.stack([vd.load_mask(ds.mask_fmt.format(a, b)).numpy() for a, b in ((i, j), (j, i))])
+                          for i, j in pairs])
+        return cls(color, flows, masks, ds.intrinsics.numpy()[frames], ds.extrinsics.numpy()[frames],
+                   [[row[i], row[j]] for i, j in pairs], frame_ids=frames, device=device)
+
+    @classmethod
+    def synthetic(cls, n_frames: int, H: int, W: int, flow_ops=("hierarchical2",), seed: int = 0, device=None,
+                  max_pairs: int = None):
+        """Synthetic clip with the reference's pair sampling (BASELINE configs 3/4)."""
+        from .. import synthetic as syn
+        from ..utils import frame_range as fr, frame_sampling as fs
+        video = syn.make_video(n_frames, H, W, seed)
+        rng = np.random.default_rng(seed + 1)
+        pairs = sorted(fs.SamplePairs.to_one_way(fs.sample_pairs(fr.FrameRange(fr.OptionalSet(), n_frames), flow_ops)))
+        if max_pairs:
+            pairs = pairs[:max_pairs]
+        flows = np.empty((len(pairs), 2, 2, H, W), np.float32)
+        masks = np.empty((len(pairs), 2, 1, H, W), np.float32)
+        for p, (i, j) in enumerate(pairs):
+            (f0, m0), (f1, m1) = syn.video_pair_data(video, i, j, rng)
+            flows[p, 0], flows[p, 1], masks[p, 0], masks[p, 1] = f0, f1, m0, m1
+        store = cls(video["color"], flows, masks, video["intrinsics"], video["extrinsics"],
+                    [list(p) for p in pairs], device=device)
+        store.gt_depth = video["gt_depth"]
+        return store
