@@ -12,7 +12,7 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -24,7 +24,10 @@ SIGNATURES = {
     "cd_build_info": (ctypes.c_char_p, []),
     "cd_consistency_loss_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "cd_mask_sums": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
-    "cd_consistency_loss_fwd_bwd": (c_i, [c_p] * 8 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 4 + [c_p, c_sz, c_p]),
+    "cd_tile_windows_bytes": (c_sz, [c_i, c_i, c_i]),
+    "cd_tile_windows": (c_i, [c_p] * 4 + [c_i, c_i, c_i, c_p, c_p]),
+    "cd_debug_set_overflow_capacity": (c_i, [c_i]),
+    "cd_consistency_loss_fwd_bwd": (c_i, [c_p] * 9 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 4 + [c_p, c_sz, c_p]),
     "cd_consistency_loss_fwd": (c_i, [c_p] * 8 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 3 + [c_p, c_sz, c_p]),
     "cd_profile_begin": (c_i, [c_i]),
     "cd_profile_end": (c_i, [c_p, c_p, c_i, c_p]),

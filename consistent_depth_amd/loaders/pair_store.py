@@ -17,7 +17,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ..loss.consistency_loss import mask_sums as _mask_sums
+from ..loss.consistency_loss import mask_sums as _mask_sums, tile_windows as _tile_windows
 
 
 class PairStore:
@@ -36,8 +36,13 @@ class PairStore:
         P = self.flows.shape[0]
         assert self.masks.shape[0] == P and self.pair_frames.shape == (P, 2)
         self.mask_sums = torch.empty(P, 2, dtype=torch.float32, device=dev)
+        wins = []
         for s in range(0, P, 256):
-            self.mask_sums[s:s + 256] = _mask_sums(self.masks[s:s + 256, 0].contiguous(), self.masks[s:s + 256, 1].contiguous())
+            fl = [self.flows[s:s + 256, 0].contiguous(), self.flows[s:s + 256, 1].contiguous()]
+            mk = [self.masks[s:s + 256, 0].contiguous(), self.masks[s:s + 256, 1].contiguous()]
+            self.mask_sums[s:s + 256] = _mask_sums(mk[0], mk[1])
+            wins.append(_tile_windows(fl, mk))
+        self.tile_windows = torch.cat(wins, 0)  # (P, bytes_per_pair) uint8
 
     def __len__(self):
         return self.flows.shape[0]
@@ -66,6 +71,7 @@ class PairStore:
                 "flows": [fl[:, 0].contiguous(), fl[:, 1].contiguous()],
                 "masks": [mk[:, 0].contiguous(), mk[:, 1].contiguous()],
                 "mask_sums": self.mask_sums[ids],
+                "tile_windows": self.tile_windows[ids].contiguous(),
             },
         }
         return images, metadata

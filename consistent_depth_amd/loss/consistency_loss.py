@@ -35,7 +35,22 @@ def mask_sums(mask_fwd: torch.Tensor, mask_bwd: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _launch(depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, intr, extr, lambda_r, lambda_b, mode, want_grad):
+def tile_windows(flows, masks) -> torch.Tensor:
+    """Opaque per-tile source windows of the gradient kernel for B pairs -> uint8 (B, bytes_per_pair).
+    Dataset constants like the mask sums: cache per pair, gather rows per batch (cd_tile_windows)."""
+    f0, f1, m0, m1 = _prep(flows[0]), _prep(flows[1]), _prep(masks[0]), _prep(masks[1])
+    B, _, H, W = f0.shape
+    lib = _native.lib()
+    nbytes = lib.cd_tile_windows_bytes(B, H, W)
+    out = torch.empty(B, nbytes // B, dtype=torch.uint8, device=f0.device)
+    rc = lib.cd_tile_windows(_native.dev_ptr(f0, "flows[0]"), _native.dev_ptr(f1, "flows[1]"),
+                             _native.dev_ptr(m0, "masks[0]"), _native.dev_ptr(m1, "masks[1]"), B, H, W,
+                             out.data_ptr(), _native.stream_ptr(out.device))
+    _native.check(rc, "cd_tile_windows")
+    return out
+
+
+def _launch(depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, twin, intr, extr, lambda_r, lambda_b, mode, want_grad):
     lib = _native.lib()
     B, N, H, W = depth.shape
     if N != 2:
@@ -52,25 +67,32 @@ def _launch(depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, intr, extr, lam
     reproj, disp, total = out[:B], out[B:2 * B], out[2 * B:]
     args = [_native.dev_ptr(depth, "depths"), _native.dev_ptr(flow_fwd, "flows[0]"),
             _native.dev_ptr(flow_bwd, "flows[1]"), _native.dev_ptr(mask_fwd, "masks[0]"),
-            _native.dev_ptr(mask_bwd, "masks[1]"), _native.dev_ptr(msum, "mask_sums") if msum is not None else None,
-            _native.dev_ptr(intr, "intrinsics"), _native.dev_ptr(extr, "extrinsics"),
+            _native.dev_ptr(mask_bwd, "masks[1]"), _native.dev_ptr(msum, "mask_sums") if msum is not None else None]
+    tail = [_native.dev_ptr(intr, "intrinsics"), _native.dev_ptr(extr, "extrinsics"),
             float(lambda_r), float(lambda_b), int(mode), B, H, W,
             reproj.data_ptr(), disp.data_ptr(), total.data_ptr()]
     if want_grad:
         grad = torch.empty_like(depth)
-        rc = lib.cd_consistency_loss_fwd_bwd(*args, grad.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(dev))
+        tw = None
+        if twin is not None:
+            if twin.dtype != torch.uint8 or not twin.is_cuda or not twin.is_contiguous() or \
+                    twin.numel() != lib.cd_tile_windows_bytes(B, H, W):
+                raise ValueError("tile_windows: expected the contiguous uint8 result of tile_windows() for this batch")
+            tw = twin.data_ptr()
+        rc = lib.cd_consistency_loss_fwd_bwd(*args, tw, *tail, grad.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _native.stream_ptr(dev))
         _native.check(rc, "cd_consistency_loss_fwd_bwd")
     else:
         grad = None
-        rc = lib.cd_consistency_loss_fwd(*args, ws.data_ptr(), ws.numel(), _native.stream_ptr(dev))
+        rc = lib.cd_consistency_loss_fwd(*args, *tail, ws.data_ptr(), ws.numel(), _native.stream_ptr(dev))
         _native.check(rc, "cd_consistency_loss_fwd")
     return total.reshape(()), reproj, disp, grad
 
 
 class _FusedConsistency(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, intr, extr, lambda_r, lambda_b, mode):
-        total, reproj, disp, grad = _launch(depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, intr, extr,
+    def forward(ctx, depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, twin, intr, extr, lambda_r, lambda_b, mode):
+        total, reproj, disp, grad = _launch(depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, twin, intr, extr,
                                             lambda_r, lambda_b, mode, True)
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(reproj, disp)
@@ -79,11 +101,11 @@ class _FusedConsistency(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_reproj, _g_disp):
         (grad,) = ctx.saved_tensors
-        return (grad * g_total,) + (None,) * 10
+        return (grad * g_total,) + (None,) * 11
 
 
 def consistency_loss(depths, flows, masks, intrinsics, extrinsics, lambda_reprojection, lambda_view_baseline,
-                     mask_sums=None, depth_mode=DEPTH_IDENTITY):
+                     mask_sums=None, depth_mode=DEPTH_IDENTITY, tile_windows=None):
     """Functional form.  `depths` (B,2,H,W) is the depth itself, or -- with depth_mode
     DEPTH_EXP / DEPTH_RECIPROCAL -- the raw network output whose exp / reciprocal is the depth
     (mannequin_challenge_model.py:66 / midas_v2_model.py:67 fused into the kernel)."""
@@ -92,9 +114,9 @@ def consistency_loss(depths, flows, masks, intrinsics, extrinsics, lambda_reproj
     intr, extr = _prep(intrinsics), _prep(extrinsics)
     msum = _prep(mask_sums) if mask_sums is not None else None
     if depth.requires_grad and torch.is_grad_enabled():
-        return _FusedConsistency.apply(depth, f0, f1, m0, m1, msum, intr, extr, float(lambda_reprojection),
-                                       float(lambda_view_baseline), int(depth_mode))
-    total, reproj, disp, _ = _launch(depth, f0, f1, m0, m1, msum, intr, extr, lambda_reprojection,
+        return _FusedConsistency.apply(depth, f0, f1, m0, m1, msum, tile_windows, intr, extr,
+                                       float(lambda_reprojection), float(lambda_view_baseline), int(depth_mode))
+    total, reproj, disp, _ = _launch(depth, f0, f1, m0, m1, msum, None, intr, extr, lambda_reprojection,
                                      lambda_view_baseline, depth_mode, False)
     return total, reproj, disp
 
@@ -103,8 +125,8 @@ class ConsistencyLoss(torch.nn.Module):
     """Drop-in for the reference's ConsistencyLoss (same constructor, same call, same outputs).
 
     `opt` needs .lambda_reprojection and .lambda_view_baseline.  Extension (not in the
-    reference): metadata["geometry_consistency"]["mask_sums"] (B,2), if present, is used as
-    the cached normaliser; `depth_mode` lets a model hand over its raw output.
+    reference): metadata["geometry_consistency"]["mask_sums"] (B,2) and ["tile_windows"], if present,
+    are used as cached dataset constants (normaliser / source windows of the gradient kernel); `depth_mode` lets a model hand over its raw output.
     """
 
     def __init__(self, opt, depth_mode: int = DEPTH_IDENTITY):
@@ -117,5 +139,5 @@ class ConsistencyLoss(torch.nn.Module):
         total, reproj, disp = consistency_loss(
             depths, geom["flows"], geom["masks"], metadata["intrinsics"], metadata["extrinsics"],
             self.opt.lambda_reprojection, self.opt.lambda_view_baseline,
-            mask_sums=geom.get("mask_sums"), depth_mode=self.depth_mode)
+            mask_sums=geom.get("mask_sums"), depth_mode=self.depth_mode, tile_windows=geom.get("tile_windows"))
         return total, {"reprojection": reproj, "disparity": disp}

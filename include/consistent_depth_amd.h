@@ -63,6 +63,15 @@ size_t cd_consistency_loss_workspace_bytes(int B, int H, int W);
 int cd_mask_sums(const float* mask_fwd, const float* mask_bwd, int B, int H, int W,
                  float* mask_sum, void* stream);
 
+/* Per-tile source windows of the gradient kernel (opaque, cd_tile_windows_bytes(B,H,W) bytes for B
+ * pairs).  Like the mask sums they depend only on flows and masks, i.e. on the dataset: compute them
+ * once per pair (rows of B pairs can be gathered: the layout is [B][2][tiles] x 8 bytes) and pass
+ * them to cd_consistency_loss_fwd_bwd; NULL there = recomputed on every call (one extra read of the
+ * flows and masks). */
+size_t cd_tile_windows_bytes(int B, int H, int W);
+int cd_tile_windows(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd,
+                    const float* mask_bwd, int B, int H, int W, void* tile_windows, void* stream);
+
 /*
  * Fused forward + analytic backward of ConsistencyLoss.__call__ in one pass over the
  * frame pairs (replaces geometry.py pixel_grid/pixels_to_points/reproject_points/
@@ -75,6 +84,7 @@ int cd_mask_sums(const float* mask_fwd, const float* mask_bwd, int B, int H, int
  *   mask_fwd   [B,1,H,W]  ...["masks"][0]  fp32 {0,1};  mask_bwd = ["masks"][1]
  *   mask_sum   [B,2] or NULL  precomputed cd_mask_sums(); NULL = computed here (one extra
  *                          read of the masks)
+ *   tile_windows  cd_tile_windows() result for these B pairs, or NULL = computed here
  *   intr       [B,2,4]    fx,fy,cx,cy per frame      (metadata["intrinsics"])
  *   extr       [B,2,3,4]  [R|t] camera-to-world      (metadata["extrinsics"])
  *   lambda_r / lambda_b   opt.lambda_reprojection / opt.lambda_view_baseline; a term whose
@@ -87,7 +97,7 @@ int cd_mask_sums(const float* mask_fwd, const float* mask_bwd, int B, int H, int
 int cd_consistency_loss_fwd_bwd(
     const float* depth, const float* flow_fwd, const float* flow_bwd,
     const float* mask_fwd, const float* mask_bwd, const float* mask_sum,
-    const float* intr, const float* extr,
+    const void* tile_windows, const float* intr, const float* extr,
     float lambda_r, float lambda_b, int depth_mode, int B, int H, int W,
     float* reproj, float* disp, float* total, float* grad_in,
     void* workspace, size_t workspace_bytes, void* stream);
@@ -107,6 +117,10 @@ int cd_consistency_loss_fwd(
  * size of each launch (negative = forward-only launch); it ends the session. */
 int cd_profile_begin(int max_records);
 int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out);
+
+/* Test hook: cap the gradient kernel's overflow list at `cap` records (< 0 restores the default), to
+ * force the overflow-apply and the device-side fallback paths in tests. */
+int cd_debug_set_overflow_capacity(int cap);
 
 /* utils/geometry.py:201-208 `sample`: bilinear, border padding, align_corners=False on an
  * align_corners=True style normalisation.  data [B,C,H,W], uv [B,2,H,W] px -> out [B,C,H,W]. */
