@@ -65,7 +65,7 @@ def make_pool(n, B, H, W, seed, device):
     from consistent_depth_amd import synthetic
     pool = []
     for i in range(n):
-        b = synthetic.make_pair_batch(B, H, W, seed=seed * 1000 + i)
+        b = synthetic.make_scene_batch(B, H, W, seed=seed * 1000 + i)
         rng = np.random.default_rng(seed * 1000 + i)
         images = rng.random((B, 2, 3, H, W), dtype=np.float32)
         t = lambda a: torch.tensor(a, device=device)  # noqa: E731
@@ -90,7 +90,7 @@ def loss_microbench(lib, B, H, W, iters, device):
     """Fused loss kernel at an HBM-saturating batch: per-launch ms from HIP events on the stream."""
     from consistent_depth_amd import synthetic
     from consistent_depth_amd.loss import consistency_loss as CL
-    base = synthetic.make_pair_batch(8, H, W, seed=99)
+    base = synthetic.make_scene_batch(8, H, W, seed=99)
     rep = (B + 7) // 8
     t = lambda a: torch.tensor(a, device=device).repeat((rep,) + (1,) * (a.ndim - 1))[:B].contiguous()  # noqa: E731
     depth = torch.log(t(base["depth"]))

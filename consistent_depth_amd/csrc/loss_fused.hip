@@ -123,21 +123,19 @@ __global__ __launch_bounds__(kBlock) void loss_main_kernel(
     }
 }
 
-__global__ __launch_bounds__(kBlock) void zero_guarded_kernel(float4* __restrict__ buf, size_t n4,
+__global__ __launch_bounds__(kBlock) void zero_guarded_kernel(float* __restrict__ buf, size_t n,
                                                               const int* __restrict__ run_flag) {
     if (run_flag != nullptr && *run_flag == 0) return;
+    const size_t n4 = n / 4;  // buf comes from the caller's allocator: 16-byte aligned
+    float4* b4 = reinterpret_cast<float4*>(buf);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock)
-        buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) buf[n4 * 4 + threadIdx.x] = 0.f;
 }
 
 int launch_zero_guarded(float* buf, size_t n, const int* run_flag, hipStream_t s) {
-    // n is a multiple of 2 planes; planes may have H*W % 4 != 0 only when the total still is a multiple of 2
-    const size_t n4 = n / 4;
-    hipLaunchKernelGGL(zero_guarded_kernel, dim3(1024), dim3(kBlock), 0, s, (float4*)buf, n4, run_flag);
-    if (n % 4) {
-        if (run_flag == nullptr) { if (hipMemsetAsync(buf + n4 * 4, 0, (n % 4) * sizeof(float), s) != hipSuccess) return CD_ERR_LAUNCH; }
-        else return CD_ERR_UNSUPPORTED;
-    }
+    if (reinterpret_cast<uintptr_t>(buf) % 16 != 0) return CD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(zero_guarded_kernel, dim3(1024), dim3(kBlock), 0, s, buf, n, run_flag);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 

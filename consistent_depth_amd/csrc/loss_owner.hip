@@ -114,9 +114,21 @@ __device__ __forceinline__ bool in_win(const TileWin& w, int x, int y) {
     return (unsigned)(x - w.x0) < (unsigned)w.w && (unsigned)(y - w.y0) < (unsigned)w.h;
 }
 
-__device__ __forceinline__ void ovf_push(Overflow* ovf, unsigned* oidx, float* oval, unsigned idx, float v) {
-    const int i = atomicAdd(&ovf->count, 1);
-    if (i < ovf->cap) { oidx[i] = idx; oval[i] = v; }
+// Wave-aggregated append to the overflow list: ONE returning atomic per wave per call (a same-address
+// returning atomic costs ~11 ns on this chip, so per-lane pushes would serialise).  Must be called by all
+// lanes of the wave (convergent); `need` selects the lanes that append.
+__device__ __forceinline__ void ovf_push(bool need, Overflow* ovf, unsigned* oidx, float* oval, unsigned idx, float v) {
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return;  // wave-uniform
+    const int lane = threadIdx.x & (kWave - 1);
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&ovf->count, (int)__popcll(mask));
+    base = __shfl(base, leader, kWave);
+    if (need) {
+        const int i = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+        if (i < ovf->cap) { oidx[i] = idx; oval[i] = v; }
+    }
 }
 
 template <int MODE, bool REPROJ>
@@ -170,11 +182,15 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
     const int lx = threadIdx.x & (TW - 1), ly0 = threadIdx.x / TW;
     float g_dir[ITERS];
     float acc_r = 0.f, acc_d = 0.f;
+    const unsigned base_k = (unsigned)(b * 2 + k) * (unsigned)HW;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         g_dir[it] = 0.f;
         const int ly = ly0 + it * ROWS_PER_IT;
         const int x = X0 + lx, y = Y0 + ly;
+        bool need[4] = {false, false, false, false};
+        unsigned oi[4] = {0u, 0u, 0u, 0u};
+        float ov[4] = {0.f, 0.f, 0.f, 0.f};
         if (x < W && y < H) {
             const int p = y * W + x;
             const float d = sB[(ly + 1) * SBW + lx + 1];
@@ -196,52 +212,46 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
                 const float ie = e > 0.f ? __builtin_amdgcn_rcpf(e) : 0.f;
                 g += cj.gr * m * (ex * dpx + ey * dpy) * ie;
             }
-            {
-                const Taps t = tap_coords(xf, yf, fx, fy, cj.sx, cj.sy, W, H);
-                // tap values: LDS window when inside, else L2/HBM
-                const int ra = t.ya - win.y0, rb = t.yb - win.y0, ca = t.xa - win.x0, cb = t.xb - win.x0;
-                const bool ina = (unsigned)ra < (unsigned)win.h, inb = (unsigned)rb < (unsigned)win.h;
-                const bool inca = (unsigned)ca < (unsigned)win.w, incb = (unsigned)cb < (unsigned)win.w;
-                const float d00 = (ina && inca) ? sA[ra * WMAXW + ca] : to_depth<MODE>(v_k[t.ya * W + t.xa]);
-                const float d01 = (ina && incb) ? sA[ra * WMAXW + cb] : to_depth<MODE>(v_k[t.ya * W + t.xb]);
-                const float d10 = (inb && inca) ? sA[rb * WMAXW + ca] : to_depth<MODE>(v_k[t.yb * W + t.xa]);
-                const float d11 = (inb && incb) ? sA[rb * WMAXW + cb] : to_depth<MODE>(v_k[t.yb * W + t.xb]);
-                const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
-                const float izs = __builtin_amdgcn_rcpf(zs);
-                const float dd = iZ - izs;
-                acc_d += m * fabsf(dd);
-                const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
-                const float gm = cj.gb * m * sg;
-                g -= gm * a2 * iZ * iZ;
-                const float gz = gm * izs * izs;
-                if (m != 0.f) {
-                    // will the owners of the taps' tiles (plane (b,k)) see this source?  If all four taps
-                    // share a tile (the common case) that is one table lookup.
-                    const int ta = (t.ya / TH) * tiles_x + t.xa / TW, tb = (t.yb / TH) * tiles_x + t.xb / TW;
-                    bool all_seen;
-                    if (ta == tb) {
-                        const TileWin wq = table_in_lds ? sWin[ta] : wins_k[ta];
-                        all_seen = in_win(wq, x, y);
-                    } else {
-                        all_seen = false;
-                    }
-                    if (!all_seen) {
-                        const unsigned base = (unsigned)(b * 2 + k) * (unsigned)HW;
-                        const int xs[4] = {t.xa, t.xb, t.xa, t.xb}, ys[4] = {t.ya, t.ya, t.yb, t.yb};
-                        const float ws[4] = {t.w00, t.w01, t.w10, t.w11}, ds[4] = {d00, d01, d10, d11};
+            const Taps t = tap_coords(xf, yf, fx, fy, cj.sx, cj.sy, W, H);
+            // tap values: LDS window when inside, else L2/HBM
+            const int ra = t.ya - win.y0, rb = t.yb - win.y0, ca = t.xa - win.x0, cb = t.xb - win.x0;
+            const bool ina = (unsigned)ra < (unsigned)win.h, inb = (unsigned)rb < (unsigned)win.h;
+            const bool inca = (unsigned)ca < (unsigned)win.w, incb = (unsigned)cb < (unsigned)win.w;
+            const float d00 = (ina && inca) ? sA[ra * WMAXW + ca] : to_depth<MODE>(v_k[t.ya * W + t.xa]);
+            const float d01 = (ina && incb) ? sA[ra * WMAXW + cb] : to_depth<MODE>(v_k[t.ya * W + t.xb]);
+            const float d10 = (inb && inca) ? sA[rb * WMAXW + ca] : to_depth<MODE>(v_k[t.yb * W + t.xa]);
+            const float d11 = (inb && incb) ? sA[rb * WMAXW + cb] : to_depth<MODE>(v_k[t.yb * W + t.xb]);
+            const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
+            const float izs = __builtin_amdgcn_rcpf(zs);
+            const float dd = iZ - izs;
+            acc_d += m * fabsf(dd);
+            const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+            const float gm = cj.gb * m * sg;
+            g -= gm * a2 * iZ * iZ;
+            const float gz = gm * izs * izs;
+            g_dir[it] = g * depth_jac<MODE>(d);
+            if (m != 0.f) {
+                // will the owners of the taps' tiles (plane (b,k)) see this source?  All four taps in one
+                // tile (the common case) = one table lookup.
+                const int ta = (t.ya / TH) * tiles_x + t.xa / TW, tb = (t.yb / TH) * tiles_x + t.xb / TW;
+                bool all_seen = false;
+                if (ta == tb) all_seen = in_win(table_in_lds ? sWin[ta] : wins_k[ta], x, y);
+                if (!all_seen) {
+                    const int xs[4] = {t.xa, t.xb, t.xa, t.xb}, ys[4] = {t.ya, t.ya, t.yb, t.yb};
+                    const float ws[4] = {t.w00, t.w01, t.w10, t.w11}, ds[4] = {d00, d01, d10, d11};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int tq = (ys[q] / TH) * tiles_x + xs[q] / TW;
-                            const TileWin wq = table_in_lds ? sWin[tq] : wins_k[tq];
-                            const float cval = -gz * ws[q] * depth_jac<MODE>(ds[q]);
-                            if (!in_win(wq, x, y) && cval != 0.f)
-                                ovf_push(ovf, oidx, oval, base + (unsigned)(ys[q] * W + xs[q]), cval);
-                        }
+                    for (int q = 0; q < 4; ++q) {
+                        const int tq = (ys[q] / TH) * tiles_x + xs[q] / TW;
+                        ov[q] = -gz * ws[q] * depth_jac<MODE>(ds[q]);
+                        oi[q] = base_k + (unsigned)(ys[q] * W + xs[q]);
+                        need[q] = ov[q] != 0.f && !in_win(table_in_lds ? sWin[tq] : wins_k[tq], x, y);
                     }
                 }
             }
-            g_dir[it] = g * depth_jac<MODE>(d);
         }
+        // convergent: every lane of the wave reaches these
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ovf_push(need[q], ovf, oidx, oval, oi[q], ov[q]);
     }
 
     // ---------------- phase 2: pull the scatter term from direction k sources inside the window

@@ -115,12 +115,78 @@ def make_pair_batch(B: int, H: int, W: int, seed: int = 0, noise_px: float = 0.5
     }
 
 
+# ---------------------------------------------------------------------------------------------
+# Geometrically CONSISTENT scenes: one static surface seen by every camera, so forward and
+# backward flows are mutual inverses wherever the mask is 1 -- which is what the reference's
+# flow-consistency masks certify on real video (flow.py:199-228).  `make_pair_batch` above gives
+# every frame its own unrelated depth field (flows of a pair disagree by tens of pixels); it is
+# kept as the adversarial generator for the parity tests.
+# ---------------------------------------------------------------------------------------------
+class Surface:
+    """Static scene: height field z_world = -D(x_world, y_world), D smooth in [lo, hi]."""
+
+    def __init__(self, rng: np.random.Generator, lo: float = 1.5, hi: float = 4.0, n_waves: int = 4):
+        self.k = rng.uniform(0.4, 1.2, (n_waves, 2)) * rng.choice([-1.0, 1.0], (n_waves, 2))
+        self.phase = rng.uniform(0, 2 * np.pi, n_waves)
+        a = rng.uniform(0.3, 1.0, n_waves)
+        self.amp = a / a.sum() * (hi - lo) / 2.0
+        self.mid = (hi + lo) / 2.0
+
+    def depth_below(self, x, y):
+        d = np.full_like(x, self.mid)
+        for (kx, ky), ph, a in zip(self.k, self.phase, self.amp):
+            d = d + a * np.sin(kx * x + ky * y + ph)
+        return d
+
+
+def render_depth(surface: Surface, intr, extr, H: int, W: int, iters: int = 12) -> np.ndarray:
+    """Depth map (distance along the camera's -z) of the surface: fixed-point ray/height-field
+    intersection (the surface is gentle, the iteration contracts)."""
+    y, x = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    fx, fy, cx, cy = intr
+    ray = np.stack([(x - cx) / fx, -(y - cy) / fy, -np.ones_like(x)], 0)
+    R, t = extr[:, :3], extr[:, 3]
+    d = np.einsum("ij,jhw->ihw", R, ray)  # world direction, d[2] < 0
+    s = np.full((H, W), surface.mid)
+    for _ in range(iters):
+        px, py = t[0] + s * d[0], t[1] + s * d[1]
+        s = (surface.depth_below(px, py) + t[2]) / (-d[2])
+    return s
+
+
+def make_scene_batch(B: int, H: int, W: int, seed: int = 0, noise_px: float = 0.25, mask_keep: float = 0.7,
+                     depth_jitter: float = 0.05, frame_gap: int = 4, dtype=np.float32) -> dict:
+    """Like make_pair_batch, but both frames of a pair look at ONE surface (consistent flows)."""
+    rng = np.random.default_rng(seed)
+    K = clip_intrinsics(H, W)
+    depth = np.zeros((B, 2, H, W))
+    flows = [np.zeros((B, 2, H, W)), np.zeros((B, 2, H, W))]
+    masks = [np.zeros((B, 1, H, W)), np.zeros((B, 1, H, W))]
+    extr = np.zeros((B, 2, 3, 4))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for b in range(B):
+        surf = Surface(rng)
+        path = camera_path(frame_gap + 1, rng, max_angle=0.1)
+        extr[b, 0], extr[b, 1] = path[0], path[frame_gap]
+        gt = [render_depth(surf, K, extr[b, k], H, W) for k in range(2)]
+        for k in range(2):
+            f = reprojection_flow(gt[k], K, extr[b, k], K, extr[b, 1 - k]) + rng.normal(0, noise_px, (2, H, W))
+            flows[k][b] = f
+            inb = ((xx + f[0] >= 0) & (xx + f[0] <= W - 1) & (yy + f[1] >= 0) & (yy + f[1] <= H - 1))
+            masks[k][b, 0] = (rng.random((H, W)) < mask_keep) & inb
+            depth[b, k] = gt[k] * np.exp(smooth_field(H, W, rng, -depth_jitter, depth_jitter))
+    return {"depth": depth.astype(dtype), "flows": [f.astype(dtype) for f in flows],
+            "masks": [m.astype(dtype) for m in masks], "intrinsics": np.tile(K, (B, 2, 1)).astype(dtype),
+            "extrinsics": extr.astype(dtype)}
+
+
 def make_video(n_frames: int, H: int, W: int, seed: int = 0):
     """A whole synthetic clip: colours (N,3,H,W) U[0,1), GT depth (N,H,W), cameras."""
     rng = np.random.default_rng(seed)
     K = clip_intrinsics(H, W)
-    extr = camera_path(n_frames, rng)
-    depth = np.stack([smooth_field(H, W, rng, 0.5, 4.0) for _ in range(n_frames)])
+    extr = camera_path(n_frames, rng, step=0.01, max_angle=0.15)
+    surf = Surface(rng)
+    depth = np.stack([render_depth(surf, K, extr[i], H, W) for i in range(n_frames)])
     color = rng.random((n_frames, 3, H, W), dtype=np.float32)
     return {"color": color, "gt_depth": depth, "intrinsics": np.tile(K, (n_frames, 1)),
             "extrinsics": extr}

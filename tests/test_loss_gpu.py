@@ -50,10 +50,14 @@ def test_golden_vectors(torch_cuda, oracle, name):
     assert oracle.rel_l1(grad, ref64["grad_depth"]) < tol
 
 
+@pytest.mark.parametrize("gen", ["scene", "unrelated"])
 @pytest.mark.parametrize("H,W", [(384, 224), (224, 384)])
-def test_baseline_size_vs_oracle(torch_cuda, oracle, H, W):
+def test_baseline_size_vs_oracle(torch_cuda, oracle, H, W, gen):
+    """BASELINE size (B=4, 384x224 and its transpose) on consistent-scene data (what real video looks
+    like: the owner kernel's windows see every source) and on the adversarial generator (unrelated
+    depth per frame: a few % of the scatter goes through the overflow list)."""
     from consistent_depth_amd import synthetic
-    batch = synthetic.make_pair_batch(4, H, W, seed=11)
+    batch = (synthetic.make_scene_batch if gen == "scene" else synthetic.make_pair_batch)(4, H, W, seed=11)
     ref = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"],
                                   batch["extrinsics"], 1.0, 0.1, dtype=np.float64)
     total, reproj, disp, grad = _run(torch_cuda, batch, 1.0, 0.1)

@@ -25,14 +25,16 @@ def main():
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--mode", type=int, default=1)
-    ap.add_argument("--noise-px", type=float, default=0.5)
+    ap.add_argument("--noise-px", type=float, default=0.25)
+    ap.add_argument("--inconsistent", action="store_true", help="adversarial generator: unrelated depth per frame")
     args = ap.parse_args()
     from consistent_depth_amd import _native, synthetic
     from consistent_depth_amd.loss import consistency_loss as CL
     lib = _native.lib()
     dev = torch.device("cuda", 0)
     H, W = args.height, args.width
-    base = synthetic.make_pair_batch(8, H, W, seed=99, noise_px=args.noise_px)
+    gen = synthetic.make_pair_batch if args.inconsistent else synthetic.make_scene_batch
+    base = gen(8, H, W, seed=99, noise_px=args.noise_px)
     res = []
     for B in [int(b) for b in args.batches.split(",")]:
         rep = (B + 7) // 8
