@@ -1,0 +1,272 @@
+// Direct 2-D convolution on the gfx950 matrix cores in exact fp32
+// (v_mfma_f32_16x16x4_f32: bitwise a k-ordered fmaf chain, 157 TFLOP/s peak -- there is no
+// TF32/xf32 on CDNA4 and the reference computes in fp32, so no precision is traded).
+//
+// Replaces the nn.Conv2d forward / input-gradient launches of the (un-vendored) hourglass
+// (/root/reference/monodepth/mannequin_challenge_model.py:60 -> netG.forward; architecture
+// SURVEY.md appendix A.3): stride 1, "same" zero padding, k in {1,3,5,7,11}, NCHW fp32.
+//
+// Mapping (implicit GEMM, no im2col buffer):  M = 16 consecutive output pixels of one row,
+// N = 16 output channels, K = 4 input channels of ONE filter tap (ky,kx).
+//   A[i = lane&15][k = lane>>4] = in[ci0+k][y+ky][x0+i+kx]   (LDS input tile with halo; the 16
+//                                  pixels are contiguous, the 4 channels sit 16 banks apart)
+//   B[k = lane>>4][j = lane&15] = w[co0+j][ci0+k][ky][kx]     (LDS, pre-packed [tap][ci][co])
+//   D: lane holds channel co0+(lane&15), pixels x0+4*(lane>>4)+{0..3}  -> one 16-byte store.
+// A block (4 waves) owns a TY x 32 output tile of one image for CO_T*16 output channels; each wave
+// keeps (TY/4 rows x 2) M-tiles x CO_T N-tiles of accumulators in registers and walks the taps
+// with immediate LDS offsets; input channels are streamed through LDS in chunks of CI_CHUNK.
+//
+// Fusions: the producer's BatchNorm-apply + ReLU is applied while the input tile is staged
+// (per-channel scale/shift), and the per-channel sum / sum-of-squares of the raw output (the batch
+// statistics the FOLLOWING train-mode BatchNorm needs) are accumulated in the epilogue -- so a
+// conv+BN+ReLU chain never makes a separate pass over the activations.
+// The input-gradient convolution (dgrad) is the same kernel on flipped/transposed packed weights.
+#include "cd_common.h"
+
+namespace cd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CV_TX = 32;  // output tile width (2 M-tiles)
+
+template <int KS> struct ConvCfg {
+    static constexpr int TY = (KS >= 7) ? 16 : 8;          // output rows per block (4 waves x TY/4 rows)
+    static constexpr int CI_CHUNK = (KS >= 7) ? 4 : 8;     // input channels staged per round
+    static constexpr int RS = CV_TX + KS - 1;              // LDS row stride (floats)
+    static constexpr int ROWS = TY + KS - 1;
+    static constexpr int PLANE_RAW = ROWS * RS;
+    // plane stride == 16 (mod 32): the 4 channels of an A fragment hit disjoint bank halves
+    static constexpr int PS = PLANE_RAW + ((16 - (PLANE_RAW % 32)) + 32) % 32;
+};
+
+__host__ __device__ constexpr int co_stride_padded(int cob) { return (cob % 32 == 0) ? cob + 16 : cob; }
+
+// ---------------------------------------------------------------- weight packing
+// w [Cout][Cin][KS][KS] -> packed [co_group][ci_chunk][tap][ci_in_chunk][COBP]  (zero padded)
+// flip_transpose: build the dgrad filter  w'[ci][co][KS-1-ky][KS-1-kx]  instead (roles of Cin/Cout swap).
+__global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int KS, int ci_chunk, int cob,
+                                    int cobp, int flip_transpose, float* __restrict__ out, size_t total) {
+    // logical conv: out-channels OC, in-channels IC
+    const int OC = flip_transpose ? Cin : Cout, IC = flip_transpose ? Cout : Cin;
+    const int taps = KS * KS;
+    const int n_chunks = (IC + ci_chunk - 1) / ci_chunk;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int j = (int)(r % cobp); r /= cobp;
+        const int cc = (int)(r % ci_chunk); r /= ci_chunk;
+        const int tap = (int)(r % taps); r /= taps;
+        const int chunk = (int)(r % n_chunks); r /= n_chunks;
+        const int grp = (int)r;
+        const int oc = grp * cob + j, ic = chunk * ci_chunk + cc;
+        float v = 0.f;
+        if (j < cob && oc < OC && ic < IC) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            if (!flip_transpose) v = w[(((size_t)oc * Cin + ic) * KS + ky) * KS + kx];
+            else v = w[(((size_t)ic * Cin + oc) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)];
+        }
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- the convolution
+template <int KS, int CO_T>
+__global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
+    const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
+    const float* __restrict__ wpk, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
+    float* __restrict__ y, int y_ctot, int y_coff, int Cout,
+    double* __restrict__ stats, int H, int W, int tiles_x) {
+    using Cfg = ConvCfg<KS>;
+    constexpr int TY = Cfg::TY, CI = Cfg::CI_CHUNK, RS = Cfg::RS, PS = Cfg::PS, ROWS = Cfg::ROWS;
+    constexpr int P = (KS - 1) / 2, TAPS = KS * KS;
+    constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
+    constexpr int RPW = TY / 4;          // output rows per wave
+    constexpr int MT = RPW * 2;          // M-tiles per wave
+    constexpr int W_ELEMS = TAPS * CI * COBP;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;                  // [CI][PS]
+    float* s_w = smem + CI * PS;         // [TAPS][CI][COBP]
+
+    const int tile = blockIdx.x, grp = blockIdx.y, n = blockIdx.z;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int X0 = tx * CV_TX, Y0 = ty * TY;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t HW = (size_t)H * W;
+    const float* xin = x + ((size_t)n * x_ctot + x_coff) * HW;
+    const int n_chunks = (Cin + CI - 1) / CI;
+
+    f32x4 acc[MT][CO_T];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < CO_T; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_lane = (lane >> 4) * PS + (lane & 15);      // A fragment: channel k = lane>>4, pixel i = lane&15
+    const int b_lane = (lane >> 4) * COBP + (lane & 15);    // B fragment: channel k, out-channel j
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        __syncthreads();  // previous round's fragments are consumed
+        // ---- stage the input tile (zero padding, fused BN-apply + ReLU of the producer)
+        for (int i = threadIdx.x; i < CI * ROWS * RS; i += kBlock) {
+            const int cc = i / (ROWS * RS), rem = i - cc * (ROWS * RS);
+            const int r = rem / RS, c = rem - r * RS;
+            const int ci = chunk * CI + cc, gy = Y0 - P + r, gx = X0 - P + c;
+            float v = 0.f;
+            if (ci < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                v = xin[(size_t)ci * HW + (size_t)gy * W + gx];
+                if (in_scale) v = v * in_scale[ci] + in_shift[ci];
+                if (in_relu) v = fmaxf(v, 0.f);
+            }
+            s_in[cc * PS + r * RS + c] = v;
+        }
+        // ---- stage this chunk's packed weights (one contiguous block)
+        const float* wsrc = wpk + ((size_t)grp * n_chunks + chunk) * W_ELEMS;
+        for (int i = threadIdx.x * 4; i < W_ELEMS; i += kBlock * 4)
+            *reinterpret_cast<float4*>(s_w + i) = *reinterpret_cast<const float4*>(wsrc + i);
+        __syncthreads();
+
+        // ---- MFMA over (channel quad, tap)
+#pragma unroll
+        for (int c4 = 0; c4 < CI / 4; ++c4) {
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    float bf[CO_T];
+#pragma unroll
+                    for (int t = 0; t < CO_T; ++t) bf[t] = s_w[((ky * KS + kx) * CI + c4 * 4) * COBP + t * 16 + b_lane];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int row = wid * RPW + (m >> 1), ct = m & 1;
+                        const float af = s_in[c4 * 4 * PS + (row + ky) * RS + ct * 16 + kx + a_lane];
+#pragma unroll
+                        for (int t = 0; t < CO_T; ++t)
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[t], acc[m][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, store, batch statistics of the raw output
+    const int co_l = lane & 15, px4 = (lane >> 4) * 4;
+    float* yout = y + ((size_t)n * y_ctot + y_coff) * HW;
+#pragma unroll
+    for (int t = 0; t < CO_T; ++t) {
+        const int co = grp * COB + t * 16 + co_l;
+        const float bv = (bias != nullptr && co < Cout) ? bias[co] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int gy = Y0 + wid * RPW + (m >> 1), gx = X0 + (m & 1) * 16 + px4;
+            f32x4 v = acc[m][t];
+            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+            if (co < Cout && gy < H) {
+                float* dst = yout + (size_t)co * HW + (size_t)gy * W + gx;
+                if (gx + 3 < W && ((W & 3) == 0)) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v.x, v.y, v.z, v.w);
+                    s1 += v.x + v.y + v.z + v.w;
+                    s2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (gx + q < W) { dst[q] = e[q]; s1 += e[q]; s2 += e[q] * e[q]; }
+                }
+            }
+        }
+        if (stats != nullptr) {  // block-uniform
+            // lanes l, l+16, l+32, l+48 hold the same channel
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 16 && co < Cout) {
+                atomicAdd(&stats[2 * (y_coff + co)], (double)s1);
+                atomicAdd(&stats[2 * (y_coff + co) + 1], (double)s2);
+            }
+        }
+    }
+}
+
+template <int KS, int CO_T>
+static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wpk, const float* bias,
+                         const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff,
+                         int Cout, double* stats, int N, int H, int W, hipStream_t s) {
+    using Cfg = ConvCfg<KS>;
+    constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
+    const int tiles_x = (W + CV_TX - 1) / CV_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
+    const int groups = (Cout + COB - 1) / COB;
+    const size_t lds = sizeof(float) * ((size_t)Cfg::CI_CHUNK * Cfg::PS + (size_t)KS * KS * Cfg::CI_CHUNK * COBP);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<KS, CO_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T>), dim3(tiles_x * tiles_y, groups, N), dim3(kBlock), lds, s, x, x_ctot,
+                       x_coff, Cin, wpk, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, H, W, tiles_x);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+// number of 16-wide output-channel tiles a block handles for a given (k, Cout)
+static inline int pick_co_tiles(int ks, int cout) {
+    const int need = (cout + 15) / 16;
+    int cap = (ks >= 11) ? 2 : 4;  // LDS: 121 taps x CI x COBP floats
+    int t = need < cap ? need : cap;
+    if (t == 3) t = 4;
+    return t < 1 ? 1 : t;
+}
+
+}  // namespace cd
+
+extern "C" {
+
+size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed) {
+    if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
+    const int OC = transposed ? Cin : Cout, IC = transposed ? Cout : Cin;
+    const int cot = cd::pick_co_tiles(ks, OC), cob = cot * 16, cobp = cd::co_stride_padded(cob);
+    const int ci_chunk = ks >= 7 ? 4 : 8;
+    const int groups = (OC + cob - 1) / cob, chunks = (IC + ci_chunk - 1) / ci_chunk;
+    return (size_t)groups * chunks * ks * ks * ci_chunk * cobp;
+}
+
+int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transposed, float* packed, void* stream) {
+    const size_t total = cd_conv2d_packed_weight_floats(Cout, Cin, ks, transposed);
+    if (!w || !packed || total == 0) return CD_ERR_INVALID_ARG;
+    const int OC = transposed ? Cin : Cout;
+    const int cot = cd::pick_co_tiles(ks, OC), cob = cot * 16, cobp = cd::co_stride_padded(cob);
+    const int ci_chunk = ks >= 7 ? 4 : 8;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cd::pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ks,
+                       ci_chunk, cob, cobp, transposed, packed, total);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w, const float* bias,
+                  const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout,
+                  double* stats, int N, int H, int W, int ks, void* stream) {
+    if (!x || !packed_w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD_ERR_INVALID_ARG;
+    if (x_coff < 0 || x_coff + Cin > x_ctot || y_coff < 0 || y_coff + Cout > y_ctot) return CD_ERR_INVALID_ARG;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return CD_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int cot = cd::pick_co_tiles(ks, Cout);
+#define CD_CONV(K, T) return cd::launch_conv_t<K, T>(x, x_ctot, x_coff, Cin, packed_w, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, N, H, W, s)
+#define CD_CONV_K(K)                     \
+    if (ks == K) {                       \
+        if (cot == 1) CD_CONV(K, 1);     \
+        if (cot == 2) CD_CONV(K, 2);     \
+        if (cot == 4) CD_CONV(K, 4);     \
+    }
+    CD_CONV_K(1) CD_CONV_K(3) CD_CONV_K(5) CD_CONV_K(7)
+    if (ks == 11) {
+        if (cot == 1) CD_CONV(11, 1);
+        if (cot == 2) CD_CONV(11, 2);
+    }
+#undef CD_CONV_K
+#undef CD_CONV
+    return CD_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"
