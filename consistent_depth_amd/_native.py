@@ -32,6 +32,9 @@ SIGNATURES = {
     "cd_profile_begin": (c_i, [c_i]),
     "cd_profile_end": (c_i, [c_p, c_p, c_i, c_p]),
     "cd_sample_bilinear_border": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "cd_conv2d_packed_weight_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "cd_conv2d_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "cd_conv2d_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_adam_step_flat": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
     "cd_adam_step_flat_guarded": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p]),
     "cd_l1_distance_workspace_bytes": (c_sz, [c_sz]),

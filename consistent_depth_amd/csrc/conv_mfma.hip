@@ -211,7 +211,7 @@ static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const 
 // number of 16-wide output-channel tiles a block handles for a given (k, Cout)
 static inline int pick_co_tiles(int ks, int cout) {
     const int need = (cout + 15) / 16;
-    int cap = (ks >= 11) ? 2 : 4;  // LDS: 121 taps x CI x COBP floats
+    int cap = (ks >= 11) ? 1 : 4;  // LDS: 121 taps x CI x COBP floats must leave room for >= 2 blocks per CU
     int t = need < cap ? need : cap;
     if (t == 3) t = 4;
     return t < 1 ? 1 : t;
@@ -260,10 +260,7 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
         if (cot == 4) CD_CONV(K, 4);     \
     }
     CD_CONV_K(1) CD_CONV_K(3) CD_CONV_K(5) CD_CONV_K(7)
-    if (ks == 11) {
-        if (cot == 1) CD_CONV(11, 1);
-        if (cot == 2) CD_CONV(11, 2);
-    }
+    if (ks == 11 && cot == 1) CD_CONV(11, 1);
 #undef CD_CONV_K
 #undef CD_CONV
     return CD_ERR_UNSUPPORTED;

@@ -128,6 +128,31 @@ int cd_sample_bilinear_border(const float* data, const float* uv, int B, int C, 
                               float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Depth CNN layers (reference: the un-vendored Mannequin-Challenge hourglass called at
+ * monodepth/mannequin_challenge_model.py:60; architecture SURVEY.md appendix A.3).
+ * All tensors NCHW fp32; a tensor argument is (pointer, total channels of the buffer it lives in,
+ * channel offset) so layers read/write channel slices of concat buffers in place.
+ * ---------------------------------------------------------------------------------- */
+
+/* Convolution weights are consumed in a packed, zero-padded layout.  transposed = 0 packs the
+ * forward filter of w[Cout][Cin][ks][ks]; transposed = 1 packs the input-gradient filter
+ * (flipped, in/out swapped) of the same w, so dgrad is cd_conv2d_fwd on the output gradient. */
+size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed);
+int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transposed, float* packed,
+                           void* stream);
+
+/* y[:, y_coff : y_coff+Cout] = conv2d(act(x[:, x_coff : x_coff+Cin]), w) + bias, stride 1, zero
+ * padding (ks-1)/2, ks in {1,3,5,7,11}, on the fp32 matrix cores (exact fp32).
+ *   act(v) = relu?(v * in_scale[c] + in_shift[c])   when in_scale/in_shift are given (the producer's
+ *            BatchNorm-apply [+ReLU] fused into the load), relu only when in_relu and no scale, else v;
+ *   stats (optional, [y_ctot][2] doubles, caller-zeroed): per-channel sum and sum of squares of the
+ *            raw output are ADDED -- the batch statistics of the following train-mode BatchNorm. */
+int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w,
+                  const float* bias, const float* in_scale, const float* in_shift, int in_relu,
+                  float* y, int y_ctot, int y_coff, int Cout, double* stats,
+                  int N, int H, int W, int ks, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Optimiser (reference: optimizer/__init__.py:16-17 -> torch.optim.Adam,
  * depth_fine_tuning.py:231-236,283; betas (0.9,0.999), eps 1e-8, no weight decay)
  * ---------------------------------------------------------------------------------- */

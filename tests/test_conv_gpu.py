@@ -1,0 +1,83 @@
+"""GPU parity of the fp32-MFMA convolution against torch.nn.functional.conv2d on the CPU
+(fp64 reference; the kernel is an exact-fp32 fmaf chain, so the tolerance is fp32 round-off of a
+K-long dot product)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, Cin, Cout, H, W, ks
+    (2, 3, 128, 24, 40, 7),      # stem shape (Cin not a multiple of the channel chunk)
+    (2, 64, 16, 20, 33, 11),     # the dominant 11x11 64->16 (odd width)
+    (1, 64, 32, 32, 48, 11),
+    (2, 32, 32, 17, 31, 7),
+    (2, 64, 64, 16, 32, 7),
+    (2, 32, 64, 16, 24, 5),
+    (2, 64, 32, 24, 32, 3),
+    (2, 128, 64, 16, 40, 1),
+    (2, 256, 32, 12, 16, 1),
+    (1, 64, 1, 24, 40, 3),       # prediction head (Cout = 1)
+    (1, 16, 64, 20, 36, 11),     # a dgrad-shaped case
+]
+
+
+def _ref(x, w, b, ks):
+    import torch
+    return torch.nn.functional.conv2d(x.double(), w.double(), b.double() if b is not None else None, padding=(ks - 1) // 2)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", CASES)
+def test_conv_fwd_matches_torch(N, Cin, Cout, H, W, ks):
+    import torch
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator().manual_seed(ks * 1000 + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    ref = _ref(x, w, b, ks)
+    pk = conv.pack_weights(w.cuda())
+    y = conv.conv2d(x.cuda(), pk, Cin, Cout, ks, bias=b.cuda())
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv_channel_slices_fused_input_and_stats():
+    """Reads a channel slice, applies the producer's BN-apply+ReLU on load, writes into a slice of a
+    concat buffer and accumulates the batch statistics of the raw output."""
+    import torch
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator().manual_seed(7)
+    N, H, W, ks = 2, 20, 36, 5
+    xbuf = torch.randn(N, 48, H, W, generator=g)
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    w = torch.randn(24, 32, ks, ks, generator=g) / np.sqrt(32 * ks * ks)
+    b = torch.randn(24, generator=g)
+    xin = torch.relu(xbuf[:, 8:40] * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = _ref(xin, w, b, ks)
+    out = torch.full((N, 40, H, W), 7.0).cuda()
+    stats = torch.zeros(40, 2, dtype=torch.float64).cuda()
+    conv.conv2d(xbuf.cuda(), conv.pack_weights(w.cuda()), 32, 24, ks, bias=b.cuda(), x_coff=8, out=out, y_coff=10,
+                in_scale=scale.cuda(), in_shift=shift.cuda(), in_relu=True, stats=stats.view(-1))
+    o = out.cpu()
+    assert (o[:, :10] == 7).all() and (o[:, 34:] == 7).all()
+    assert (o[:, 10:34].double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    s = stats.cpu()
+    np.testing.assert_allclose(s[10:34, 0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[10:34, 1].numpy(), (ref ** 2).sum((0, 2, 3)).numpy(), rtol=1e-5)
+    assert (s[:10] == 0).all() and (s[34:] == 0).all()
+
+
+@pytest.mark.parametrize("Cin,Cout,ks", [(64, 16, 11), (32, 32, 7), (128, 64, 1), (3, 128, 7)])
+def test_dgrad_is_conv_with_transposed_filter(Cin, Cout, ks):
+    import torch
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator().manual_seed(ks + Cin)
+    N, H, W = 2, 18, 34
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g, dtype=torch.float64) / np.sqrt(Cin * ks * ks)
+    dy = torch.randn(N, Cout, H, W, generator=g, dtype=torch.float64)
+    torch.nn.functional.conv2d(x, w, padding=(ks - 1) // 2).backward(dy)
+    pk = conv.pack_weights(w.float().cuda(), transposed=True)
+    dx = conv.conv2d(dy.float().cuda(), pk, Cout, Cin, ks)
+    assert (dx.cpu().double() - x.grad).abs().max().item() < 2e-5 * x.grad.abs().max().item()

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-shape throughput of the MFMA convolution on the hourglass's dominant shapes (batch of 8 images)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SHAPES = [  # H, W, ks, Cin, Cout, share of forward MACs
+    (384, 224, 11, 64, 16, 20.2), (192, 112, 11, 64, 32, 10.1), (192, 112, 7, 64, 32, 8.2), (384, 224, 7, 64, 16, 8.2),
+    (192, 112, 7, 32, 32, 6.1), (96, 56, 11, 64, 64, 5.0), (384, 224, 1, 128, 64, 4.0), (192, 112, 5, 32, 32, 3.1),
+    (384, 224, 7, 3, 128, 3.1), (96, 56, 7, 32, 64, 3.1), (192, 112, 1, 128, 32, 2.8), (192, 112, 3, 64, 32, 1.5),
+    (48, 28, 7, 32, 64, 1.3), (24, 14, 7, 32, 64, 0.1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--torch", action="store_true", help="also time torch (MIOpen) on the same shape")
+    ap.add_argument("--only", type=int, default=-1)
+    args = ap.parse_args()
+    from consistent_depth_amd.ops import conv
+    N = 8
+    for i, (H, W, ks, Cin, Cout, share) in enumerate(SHAPES):
+        if args.only >= 0 and i != args.only:
+            continue
+        x = torch.randn(N, Cin, H, W, device="cuda")
+        w = torch.randn(Cout, Cin, ks, ks, device="cuda") * 0.05
+        b = torch.zeros(Cout, device="cuda")
+        pk = conv.pack_weights(w)
+        out = torch.empty(N, Cout, H, W, device="cuda")
+        flops = 2.0 * N * H * W * Cin * ks * ks * Cout
+
+        def timeit(fn):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / args.iters
+
+        ms = timeit(lambda: conv.conv2d(x, pk, Cin, Cout, ks, bias=b, out=out))
+        rec = {"shape": [H, W, ks, Cin, Cout], "share_pct": share, "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1)}
+        if args.torch:
+            ms_t = timeit(lambda: torch.nn.functional.conv2d(x, w, b, padding=(ks - 1) // 2))
+            rec["torch_ms"] = round(ms_t, 4)
+            rec["torch_TFLOPs"] = round(flops / ms_t / 1e9, 1)
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
