@@ -14,7 +14,11 @@
 //              bilinear taps come from the LDS window,
 //     phase 2  PULLS the scatter term: re-evaluates direction k for the sources p inside the
 //              window (depth from LDS, flow/mask from L2/HBM) and adds the tap contributions
-//              that land inside T into an LDS accumulator (ds_add_f32),
+//              that land inside T into an LDS accumulator.  The accumulator is 64-bit FIXED POINT
+//              (2^-40 units, |value| < 2048, ds_add_u64): on gfx950 ds_add_f32 retires ~1 lane
+//              per 3 clocks (185 CU-cycles per wave instruction, profiles/lds_atomics_exp_r01.txt)
+//              while integer LDS atomics run at full rate (5 cycles) -- and integer addition is
+//              associative, so the scatter sum is bit-reproducible,
 //     phase 3  writes grad[b, j, T] = direct + scatter with plain coalesced stores.
 //
 // The window is a per-tile prediction: the bounding box of where T's own (valid) pixels sample
@@ -109,6 +113,20 @@ __global__ __launch_bounds__(kBlock) void tile_window_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------- fixed-point scatter accumulator
+constexpr double FX_ONE = 1099511627776.0;           // 2^40
+constexpr double FX_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: adding it rounds to an integer in the low mantissa bits
+constexpr float FX_LIMIT = 2047.f;                   // saturation (|x| * 2^40 must stay below 2^51)
+
+__device__ __forceinline__ unsigned long long to_fixed(float c) {
+    c = fminf(fmaxf(c, -FX_LIMIT), FX_LIMIT);
+    const double d = __fma_rn((double)c, FX_ONE, FX_MAGIC);
+    return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(FX_MAGIC));
+}
+__device__ __forceinline__ float from_fixed(unsigned long long v) {
+    return (float)((double)(long long)v * (1.0 / FX_ONE));
+}
+
 // ---------------------------------------------------------------- the owner kernel
 __device__ __forceinline__ bool in_win(const TileWin& w, int x, int y) {
     return (unsigned)(x - w.x0) < (unsigned)w.w && (unsigned)(y - w.y0) < (unsigned)w.h;
@@ -139,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
     float* __restrict__ grad, Overflow* ovf, unsigned* __restrict__ oidx, float* __restrict__ oval) {
     __shared__ float sA[WMAXH * WMAXW];   // depth of frame k over the window
     __shared__ float sB[SBH * SBW];       // depth of frame j over T + halo
-    __shared__ float sG[TH * TW];         // scatter accumulator for T
+    __shared__ unsigned long long sG[TH * TW];  // scatter accumulator for T, 2^-40 fixed point
     __shared__ TileWin sWin[MAXT_LDS];    // windows of plane (b,k)'s owners (in frame-j coordinates)
     __shared__ float red[kBlock / kWave];
 
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
         const int y = min(max(Y0 - 1 + r, 0), H - 1), x = min(max(X0 - 1 + c, 0), W - 1);
         sB[i] = to_depth<MODE>(v_j[y * W + x]);
     }
-    for (int i = threadIdx.x; i < TH * TW; i += kBlock) sG[i] = 0.f;
+    for (int i = threadIdx.x; i < TH * TW; i += kBlock) sG[i] = 0ull;
     if (table_in_lds)
         for (int i = threadIdx.x; i < ntiles; i += kBlock) sWin[i] = wins_k[i];
     __syncthreads();
@@ -188,70 +206,70 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
         g_dir[it] = 0.f;
         const int ly = ly0 + it * ROWS_PER_IT;
         const int x = X0 + lx, y = Y0 + ly;
-        bool need[4] = {false, false, false, false};
-        unsigned oi[4] = {0u, 0u, 0u, 0u};
-        float ov[4] = {0.f, 0.f, 0.f, 0.f};
-        if (x < W && y < H) {
-            const int p = y * W + x;
-            const float d = sB[(ly + 1) * SBW + lx + 1];
-            const float m = mk_j[p], fx = fl_j[p], fy = fl_j[HW + p];
-            const float xf = (float)x, yf = (float)y;
-            const float r0 = (xf - cj.cx_r) * cj.ifx_r, r1 = -(yf - cj.cy_r) * cj.ify_r;
-            const float a0 = cj.M[0] * r0 + cj.M[1] * r1 - cj.M[2];
-            const float a1 = cj.M[3] * r0 + cj.M[4] * r1 - cj.M[5];
-            const float a2 = cj.M[6] * r0 + cj.M[7] * r1 - cj.M[8];
-            const float X = d * a0 + cj.c[0], Y = d * a1 + cj.c[1], Z = d * a2 + cj.c[2];
-            const float iZ = __builtin_amdgcn_rcpf(Z);
-            float g = 0.f;
-            if (REPROJ) {
-                const float mx = xf + fx, my = yf + fy;
-                const float ex = (cj.cx_t - cj.fx_t * X * iZ) - mx, ey = (cj.cy_t + cj.fy_t * Y * iZ) - my;
-                const float e = __builtin_amdgcn_sqrtf(ex * ex + ey * ey);
-                acc_r += m * e;
-                const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
-                const float ie = e > 0.f ? __builtin_amdgcn_rcpf(e) : 0.f;
-                g += cj.gr * m * (ex * dpx + ey * dpy) * ie;
-            }
-            const Taps t = tap_coords(xf, yf, fx, fy, cj.sx, cj.sy, W, H);
-            // tap values: LDS window when inside, else L2/HBM
-            const int ra = t.ya - win.y0, rb = t.yb - win.y0, ca = t.xa - win.x0, cb = t.xb - win.x0;
+        const bool valid = x < W && y < H;
+        const int p = valid ? y * W + x : 0;
+        const float d = sB[(ly + 1) * SBW + lx + 1];
+        const float m = valid ? mk_j[p] : 0.f;
+        const float fx = fl_j[p], fy = fl_j[HW + p];
+        const float xf = (float)x, yf = (float)y;
+        const float r0 = (xf - cj.cx_r) * cj.ifx_r, r1 = -(yf - cj.cy_r) * cj.ify_r;
+        const float a0 = cj.M[0] * r0 + cj.M[1] * r1 - cj.M[2];
+        const float a1 = cj.M[3] * r0 + cj.M[4] * r1 - cj.M[5];
+        const float a2 = cj.M[6] * r0 + cj.M[7] * r1 - cj.M[8];
+        const float X = d * a0 + cj.c[0], Y = d * a1 + cj.c[1], Z = d * a2 + cj.c[2];
+        const float iZ = __builtin_amdgcn_rcpf(Z);
+        float g = 0.f;
+        if (REPROJ) {
+            const float mx = xf + fx, my = yf + fy;
+            const float ex = (cj.cx_t - cj.fx_t * X * iZ) - mx, ey = (cj.cy_t + cj.fy_t * Y * iZ) - my;
+            const float e = __builtin_amdgcn_sqrtf(ex * ex + ey * ey);
+            acc_r += m * e;
+            const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
+            const float ie = e > 0.f ? __builtin_amdgcn_rcpf(e) : 0.f;
+            g += cj.gr * m * (ex * dpx + ey * dpy) * ie;
+        }
+        const Taps t = tap_coords(xf, yf, fx, fy, cj.sx, cj.sy, W, H);
+        // tap values: the LDS window when the whole wave's taps are inside it (the common case), else per tap
+        const int ra = t.ya - win.y0, ca = t.xa - win.x0, dyb = t.yb - t.ya, dxb = t.xb - t.xa;
+        const bool inside = (unsigned)ra < (unsigned)max(win.h - dyb, 0) && (unsigned)ca < (unsigned)max(win.w - dxb, 0);
+        float d00, d01, d10, d11;
+        if (__all(inside || !valid)) {
+            const int i00 = inside ? ra * WMAXW + ca : 0;
+            d00 = sA[i00]; d01 = sA[i00 + dxb]; d10 = sA[i00 + dyb * WMAXW]; d11 = sA[i00 + dyb * WMAXW + dxb];
+        } else {
+            const int rb = ra + dyb, cb = ca + dxb;
             const bool ina = (unsigned)ra < (unsigned)win.h, inb = (unsigned)rb < (unsigned)win.h;
             const bool inca = (unsigned)ca < (unsigned)win.w, incb = (unsigned)cb < (unsigned)win.w;
-            const float d00 = (ina && inca) ? sA[ra * WMAXW + ca] : to_depth<MODE>(v_k[t.ya * W + t.xa]);
-            const float d01 = (ina && incb) ? sA[ra * WMAXW + cb] : to_depth<MODE>(v_k[t.ya * W + t.xb]);
-            const float d10 = (inb && inca) ? sA[rb * WMAXW + ca] : to_depth<MODE>(v_k[t.yb * W + t.xa]);
-            const float d11 = (inb && incb) ? sA[rb * WMAXW + cb] : to_depth<MODE>(v_k[t.yb * W + t.xb]);
-            const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
-            const float izs = __builtin_amdgcn_rcpf(zs);
-            const float dd = iZ - izs;
-            acc_d += m * fabsf(dd);
-            const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
-            const float gm = cj.gb * m * sg;
-            g -= gm * a2 * iZ * iZ;
-            const float gz = gm * izs * izs;
-            g_dir[it] = g * depth_jac<MODE>(d);
-            if (m != 0.f) {
-                // will the owners of the taps' tiles (plane (b,k)) see this source?  All four taps in one
-                // tile (the common case) = one table lookup.
-                const int ta = (t.ya / TH) * tiles_x + t.xa / TW, tb = (t.yb / TH) * tiles_x + t.xb / TW;
-                bool all_seen = false;
-                if (ta == tb) all_seen = in_win(table_in_lds ? sWin[ta] : wins_k[ta], x, y);
-                if (!all_seen) {
-                    const int xs[4] = {t.xa, t.xb, t.xa, t.xb}, ys[4] = {t.ya, t.ya, t.yb, t.yb};
-                    const float ws[4] = {t.w00, t.w01, t.w10, t.w11}, ds[4] = {d00, d01, d10, d11};
+            d00 = (ina && inca) ? sA[ra * WMAXW + ca] : to_depth<MODE>(v_k[t.ya * W + t.xa]);
+            d01 = (ina && incb) ? sA[ra * WMAXW + cb] : to_depth<MODE>(v_k[t.ya * W + t.xb]);
+            d10 = (inb && inca) ? sA[rb * WMAXW + ca] : to_depth<MODE>(v_k[t.yb * W + t.xa]);
+            d11 = (inb && incb) ? sA[rb * WMAXW + cb] : to_depth<MODE>(v_k[t.yb * W + t.xb]);
+        }
+        const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
+        const float izs = __builtin_amdgcn_rcpf(zs);
+        const float dd = iZ - izs;
+        acc_d += m * fabsf(dd);
+        const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+        const float gm = cj.gb * m * sg;
+        g -= gm * a2 * iZ * iZ;
+        const float gz = gm * izs * izs;
+        if (valid) g_dir[it] = g * depth_jac<MODE>(d);
+        // will the owners of the taps' tiles (plane (b,k)) see this source?  All four taps in one tile (the
+        // common case) = one table lookup; anything else goes through the (wave-uniform) slow path.
+        const int ta = (t.ya / TH) * tiles_x + t.xa / TW, tb = (t.yb / TH) * tiles_x + t.xb / TW;
+        const bool seen = ta == tb && in_win(table_in_lds ? sWin[ta] : wins_k[ta], x, y);
+        const bool check = m != 0.f && !seen;
+        if (__any(check)) {
+            const int xs[4] = {t.xa, t.xb, t.xa, t.xb}, ys[4] = {t.ya, t.ya, t.yb, t.yb};
+            const float ws[4] = {t.w00, t.w01, t.w10, t.w11}, ds[4] = {d00, d01, d10, d11};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int tq = (ys[q] / TH) * tiles_x + xs[q] / TW;
-                        ov[q] = -gz * ws[q] * depth_jac<MODE>(ds[q]);
-                        oi[q] = base_k + (unsigned)(ys[q] * W + xs[q]);
-                        need[q] = ov[q] != 0.f && !in_win(table_in_lds ? sWin[tq] : wins_k[tq], x, y);
-                    }
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int tq = (ys[q] / TH) * tiles_x + xs[q] / TW;
+                const float cv = -gz * ws[q] * depth_jac<MODE>(ds[q]);
+                const bool need = check && cv != 0.f && !in_win(table_in_lds ? sWin[tq] : wins_k[tq], x, y);
+                ovf_push(need, ovf, oidx, oval, base_k + (unsigned)(ys[q] * W + xs[q]), cv);
             }
         }
-        // convergent: every lane of the wave reaches these
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ovf_push(need[q], ovf, oidx, oval, oi[q], ov[q]);
     }
 
     // ---------------- phase 2: pull the scatter term from direction k sources inside the window
@@ -277,10 +295,10 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
         const float gz = ck.gb * m * sg * izs * izs;
         const bool ya_in = (unsigned)(ra - 1) < (unsigned)TH, yb_in = (unsigned)(rb - 1) < (unsigned)TH;
         const bool xa_in = (unsigned)(ca - 1) < (unsigned)TW, xb_in = (unsigned)(cb - 1) < (unsigned)TW;
-        if (ya_in && xa_in) atomicAdd(&sG[(ra - 1) * TW + ca - 1], -gz * t.w00 * depth_jac<MODE>(d00));
-        if (ya_in && xb_in) atomicAdd(&sG[(ra - 1) * TW + cb - 1], -gz * t.w01 * depth_jac<MODE>(d01));
-        if (yb_in && xa_in) atomicAdd(&sG[(rb - 1) * TW + ca - 1], -gz * t.w10 * depth_jac<MODE>(d10));
-        if (yb_in && xb_in) atomicAdd(&sG[(rb - 1) * TW + cb - 1], -gz * t.w11 * depth_jac<MODE>(d11));
+        if (ya_in && xa_in) atomicAdd(&sG[(ra - 1) * TW + ca - 1], to_fixed(-gz * t.w00 * depth_jac<MODE>(d00)));
+        if (ya_in && xb_in) atomicAdd(&sG[(ra - 1) * TW + cb - 1], to_fixed(-gz * t.w01 * depth_jac<MODE>(d01)));
+        if (yb_in && xa_in) atomicAdd(&sG[(rb - 1) * TW + ca - 1], to_fixed(-gz * t.w10 * depth_jac<MODE>(d10)));
+        if (yb_in && xb_in) atomicAdd(&sG[(rb - 1) * TW + cb - 1], to_fixed(-gz * t.w11 * depth_jac<MODE>(d11)));
     }
     __syncthreads();
 
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
     for (int it = 0; it < ITERS; ++it) {
         const int ly = ly0 + it * ROWS_PER_IT;
         const int x = X0 + lx, y = Y0 + ly;
-        if (x < W && y < H) g_j[y * W + x] = g_dir[it] + sG[ly * TW + lx];
+        if (x < W && y < H) g_j[y * W + x] = g_dir[it] + from_fixed(sG[ly * TW + lx]);
     }
     acc_r = block_sum(acc_r, red);
     acc_d = block_sum(acc_d, red);
