@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
             const float mx = xf + fx, my = yf + fy;
             const float ex = (cj.cx_t - cj.fx_t * X * iZ) - mx, ey = (cj.cy_t + cj.fy_t * Y * iZ) - my;
             const float e = __builtin_amdgcn_sqrtf(ex * ex + ey * ey);
-            acc_r += m * e;
+            acc_r += valid ? m * e : 0.f;  // lanes outside a partial tile carry garbage
             const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
             const float ie = e > 0.f ? __builtin_amdgcn_rcpf(e) : 0.f;
             g += cj.gr * m * (ex * dpx + ey * dpy) * ie;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
         const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
         const float izs = __builtin_amdgcn_rcpf(zs);
         const float dd = iZ - izs;
-        acc_d += m * fabsf(dd);
+        acc_d += valid ? m * fabsf(dd) : 0.f;
         const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
         const float gm = cj.gb * m * sg;
         g -= gm * a2 * iZ * iZ;
