@@ -1,0 +1,250 @@
+// Weight gradient of the stride-1 "same" convolution on the gfx950 matrix cores, exact fp32.
+//
+//   dW[co][ci][ky][kx] = sum_{n,y,x} dY[n][co][y][x] * act(X)[n][ci][y+ky-P][x+kx-P]
+//
+// (the nn.Conv2d weight-gradient launches of autograd for the hourglass the reference trains,
+// /root/reference/depth_fine_tuning.py:282 loss.backward()).  GEMM view per filter tap:
+// M = 16 output channels, N = 16 input channels, K = pixels; v_mfma_f32_16x16x4_f32 consumes 4
+// consecutive pixels of a row per instruction:
+//   A[i = lane&15][k = lane>>4] = dY[co0+i][y][x0+k]            (LDS, channel planes 2 banks apart)
+//   B[k = lane>>4][j = lane&15] = act(X)[ci0+j][y+ky][x0+k+kx]  (LDS input tile with halo)
+//   D: lane holds ci0+(lane&15), co0 + 4*(lane>>4) + {0..3}.
+// A block stages a TY x 32 pixel tile of dY (CO_T*16 channels) and of the input (CI_T*16 channels,
+// + halo) in LDS; its 4 waves split the filter taps (k >= 7), taps x rows (k = 5) or rows (k <= 3)
+// and keep one accumulator tile per (tap, co tile, ci tile) in registers while the block walks all the
+// image tiles assigned to it (grid-stride over (image, tile)); partial sums are flushed ONCE per block
+// with fp32 atomics into a zeroed packed buffer [co grp][ci grp][tap][co][ci] (64-byte contiguous per
+// (tap, co)), which unpack_wgrad_kernel transposes into the [Cout][Cin][k][k] gradient.
+#include "cd_common.h"
+
+namespace cd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_TX = 32, WG_TY = 8;
+
+template <int KS> struct WgCfg {
+    static constexpr int NW_T = (KS >= 7) ? 4 : (KS == 5 ? 2 : 1);  // waves splitting the taps
+    static constexpr int NW_R = 4 / NW_T;                            // waves splitting the rows
+    static constexpr int TAPS = KS * KS;
+    static constexpr int TPW = (TAPS + NW_T - 1) / NW_T;             // taps per wave
+    static constexpr int RS = WG_TX + KS - 1, ROWS = WG_TY + KS - 1;
+    static constexpr int PS_IN_RAW = ROWS * RS;
+    static constexpr int PS_IN = PS_IN_RAW + ((2 - (PS_IN_RAW % 32)) + 32) % 32;   // == 2 (mod 32)
+    static constexpr int PS_DY = WG_TY * WG_TX + 2;                                  // 258 == 2 (mod 32)
+};
+
+template <int KS, int CO_T, int CI_T>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
+    const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
+    const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
+    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y) {
+    using Cfg = WgCfg<KS>;
+    constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, TPW = Cfg::TPW, NW_T = Cfg::NW_T, NW_R = Cfg::NW_R;
+    constexpr int RS = Cfg::RS, ROWS = Cfg::ROWS, PSI = Cfg::PS_IN, PSD = Cfg::PS_DY;
+    constexpr int COB = CO_T * 16, CIB = CI_T * 16;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_dy = smem;               // [COB][PSD]
+    float* s_in = smem + COB * PSD;   // [CIB][PSI]
+
+    const int cig = blockIdx.y, cog = blockIdx.z;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wt = wid % NW_T, wr = wid / NW_T;   // this wave's tap slot / row slot
+    const size_t HW = (size_t)H * W;
+    const int items = N * tiles_x * tiles_y;
+
+    f32x4 acc[TPW][CO_T][CI_T];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int a = 0; a < CO_T; ++a)
+#pragma unroll
+            for (int c = 0; c < CI_T; ++c) acc[t][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_lane = (lane & 15) * PSD + (lane >> 4);   // dY fragment: channel i = lane&15, pixel k = lane>>4
+    const int b_lane = (lane & 15) * PSI + (lane >> 4);   // input fragment: channel j = lane&15, pixel k
+
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int n = item / (tiles_x * tiles_y), tile = item - n * (tiles_x * tiles_y);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int X0 = tx * WG_TX, Y0 = ty * WG_TY;
+        __syncthreads();
+        // ---- stage dY tile (zero outside the image / beyond Cout)
+        const float* dyn = dy + ((size_t)n * dy_ctot + dy_coff) * HW;
+        for (int i = threadIdx.x; i < COB * WG_TY * WG_TX; i += kBlock) {
+            const int c = i / (WG_TY * WG_TX), rem = i - c * (WG_TY * WG_TX);
+            const int r = rem / WG_TX, col = rem - r * WG_TX;
+            const int co = cog * COB + c, gy = Y0 + r, gx = X0 + col;
+            float v = 0.f;
+            if (co < Cout && gy < H && gx < W) v = dyn[(size_t)co * HW + (size_t)gy * W + gx];
+            s_dy[c * PSD + r * WG_TX + col] = v;
+        }
+        // ---- stage activated input tile with halo (zero padding)
+        const float* xn = x + ((size_t)n * x_ctot + x_coff) * HW;
+        for (int i = threadIdx.x; i < CIB * ROWS * RS; i += kBlock) {
+            const int c = i / (ROWS * RS), rem = i - c * (ROWS * RS);
+            const int r = rem / RS, col = rem - r * RS;
+            const int ci = cig * CIB + c, gy = Y0 - P + r, gx = X0 - P + col;
+            float v = 0.f;
+            if (ci < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                v = xn[(size_t)ci * HW + (size_t)gy * W + gx];
+                if (in_scale) v = v * in_scale[ci] + in_shift[ci];
+                if (in_relu) v = fmaxf(v, 0.f);
+            }
+            s_in[c * PSI + r * RS + col] = v;
+        }
+        __syncthreads();
+        // ---- MFMA: this wave's rows x all 4-pixel groups x this wave's taps
+#pragma unroll 1
+        for (int r = wr; r < WG_TY; r += NW_R) {
+#pragma unroll 2
+            for (int c4 = 0; c4 < WG_TX / 4; ++c4) {
+                float af[CO_T];
+#pragma unroll
+                for (int a = 0; a < CO_T; ++a) af[a] = s_dy[a * 16 * PSD + r * WG_TX + c4 * 4 + a_lane];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int tap = t * NW_T + wt;   // compile-time stride, wave-uniform offset
+                    if (tap < TAPS) {
+                        const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+                        for (int c = 0; c < CI_T; ++c) {
+                            const float bf = s_in[c * 16 * PSI + (r + ky) * RS + c4 * 4 + kx + b_lane];
+#pragma unroll
+                            for (int a = 0; a < CO_T; ++a)
+                                acc[t][a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf, acc[t][a][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- flush: packed [cog][cig][tap][COB][CIB]
+    const size_t base = ((size_t)cog * gridDim.y + cig) * TAPS * COB * CIB;
+    const int ci_l = lane & 15, co4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = t * NW_T + wt;
+        if (tap < TAPS) {
+#pragma unroll
+            for (int a = 0; a < CO_T; ++a)
+#pragma unroll
+                for (int c = 0; c < CI_T; ++c) {
+                    float* dst = dw_packed + base + ((size_t)tap * COB + a * 16 + co4) * CIB + c * 16 + ci_l;
+                    const f32x4 v = acc[t][a][c];
+                    atomic_add_f32(dst, v.x);
+                    atomic_add_f32(dst + CIB, v.y);
+                    atomic_add_f32(dst + 2 * CIB, v.z);
+                    atomic_add_f32(dst + 3 * CIB, v.w);
+                }
+        }
+    }
+}
+
+// packed [cog][cig][tap][COB][CIB] -> dW[Cout][Cin][KS][KS]  (accumulate = 0: overwrite, 1: add)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ packed, int Cout, int Cin, int KS, int COB, int CIB,
+                                    int ci_groups, float* __restrict__ dw, int accumulate) {
+    const int total = Cout * Cin * KS * KS, taps = KS * KS;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int tap = i % taps, ci = (i / taps) % Cin, co = i / (taps * Cin);
+        const int cog = co / COB, cig = ci / CIB;
+        const float v = packed[(((size_t)cog * ci_groups + cig) * taps + tap) * COB * CIB + (size_t)(co - cog * COB) * CIB + (ci - cig * CIB)];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
+struct WgPlan { int co_t, ci_t; };
+
+static inline WgPlan wgrad_plan(int ks, int cout, int cin) {
+    WgPlan p;
+    const int co_need = (cout + 15) / 16, ci_need = (cin + 15) / 16;
+    if (ks == 11) { p.co_t = 1; p.ci_t = 1; }
+    else if (ks == 7) { p.co_t = co_need >= 2 ? 2 : 1; p.ci_t = 1; }
+    else if (ks == 5) { p.co_t = co_need >= 2 ? 2 : 1; p.ci_t = 1; }
+    else if (ks == 3) { p.co_t = co_need >= 2 ? 2 : 1; p.ci_t = ci_need >= 2 ? 2 : 1; }
+    else { p.co_t = co_need >= 4 ? 4 : (co_need >= 2 ? 2 : 1); p.ci_t = ci_need >= 4 ? 4 : (ci_need >= 2 ? 2 : 1); }
+    return p;
+}
+
+template <int KS, int CO_T, int CI_T>
+static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift,
+                          int in_relu, const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H,
+                          int W, hipStream_t s) {
+    using Cfg = WgCfg<KS>;
+    constexpr int COB = CO_T * 16, CIB = CI_T * 16;
+    const int tiles_x = (W + WG_TX - 1) / WG_TX, tiles_y = (H + WG_TY - 1) / WG_TY;
+    const int cogs = (Cout + COB - 1) / COB, cigs = (Cin + CIB - 1) / CIB;
+    const int items = N * tiles_x * tiles_y;
+    // enough blocks to fill the chip (~3 per CU), few enough that the atomic flush stays small
+    int splits = (256 * 3 + cogs * cigs - 1) / (cogs * cigs);
+    if (splits > items) splits = items;
+    if (splits < 1) splits = 1;
+    const size_t lds = sizeof(float) * ((size_t)COB * Cfg::PS_DY + (size_t)CIB * Cfg::PS_IN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<KS, CO_T, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, CO_T, CI_T>), dim3(splits, cigs, cogs), dim3(kBlock), lds, s, x, x_ctot, x_coff,
+                       Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+}  // namespace cd
+
+extern "C" {
+
+size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
+    if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
+    const cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
+    const int cob = p.co_t * 16, cib = p.ci_t * 16;
+    return (size_t)((Cout + cob - 1) / cob) * ((Cin + cib - 1) / cib) * ks * ks * cob * cib;
+}
+
+int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift,
+                    int in_relu, const float* dy, int dy_ctot, int dy_coff, int Cout, float* dw, int accumulate,
+                    float* workspace, int N, int H, int W, int ks, void* stream) {
+    if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD_ERR_INVALID_ARG;
+    if (x_coff < 0 || x_coff + Cin > x_ctot || dy_coff < 0 || dy_coff + Cout > dy_ctot) return CD_ERR_INVALID_ARG;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return CD_ERR_INVALID_ARG;
+    const size_t wsf = cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks);
+    if (wsf == 0) return CD_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, wsf * sizeof(float), s) != hipSuccess) return CD_ERR_LAUNCH;
+    const cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
+    int rc = CD_ERR_UNSUPPORTED;
+#define CD_WG(K, A, C) rc = cd::launch_wgrad_t<K, A, C>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, s)
+    if (ks == 11) CD_WG(11, 1, 1);
+    else if (ks == 7) { if (p.co_t == 2) CD_WG(7, 2, 1); else CD_WG(7, 1, 1); }
+    else if (ks == 5) { if (p.co_t == 2) CD_WG(5, 2, 1); else CD_WG(5, 1, 1); }
+    else if (ks == 3) {
+        if (p.co_t == 2 && p.ci_t == 2) CD_WG(3, 2, 2);
+        else if (p.co_t == 2) CD_WG(3, 2, 1);
+        else if (p.ci_t == 2) CD_WG(3, 1, 2);
+        else CD_WG(3, 1, 1);
+    } else {
+        if (p.co_t == 4 && p.ci_t == 4) CD_WG(1, 4, 4);
+        else if (p.co_t == 4 && p.ci_t == 2) CD_WG(1, 4, 2);
+        else if (p.co_t == 4) CD_WG(1, 4, 1);
+        else if (p.co_t == 2 && p.ci_t == 4) CD_WG(1, 2, 4);
+        else if (p.co_t == 2 && p.ci_t == 2) CD_WG(1, 2, 2);
+        else if (p.co_t == 2) CD_WG(1, 2, 1);
+        else if (p.ci_t == 4) CD_WG(1, 1, 4);
+        else if (p.ci_t == 2) CD_WG(1, 1, 2);
+        else CD_WG(1, 1, 1);
+    }
+#undef CD_WG
+    if (rc != CD_OK) return rc;
+    const int cob = p.co_t * 16, cib = p.ci_t * 16;
+    const int total = Cout * Cin * ks * ks;
+    hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
+                       workspace, Cout, Cin, ks, cob, cib, (Cin + cib - 1) / cib, dw, accumulate);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+}  // extern "C"
