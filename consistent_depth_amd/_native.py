@@ -35,6 +35,16 @@ SIGNATURES = {
     "cd_conv2d_packed_weight_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "cd_conv2d_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "cd_conv2d_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cd_conv2d_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),
+    "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cd_bn_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
+    "cd_bn_relu_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "cd_avgpool2_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_avgpool2_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_upsample2x_add_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_upsample2x_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_add_slice": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_channel_sum": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "cd_adam_step_flat": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
     "cd_adam_step_flat_guarded": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p]),
     "cd_l1_distance_workspace_bytes": (c_sz, [c_sz]),

@@ -1,0 +1,325 @@
+// Memory-bound layers of the hourglass around the MFMA convolutions (gfx950, NCHW fp32, 16 B per
+// lane where the row length allows).  They replace the BatchNorm2d(train) / ReLU / AvgPool2d(2) /
+// UpsamplingBilinear2d(2) / add launches (forward and autograd backward) of the network the
+// reference fine-tunes.
+//
+// Activation convention of the engine: a conv+BN+ReLU unit keeps x_hat = (y - mean) / sqrt(var+eps)
+// (normalised, PRE-ReLU) in memory; every consumer applies act(v) = relu(v*scale[c] + shift[c]) while
+// loading (scale/shift only for the affine stem BN).  x_hat is exactly what the BN/ReLU backward
+// needs, so no separate post-ReLU tensor or mask is ever stored.
+#include "cd_common.h"
+
+namespace cd {
+
+__device__ __forceinline__ float act(float v, const float* sc, const float* sh, int c, int relu) {
+    if (sc) v = v * sc[c] + sh[c];
+    return relu ? fmaxf(v, 0.f) : v;
+}
+
+// ---------------------------------------------------------------- BatchNorm (train) forward
+// stats[c] = (sum, sumsq) of the raw conv output over N*H*W (accumulated by the conv epilogue).
+// In place: x <- (x - mean) * rsqrt(var + eps); saves (mean, invstd); updates the running stats like
+// nn.BatchNorm2d(momentum): running_var uses the unbiased variance.
+__global__ __launch_bounds__(kBlock) void bn_normalize_kernel(float* __restrict__ x, int ctot, int coff,
+                                                              const double* __restrict__ stats, double count, float eps,
+                                                              float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float momentum,
+                                                              float* __restrict__ mean_invstd, int HW) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const double mean_d = stats[2 * (coff + c)] / count;
+    double var_d = stats[2 * (coff + c) + 1] / count - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+        mean_invstd[2 * (coff + c)] = mean;
+        mean_invstd[2 * (coff + c) + 1] = invstd;
+        if (running_mean) {
+            const double unb = count > 1.0 ? var_d * count / (count - 1.0) : var_d;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+    float* p = x + ((size_t)n * ctot + coff + c) * HW;
+    if ((HW & 3) == 0) {
+        float4* p4 = reinterpret_cast<float4*>(p);
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW / 4; i += gridDim.x * kBlock) {
+            float4 v = p4[i];
+            v.x = (v.x - mean) * invstd; v.y = (v.y - mean) * invstd; v.z = (v.z - mean) * invstd; v.w = (v.w - mean) * invstd;
+            p4[i] = v;
+        }
+    } else {
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) p[i] = (p[i] - mean) * invstd;
+    }
+}
+
+// ---------------------------------------------------------------- BN(train)+ReLU backward
+// Given dA = d loss / d a with a = relu(gamma*x_hat + beta):
+//   pass 1: T1[c] = sum dA*mask, T2[c] = sum dA*mask*x_hat          (mask = gamma*x_hat + beta > 0)
+//   pass 2: dY = gamma*invstd * (dA*mask - T1/cnt - x_hat*T2/cnt)   in place over dA   (d loss / d raw conv output)
+//           and  d gamma = T2, d beta = T1 for the affine stem BN.
+__global__ __launch_bounds__(kBlock) void bn_relu_bwd_reduce_kernel(const float* __restrict__ dA, int d_ctot, int d_coff,
+                                                                    const float* __restrict__ xhat, int x_ctot,
+                                                                    int x_coff, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta,
+                                                                    double* __restrict__ sums, int HW) {
+    __shared__ float lds[kBlock / kWave];
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
+    const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
+    float t1 = 0.f, t2 = 0.f;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
+        const float xv = xh[i];
+        const float dv = (g * xv + b > 0.f) ? d[i] : 0.f;
+        t1 += dv;
+        t2 += dv * xv;
+    }
+    t1 = block_sum(t1, lds);
+    t2 = block_sum(t2, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], (double)t1);
+        atomicAdd(&sums[2 * c + 1], (double)t2);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __restrict__ dA, int d_ctot, int d_coff,
+                                                                   const float* __restrict__ xhat, int x_ctot, int x_coff,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   const double* __restrict__ sums, double count,
+                                                                   const float* __restrict__ mean_invstd,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   int HW) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
+    const float k = g * mean_invstd[2 * (x_coff + c) + 1];
+    if (dgamma && blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+        dgamma[c] = (float)sums[2 * c + 1];
+        dbeta[c] = (float)sums[2 * c];
+    }
+    float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
+    const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
+        const float xv = xh[i];
+        const float dv = (g * xv + b > 0.f) ? d[i] : 0.f;
+        d[i] = k * (dv - m1 - xv * m2);
+    }
+}
+
+// ---------------------------------------------------------------- AvgPool2d(2)
+__global__ __launch_bounds__(kBlock) void avgpool2_fwd_kernel(const float* __restrict__ x, int x_ctot, int x_coff,
+                                                              const float* __restrict__ sc, const float* __restrict__ sh,
+                                                              int relu, float* __restrict__ y, int y_ctot, int y_coff,
+                                                              int H, int W) {
+    const int c = blockIdx.y, n = blockIdx.z, Ho = H / 2, Wo = W / 2;
+    const float* xi = x + ((size_t)n * x_ctot + x_coff + c) * H * W;
+    float* yo = y + ((size_t)n * y_ctot + y_coff + c) * Ho * Wo;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < Ho * Wo; i += gridDim.x * kBlock) {
+        const int oy = i / Wo, ox = i - oy * Wo;
+        const float2 a = *reinterpret_cast<const float2*>(xi + (size_t)(2 * oy) * W + 2 * ox);
+        const float2 b = *reinterpret_cast<const float2*>(xi + (size_t)(2 * oy + 1) * W + 2 * ox);
+        yo[i] = 0.25f * (act(a.x, sc, sh, c, relu) + act(a.y, sc, sh, c, relu) + act(b.x, sc, sh, c, relu) + act(b.y, sc, sh, c, relu));
+    }
+}
+
+// dIn (gradient w.r.t. the ACTIVATED input) (+)= 0.25 * dOut
+__global__ __launch_bounds__(kBlock) void avgpool2_bwd_kernel(const float* __restrict__ dy, int dy_ctot, int dy_coff,
+                                                              float* __restrict__ dx, int dx_ctot, int dx_coff, int H,
+                                                              int W, int accumulate) {
+    const int c = blockIdx.y, n = blockIdx.z, Ho = H / 2, Wo = W / 2;
+    const float* d = dy + ((size_t)n * dy_ctot + dy_coff + c) * Ho * Wo;
+    float* o = dx + ((size_t)n * dx_ctot + dx_coff + c) * H * W;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < H * W; i += gridDim.x * kBlock) {
+        const int yy = i / W, xx = i - yy * W;
+        const float v = 0.25f * d[(yy >> 1) * Wo + (xx >> 1)];
+        o[i] = accumulate ? o[i] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------- bilinear x2 (align_corners=True) + add
+// out[y][x] = bilinear(act_a(lo))[y][x] + act_b(hi)[y][x];   lo is (h, w), hi/out are (2h, 2w)
+__global__ __launch_bounds__(kBlock) void upsample2x_add_fwd_kernel(
+    const float* __restrict__ lo, int lo_ctot, int lo_coff, const float* __restrict__ lsc, const float* __restrict__ lsh,
+    int lrelu, const float* __restrict__ hi, int hi_ctot, int hi_coff, const float* __restrict__ hsc,
+    const float* __restrict__ hsh, int hrelu, float* __restrict__ out, int o_ctot, int o_coff, int h, int w) {
+    const int c = blockIdx.y, n = blockIdx.z, H = 2 * h, W = 2 * w;
+    const float ry = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rx = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float* l = lo + ((size_t)n * lo_ctot + lo_coff + c) * h * w;
+    const float* hh = hi ? hi + ((size_t)n * hi_ctot + hi_coff + c) * H * W : nullptr;
+    float* o = out + ((size_t)n * o_ctot + o_coff + c) * H * W;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < H * W; i += gridDim.x * kBlock) {
+        const int y = i / W, x = i - y * W;
+        const float sy = ry * (float)y, sx = rx * (float)x;
+        const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1), y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ty = sy - (float)y0, tx = sx - (float)x0;
+        const float v00 = act(l[y0 * w + x0], lsc, lsh, c, lrelu), v01 = act(l[y0 * w + x1], lsc, lsh, c, lrelu);
+        const float v10 = act(l[y1 * w + x0], lsc, lsh, c, lrelu), v11 = act(l[y1 * w + x1], lsc, lsh, c, lrelu);
+        float v = (1.f - ty) * ((1.f - tx) * v00 + tx * v01) + ty * ((1.f - tx) * v10 + tx * v11);
+        if (hh) v += act(hh[i], hsc, hsh, c, hrelu);
+        o[i] = v;
+    }
+}
+
+// adjoint of the bilinear part, as a GATHER over the high-res gradient (no atomics):
+// dlo[yy][xx] (+)= sum_{y,x} wy(y,yy) * wx(x,xx) * dout[y][x]
+__global__ __launch_bounds__(kBlock) void upsample2x_bwd_kernel(const float* __restrict__ dout, int d_ctot, int d_coff,
+                                                                float* __restrict__ dlo, int l_ctot, int l_coff, int h,
+                                                                int w, int accumulate) {
+    const int c = blockIdx.y, n = blockIdx.z, H = 2 * h, W = 2 * w;
+    const float ry = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rx = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float* d = dout + ((size_t)n * d_ctot + d_coff + c) * H * W;
+    float* o = dlo + ((size_t)n * l_ctot + l_coff + c) * h * w;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < h * w; i += gridDim.x * kBlock) {
+        const int yy = i / w, xx = i - yy * w;
+        // high-res rows whose source coordinate lies in (yy-1, yy+1): y in ((yy-1)/ry, (yy+1)/ry)
+        // (one extra candidate on each side: the weights below are exact, candidates outside get weight 0)
+        const int ya = ry > 0.f ? max(0, (int)floorf((float)(yy - 1) / ry) - 1) : 0;
+        const int yb = ry > 0.f ? min(H - 1, (int)ceilf((float)(yy + 1) / ry) + 1) : H - 1;
+        const int xa = rx > 0.f ? max(0, (int)floorf((float)(xx - 1) / rx) - 1) : 0;
+        const int xb = rx > 0.f ? min(W - 1, (int)ceilf((float)(xx + 1) / rx) + 1) : W - 1;
+        float acc = 0.f;
+        for (int y = ya; y <= yb; ++y) {
+            // identical arithmetic to the forward: sy, y0 = min((int)sy, h-1), y1 = min(y0+1, h-1), ty
+            const float sy = ry * (float)y;
+            const int y0 = min((int)sy, h - 1), y1 = min(y0 + 1, h - 1);
+            const float ty = sy - (float)y0;
+            const float wy = (y0 == yy ? 1.f - ty : 0.f) + (y1 == yy ? ty : 0.f);
+            if (wy == 0.f) continue;
+            for (int x = xa; x <= xb; ++x) {
+                const float sx = rx * (float)x;
+                const int x0 = min((int)sx, w - 1), x1 = min(x0 + 1, w - 1);
+                const float tx = sx - (float)x0;
+                const float wx = (x0 == xx ? 1.f - tx : 0.f) + (x1 == xx ? tx : 0.f);
+                acc += wy * wx * d[y * W + x];
+            }
+        }
+        o[i] = accumulate ? o[i] + acc : acc;
+    }
+}
+
+// dst[:, coff:coff+C] (+)= src[:, scoff:scoff+C]   (gradient fan-in of an activation with several consumers)
+__global__ __launch_bounds__(kBlock) void add_slice_kernel(const float* __restrict__ src, int s_ctot, int s_coff,
+                                                           float* __restrict__ dst, int d_ctot, int d_coff, int HW,
+                                                           int accumulate) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float* s = src + ((size_t)n * s_ctot + s_coff + c) * HW;
+    float* d = dst + ((size_t)n * d_ctot + d_coff + c) * HW;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) d[i] = accumulate ? d[i] + s[i] : s[i];
+}
+
+// out[c] = sum over n, y, x of src[n][coff+c]   (bias gradient of a conv that is NOT followed by BatchNorm)
+__global__ __launch_bounds__(kBlock) void channel_sum_kernel(const float* __restrict__ src, int ctot, int coff, int N,
+                                                             int HW, float* __restrict__ out, int accumulate) {
+    __shared__ float lds[kBlock / kWave];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* s = src + ((size_t)n * ctot + coff + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += kBlock) acc += s[i];
+    }
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + acc : acc;
+}
+
+static inline dim3 plane_grid(int HW, int C, int N, int per_thread) {
+    int bx = (HW + kBlock * per_thread - 1) / (kBlock * per_thread);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    return dim3(bx, C, N);
+}
+
+}  // namespace cd
+
+extern "C" {
+
+#define CD_ARGCHK(cond) do { if (!(cond)) return CD_ERR_INVALID_ARG; } while (0)
+
+int cd_bn_normalize(float* x, int ctot, int coff, int C, const double* stats, float eps, float* running_mean,
+                    float* running_var, float momentum, float* mean_invstd, int N, int H, int W, void* stream) {
+    CD_ARGCHK(x && stats && mean_invstd && C > 0 && coff >= 0 && coff + C <= ctot && N > 0 && H > 0 && W > 0);
+    CD_ARGCHK((running_mean == nullptr) == (running_var == nullptr));
+    hipLaunchKernelGGL(cd::bn_normalize_kernel, cd::plane_grid(H * W, C, N, 8), dim3(cd::kBlock), 0, (hipStream_t)stream, x,
+                       ctot, coff, stats, (double)N * H * W, eps, running_mean, running_var, momentum, mean_invstd, H * W);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C, const float* gamma,
+                   const float* beta, const float* mean_invstd, double* sums, float* dgamma, float* dbeta, int N, int H,
+                   int W, void* stream) {
+    CD_ARGCHK(dA && xhat && mean_invstd && sums && C > 0 && d_coff >= 0 && d_coff + C <= d_ctot && x_coff >= 0 && x_coff + C <= x_ctot);
+    CD_ARGCHK((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr));
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s) != hipSuccess) return CD_ERR_LAUNCH;
+    const dim3 grid = cd::plane_grid(H * W, C, N, 8);
+    hipLaunchKernelGGL(cd::bn_relu_bwd_reduce_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
+                       gamma, beta, sums, H * W);
+    CD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cd::bn_relu_bwd_apply_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
+                       gamma, beta, sums, (double)N * H * W, mean_invstd, dgamma, dbeta, H * W);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* in_scale, const float* in_shift, int in_relu,
+                    float* y, int y_ctot, int y_coff, int C, int N, int H, int W, void* stream) {
+    CD_ARGCHK(x && y && C > 0 && (H % 2) == 0 && (W % 2) == 0 && x_coff + C <= x_ctot && y_coff + C <= y_ctot);
+    CD_ARGCHK((in_scale == nullptr) == (in_shift == nullptr));
+    hipLaunchKernelGGL(cd::avgpool2_fwd_kernel, cd::plane_grid(H * W / 4, C, N, 4), dim3(cd::kBlock), 0, (hipStream_t)stream,
+                       x, x_ctot, x_coff, in_scale, in_shift, in_relu, y, y_ctot, y_coff, H, W);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_avgpool2_bwd(const float* dy, int dy_ctot, int dy_coff, float* dx, int dx_ctot, int dx_coff, int C, int N, int H,
+                    int W, int accumulate, void* stream) {
+    CD_ARGCHK(dy && dx && C > 0 && (H % 2) == 0 && (W % 2) == 0 && dy_coff + C <= dy_ctot && dx_coff + C <= dx_ctot);
+    hipLaunchKernelGGL(cd::avgpool2_bwd_kernel, cd::plane_grid(H * W, C, N, 4), dim3(cd::kBlock), 0, (hipStream_t)stream, dy,
+                       dy_ctot, dy_coff, dx, dx_ctot, dx_coff, H, W, accumulate);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_upsample2x_add_fwd(const float* lo, int lo_ctot, int lo_coff, const float* lo_scale, const float* lo_shift,
+                          int lo_relu, const float* hi, int hi_ctot, int hi_coff, const float* hi_scale,
+                          const float* hi_shift, int hi_relu, float* out, int o_ctot, int o_coff, int C, int N, int h, int w,
+                          void* stream) {
+    CD_ARGCHK(lo && out && C > 0 && h > 0 && w > 0 && lo_coff + C <= lo_ctot && o_coff + C <= o_ctot);
+    CD_ARGCHK(hi == nullptr || hi_coff + C <= hi_ctot);
+    CD_ARGCHK((lo_scale == nullptr) == (lo_shift == nullptr) && (hi_scale == nullptr) == (hi_shift == nullptr));
+    hipLaunchKernelGGL(cd::upsample2x_add_fwd_kernel, cd::plane_grid(4 * h * w, C, N, 4), dim3(cd::kBlock), 0,
+                       (hipStream_t)stream, lo, lo_ctot, lo_coff, lo_scale, lo_shift, lo_relu, hi, hi_ctot, hi_coff, hi_scale,
+                       hi_shift, hi_relu, out, o_ctot, o_coff, h, w);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_upsample2x_bwd(const float* dout, int d_ctot, int d_coff, float* dlo, int l_ctot, int l_coff, int C, int N, int h,
+                      int w, int accumulate, void* stream) {
+    CD_ARGCHK(dout && dlo && C > 0 && h > 0 && w > 0 && d_coff + C <= d_ctot && l_coff + C <= l_ctot);
+    hipLaunchKernelGGL(cd::upsample2x_bwd_kernel, cd::plane_grid(h * w, C, N, 1), dim3(cd::kBlock), 0, (hipStream_t)stream,
+                       dout, d_ctot, d_coff, dlo, l_ctot, l_coff, h, w, accumulate);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_ctot, int d_coff, int C, int N, int H, int W,
+                 int accumulate, void* stream) {
+    CD_ARGCHK(src && dst && C > 0 && s_coff + C <= s_ctot && d_coff + C <= d_ctot);
+    hipLaunchKernelGGL(cd::add_slice_kernel, cd::plane_grid(H * W, C, N, 4), dim3(cd::kBlock), 0, (hipStream_t)stream, src,
+                       s_ctot, s_coff, dst, d_ctot, d_coff, H * W, accumulate);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_channel_sum(const float* src, int ctot, int coff, int C, int N, int H, int W, float* out, int accumulate,
+                   void* stream) {
+    CD_ARGCHK(src && out && C > 0 && coff + C <= ctot);
+    hipLaunchKernelGGL(cd::channel_sum_kernel, dim3(C), dim3(cd::kBlock), 0, (hipStream_t)stream, src, ctot, coff, N, H * W, out,
+                       accumulate);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""Python face of the memory-bound layer kernels (cd_bn_*, cd_avgpool2_*, cd_upsample2x_*, ...).
+All tensors NCHW fp32 on the HIP device; (tensor, channel offset, C) address channel slices."""
+from __future__ import annotations
+
+import torch
+
+from .. import _native
+
+_p = _native.dev_ptr
+
+
+def _o(t, name="t"):
+    return _native.dev_ptr(t, name) if t is not None else None
+
+
+def _s(t):
+    return _native.stream_ptr(t.device)
+
+
+def bn_normalize(x, coff, C, stats, mean_invstd, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
+    N, ctot, H, W = x.shape
+    rc = _native.lib().cd_bn_normalize(_p(x), ctot, coff, C, stats.data_ptr(), float(eps), _o(running_mean), _o(running_var),
+                                       float(momentum), _p(mean_invstd), N, H, W, _s(x))
+    _native.check(rc, "cd_bn_normalize")
+
+
+def bn_relu_bwd(dA, d_coff, xhat, x_coff, C, mean_invstd, sums, gamma=None, beta=None, dgamma=None, dbeta=None):
+    N, d_ctot, H, W = dA.shape
+    rc = _native.lib().cd_bn_relu_bwd(_p(dA), d_ctot, d_coff, _p(xhat), xhat.shape[1], x_coff, C, _o(gamma), _o(beta),
+                                      _p(mean_invstd), sums.data_ptr(), _o(dgamma), _o(dbeta), N, H, W, _s(dA))
+    _native.check(rc, "cd_bn_relu_bwd")
+
+
+def avgpool2_fwd(x, x_coff, C, y, y_coff=0, in_scale=None, in_shift=None, in_relu=False):
+    N, x_ctot, H, W = x.shape
+    rc = _native.lib().cd_avgpool2_fwd(_p(x), x_ctot, x_coff, _o(in_scale), _o(in_shift), int(in_relu), _p(y), y.shape[1],
+                                       y_coff, C, N, H, W, _s(x))
+    _native.check(rc, "cd_avgpool2_fwd")
+
+
+def avgpool2_bwd(dy, dy_coff, dx, dx_coff, C, accumulate):
+    N, dx_ctot, H, W = dx.shape
+    rc = _native.lib().cd_avgpool2_bwd(_p(dy), dy.shape[1], dy_coff, _p(dx), dx_ctot, dx_coff, C, N, H, W, int(accumulate),
+                                       _s(dx))
+    _native.check(rc, "cd_avgpool2_bwd")
+
+
+def upsample2x_add_fwd(lo, lo_coff, C, out, out_coff=0, hi=None, hi_coff=0, lo_relu=False, hi_relu=False, lo_scale=None,
+                       lo_shift=None, hi_scale=None, hi_shift=None):
+    N, lo_ctot, h, w = lo.shape
+    rc = _native.lib().cd_upsample2x_add_fwd(_p(lo), lo_ctot, lo_coff, _o(lo_scale), _o(lo_shift), int(lo_relu), _o(hi),
+                                             hi.shape[1] if hi is not None else 0, hi_coff, _o(hi_scale), _o(hi_shift),
+                                             int(hi_relu), _p(out), out.shape[1], out_coff, C, N, h, w, _s(lo))
+    _native.check(rc, "cd_upsample2x_add_fwd")
+
+
+def upsample2x_bwd(dout, d_coff, dlo, l_coff, C, accumulate):
+    N, l_ctot, h, w = dlo.shape
+    rc = _native.lib().cd_upsample2x_bwd(_p(dout), dout.shape[1], d_coff, _p(dlo), l_ctot, l_coff, C, N, h, w,
+                                         int(accumulate), _s(dlo))
+    _native.check(rc, "cd_upsample2x_bwd")
+
+
+def add_slice(src, s_coff, dst, d_coff, C, accumulate):
+    N, d_ctot, H, W = dst.shape
+    rc = _native.lib().cd_add_slice(_p(src), src.shape[1], s_coff, _p(dst), d_ctot, d_coff, C, N, H, W, int(accumulate),
+                                    _s(dst))
+    _native.check(rc, "cd_add_slice")
+
+
+def channel_sum(src, coff, C, out, accumulate=False):
+    N, ctot, H, W = src.shape
+    rc = _native.lib().cd_channel_sum(_p(src), ctot, coff, C, N, H, W, _p(out), int(accumulate), _s(src))
+    _native.check(rc, "cd_channel_sum")

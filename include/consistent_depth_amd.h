@@ -152,6 +152,54 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                   float* y, int y_ctot, int y_coff, int Cout, double* stats,
                   int N, int H, int W, int ks, void* stream);
 
+/* Weight gradient dw[Cout][Cin][ks][ks] (=, or += when accumulate) of the same convolution:
+ * sum over n,y,x of dy[n][co][y][x] * act(x)[n][ci][y+ky-P][x+kx-P]  (act as in cd_conv2d_fwd).
+ * workspace: cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) floats (zeroed inside). */
+size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks);
+int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale,
+                    const float* in_shift, int in_relu, const float* dy, int dy_ctot, int dy_coff,
+                    int Cout, float* dw, int accumulate, float* workspace, int N, int H, int W, int ks,
+                    void* stream);
+
+/* BatchNorm2d in training mode, forward.  stats[ctot][2] = per-channel (sum, sum of squares) of the raw
+ * tensor over N*H*W (what cd_conv2d_fwd accumulates).  In place: x <- (x - mean) * rsqrt(var + eps)
+ * (x_hat, PRE-ReLU: consumers apply relu / the affine part while loading); writes
+ * mean_invstd[ctot][2] (mean, 1/std) for the backward and updates running_mean/var[C] (momentum, unbiased
+ * variance) like nn.BatchNorm2d when they are given. */
+int cd_bn_normalize(float* x, int ctot, int coff, int C, const double* stats, float eps,
+                    float* running_mean, float* running_var, float momentum, float* mean_invstd,
+                    int N, int H, int W, void* stream);
+
+/* Backward of relu(gamma * x_hat + beta) + train-mode BatchNorm in one call: dA (gradient w.r.t. the
+ * activated output) is replaced IN PLACE by the gradient w.r.t. the raw (pre-BN) tensor.  gamma/beta
+ * NULL = BatchNorm2d(affine=False); dgamma/dbeta[C] receive the affine gradients when given.
+ * sums: scratch of 2*C doubles. */
+int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C,
+                   const float* gamma, const float* beta, const float* mean_invstd, double* sums,
+                   float* dgamma, float* dbeta, int N, int H, int W, void* stream);
+
+/* AvgPool2d(2) of act(x) and its adjoint (dx = gradient w.r.t. the ACTIVATED input, (+)= when accumulate). */
+int cd_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* in_scale, const float* in_shift,
+                    int in_relu, float* y, int y_ctot, int y_coff, int C, int N, int H, int W, void* stream);
+int cd_avgpool2_bwd(const float* dy, int dy_ctot, int dy_coff, float* dx, int dx_ctot, int dx_coff, int C,
+                    int N, int H, int W, int accumulate, void* stream);
+
+/* out = UpsamplingBilinear2d(2)(act(lo)) [+ act(hi)]  (align_corners=True; hi may be NULL), lo is h x w;
+ * cd_upsample2x_bwd is the adjoint of the bilinear part as a gather (no atomics): dlo (+)= U^T dout. */
+int cd_upsample2x_add_fwd(const float* lo, int lo_ctot, int lo_coff, const float* lo_scale,
+                          const float* lo_shift, int lo_relu, const float* hi, int hi_ctot, int hi_coff,
+                          const float* hi_scale, const float* hi_shift, int hi_relu, float* out, int o_ctot,
+                          int o_coff, int C, int N, int h, int w, void* stream);
+int cd_upsample2x_bwd(const float* dout, int d_ctot, int d_coff, float* dlo, int l_ctot, int l_coff, int C,
+                      int N, int h, int w, int accumulate, void* stream);
+
+/* dst[:, d_coff:+C] (+)= src[:, s_coff:+C]  -- gradient fan-in of a tensor with several consumers. */
+int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_ctot, int d_coff, int C, int N,
+                 int H, int W, int accumulate, void* stream);
+/* out[c] (+)= sum over n,y,x of src[n][coff+c]  -- bias gradient of a conv not followed by BatchNorm. */
+int cd_channel_sum(const float* src, int ctot, int coff, int C, int N, int H, int W, float* out,
+                   int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Optimiser (reference: optimizer/__init__.py:16-17 -> torch.optim.Adam,
  * depth_fine_tuning.py:231-236,283; betas (0.9,0.999), eps 1e-8, no weight decay)

@@ -1,0 +1,106 @@
+"""GPU parity of the wgrad convolution and the memory-bound layer kernels against torch on the CPU (fp64)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [
+    (2, 64, 16, 20, 36, 11), (2, 32, 32, 17, 40, 7), (2, 64, 64, 16, 32, 7), (2, 32, 64, 12, 24, 5),
+    (2, 64, 32, 16, 32, 3), (2, 128, 64, 16, 40, 1), (2, 256, 32, 8, 16, 1), (1, 64, 1, 24, 40, 3), (2, 3, 128, 24, 40, 7),
+    (2, 16, 16, 9, 33, 3), (2, 128, 16, 8, 32, 1),
+])
+def test_wgrad_matches_autograd(N, Cin, Cout, H, W, ks):
+    import torch
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator().manual_seed(ks * 77 + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(N, Cout, H, W, generator=g, dtype=torch.float64)
+    torch.nn.functional.conv2d(torch.relu(x), w, padding=(ks - 1) // 2).backward(dy)
+    dw = torch.empty(Cout, Cin, ks, ks, device="cuda")
+    ws = conv.wgrad_workspace(Cout, Cin, ks, "cuda")
+    conv.conv2d_wgrad(x.float().cuda(), dy.float().cuda(), Cin, Cout, ks, dw, ws, in_relu=True)
+    ref = w.grad
+    assert (dw.cpu().double() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+    # accumulate mode
+    conv.conv2d_wgrad(x.float().cuda(), dy.float().cuda(), Cin, Cout, ks, dw, ws, in_relu=True, accumulate=True)
+    assert (dw.cpu().double() - 2 * ref).abs().max().item() < 6e-5 * ref.abs().max().item()
+
+
+def test_bn_normalize_and_backward_match_torch():
+    import torch
+    from consistent_depth_amd.ops import conv, layers
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W, coff, ctot = 3, 24, 12, 20, 8, 40
+    raw = torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 2 + 0.5
+    gamma = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, generator=g, dtype=torch.float64) * 0.3
+    for affine in (False, True):
+        x = raw.clone().requires_grad_(True)
+        bn = torch.nn.BatchNorm2d(C, affine=affine).double()
+        if affine:
+            bn.weight.data.copy_(gamma); bn.bias.data.copy_(beta)
+        a = torch.relu(bn(x))
+        dA = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+        a.backward(dA)
+        buf = torch.zeros(N, ctot, H, W).cuda()
+        buf[:, coff:coff + C] = raw.float().cuda()
+        stats = torch.zeros(ctot, 2, dtype=torch.float64).cuda()
+        stats[coff:coff + C, 0] = raw.sum((0, 2, 3)).cuda()
+        stats[coff:coff + C, 1] = (raw ** 2).sum((0, 2, 3)).cuda()
+        mi = torch.zeros(ctot, 2).cuda()
+        rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+        layers.bn_normalize(buf, coff, C, stats, mi, running_mean=rm, running_var=rv)
+        xhat_ref = (raw - raw.mean((0, 2, 3), keepdim=True)) / torch.sqrt(raw.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5)
+        assert (buf[:, coff:coff + C].cpu().double() - xhat_ref).abs().max().item() < 2e-5
+        np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5)
+        d = torch.zeros(N, ctot, H, W).cuda()
+        d[:, coff:coff + C] = dA.float().cuda()
+        sums = torch.zeros(2 * C, dtype=torch.float64).cuda()
+        kw = {}
+        if affine:
+            kw = dict(gamma=gamma.float().cuda(), beta=beta.float().cuda(), dgamma=torch.zeros(C).cuda(), dbeta=torch.zeros(C).cuda())
+        layers.bn_relu_bwd(d, coff, buf, coff, C, mi, sums, **kw)
+        assert (d[:, coff:coff + C].cpu().double() - x.grad).abs().max().item() < 3e-5 * x.grad.abs().max().item()
+        if affine:
+            np.testing.assert_allclose(kw["dgamma"].cpu().numpy(), bn.weight.grad.numpy(), rtol=2e-5, atol=1e-4)
+            np.testing.assert_allclose(kw["dbeta"].cpu().numpy(), bn.bias.grad.numpy(), rtol=2e-5, atol=1e-4)
+
+
+def test_pool_upsample_add_and_adjoints():
+    import torch
+    from consistent_depth_amd.ops import layers
+    g = torch.Generator().manual_seed(5)
+    N, C, h, w = 2, 6, 7, 12
+    x = torch.randn(N, C, 2 * h, 2 * w, generator=g, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.avg_pool2d(torch.relu(x), 2)
+    dy = torch.randn(N, C, h, w, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    out = torch.zeros(N, C + 2, h, w).cuda()
+    layers.avgpool2_fwd(x.detach().float().cuda(), 0, C, out, 1, in_relu=True)
+    assert (out[:, 1:C + 1].cpu().double() - y).abs().max().item() < 1e-6
+    dx = torch.ones(N, C, 2 * h, 2 * w).cuda()
+    layers.avgpool2_bwd(dy.float().cuda(), 0, dx, 0, C, accumulate=True)
+    # gradient w.r.t. the ACTIVATED input = 0.25 * dy (the relu mask is applied by the producer's backward)
+    ref = torch.nn.functional.interpolate(dy, scale_factor=2, mode="nearest") * 0.25 + 1
+    assert (dx.cpu().double() - ref).abs().max().item() < 1e-6
+
+    lo = torch.randn(N, C, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    hi = torch.randn(N, C, 2 * h, 2 * w, generator=g, dtype=torch.float64, requires_grad=True)
+    o = torch.nn.functional.interpolate(torch.relu(lo), scale_factor=2, mode="bilinear", align_corners=True) + torch.relu(hi)
+    do = torch.randn(N, C, 2 * h, 2 * w, generator=g, dtype=torch.float64)
+    o.backward(do)
+    got = torch.zeros(N, C, 2 * h, 2 * w).cuda()
+    layers.upsample2x_add_fwd(lo.detach().float().cuda(), 0, C, got, 0, hi=hi.detach().float().cuda(), lo_relu=True, hi_relu=True)
+    assert (got.cpu().double() - o).abs().max().item() < 2e-6
+    dlo = torch.zeros(N, C, h, w).cuda()
+    layers.upsample2x_bwd(do.float().cuda(), 0, dlo, 0, C, accumulate=False)
+    # adjoint w.r.t. the activated low-res input = U^T do
+    lo2 = torch.randn(N, C, h, w, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.interpolate(lo2, scale_factor=2, mode="bilinear", align_corners=True).backward(do)
+    assert (dlo.cpu().double() - lo2.grad).abs().max().item() < 1e-5
+    s = torch.zeros(C).cuda()
+    layers.channel_sum(do.float().cuda(), 0, C, s)
+    np.testing.assert_allclose(s.cpu().numpy(), do.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-4)
