@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     const float* __restrict__ wpk, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     float* __restrict__ y, int y_ctot, int y_coff, int Cout,
-    double* __restrict__ stats, int H, int W, int tiles_x) {
+    double* __restrict__ stats, int accumulate, int H, int W, int tiles_x) {
     using Cfg = ConvCfg<KS>;
     constexpr int TY = Cfg::TY, CI = Cfg::CI_CHUNK, RS = Cfg::RS, PS = Cfg::PS, ROWS = Cfg::ROWS;
     constexpr int P = (KS - 1) / 2, TAPS = KS * KS;
@@ -165,14 +165,21 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
             if (co < Cout && gy < H) {
                 float* dst = yout + (size_t)co * HW + (size_t)gy * W + gx;
                 if (gx + 3 < W && ((W & 3) == 0)) {
+                    if (accumulate) {  // gradient fan-in: y += conv
+                        const float4 o = *reinterpret_cast<const float4*>(dst);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
                     *reinterpret_cast<float4*>(dst) = make_float4(v.x, v.y, v.z, v.w);
                     s1 += v.x + v.y + v.z + v.w;
                     s2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 } else {
-                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (gx + q < W) { dst[q] = e[q]; s1 += e[q]; s2 += e[q] * e[q]; }
+                        if (gx + q < W) {
+                            if (accumulate) e[q] += dst[q];
+                            dst[q] = e[q]; s1 += e[q]; s2 += e[q] * e[q];
+                        }
                 }
             }
         }
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
 template <int KS, int CO_T>
 static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wpk, const float* bias,
                          const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff,
-                         int Cout, double* stats, int N, int H, int W, hipStream_t s) {
+                         int Cout, double* stats, int accumulate, int N, int H, int W, hipStream_t s) {
     using Cfg = ConvCfg<KS>;
     constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
     const int tiles_x = (W + CV_TX - 1) / CV_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
@@ -204,7 +211,7 @@ static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const 
     }
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T>), dim3(tiles_x * tiles_y, groups, N), dim3(kBlock), lds, s, x, x_ctot,
-                       x_coff, Cin, wpk, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, H, W, tiles_x);
+                       x_coff, Cin, wpk, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, H, W, tiles_x);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -246,13 +253,13 @@ int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transp
 
 int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w, const float* bias,
                   const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout,
-                  double* stats, int N, int H, int W, int ks, void* stream) {
+                  double* stats, int accumulate, int N, int H, int W, int ks, void* stream) {
     if (!x || !packed_w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD_ERR_INVALID_ARG;
     if (x_coff < 0 || x_coff + Cin > x_ctot || y_coff < 0 || y_coff + Cout > y_ctot) return CD_ERR_INVALID_ARG;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return CD_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int cot = cd::pick_co_tiles(ks, Cout);
-#define CD_CONV(K, T) return cd::launch_conv_t<K, T>(x, x_ctot, x_coff, Cin, packed_w, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, N, H, W, s)
+#define CD_CONV(K, T) return cd::launch_conv_t<K, T>(x, x_ctot, x_coff, Cin, packed_w, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
 #define CD_CONV_K(K)                     \
     if (ks == K) {                       \
         if (cot == 1) CD_CONV(K, 1);     \

@@ -1,0 +1,289 @@
+"""Hand-written-HIP execution engine for the Mannequin-Challenge hourglass (forward AND backward).
+
+Executes the same network as consistent_depth_amd/monodepth/hourglass.py (whose nn.Module stays the
+parameter / state_dict container) on the gfx950 kernels behind the C ABI:
+
+    conv (all 157)      cd_conv2d_fwd        fp32 MFMA direct convolution; the producer's ReLU (and the stem's
+                                             affine) is applied while loading, the batch statistics of the
+                                             raw output are accumulated in the epilogue
+    BatchNorm (train)   cd_bn_normalize      in place -> x_hat (pre-ReLU); running stats updated like PyTorch
+    AvgPool2d(2)        cd_avgpool2_fwd
+    Upsample x2 + add   cd_upsample2x_add_fwd   (the residual add of every Channels block is fused in)
+    backward            cd_bn_relu_bwd, cd_conv2d_wgrad, cd_conv2d_fwd on transposed filters (dgrad),
+                        cd_avgpool2_bwd, cd_upsample2x_bwd, cd_add_slice, cd_channel_sum
+
+No autograd tape is built for the network: the backward pass is the explicit reverse walk of the plan.
+Towards PyTorch the engine is ONE autograd node: forward(x) returns pred_d attached to the graph, and
+loss.backward() calls `_backward`, which writes every parameter gradient into p.grad (views of the
+flat Adam buffer).  The unused `uncertainty_layer` head is not evaluated (its output is discarded by
+the reference, mannequin_challenge_model.py:60, and its parameters never receive gradients).
+
+Conv biases in front of a train-mode BatchNorm have an identically zero gradient (the mean subtraction
+removes them); the engine leaves those gradients at exactly 0 instead of computing round-off noise.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from ..ops import conv as C
+from ..ops import layers as L
+from . import hourglass as HG
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+class Act:
+    """An activation of the plan: channels [coff, coff+C) of `buf`; consumers apply
+    relu(v*scale + shift) on load when flagged.  `gbuf` receives d loss / d (activated value)."""
+
+    registry = None  # set while a plan is being built: every Act of the plan is collected here
+
+    def __init__(self, buf, coff, C, relu=False, scale=None, shift=None, needs_grad=True):
+        self.buf, self.coff, self.C, self.relu, self.scale, self.shift = buf, coff, C, relu, scale, shift
+        self.gbuf = torch.empty_like(buf) if needs_grad else None
+        self.grad_written = False
+        if Act.registry is not None:
+            Act.registry.append(self)
+
+    def grad_mode(self) -> bool:
+        """accumulate flag for the next gradient contribution (first writer overwrites)."""
+        acc = self.grad_written
+        self.grad_written = True
+        return acc
+
+
+class ConvUnit:
+    def __init__(self, eng, conv_mod, bn_mod, src: Act, dst_buf, dst_coff, stats, mean_invstd):
+        self.eng, self.conv, self.bn, self.src = eng, conv_mod, bn_mod, src
+        self.ks, self.cin, self.cout = conv_mod.kernel_size[0], conv_mod.in_channels, conv_mod.out_channels
+        self.dst_buf, self.dst_coff, self.stats, self.mi = dst_buf, dst_coff, stats, mean_invstd
+        affine = bn_mod is not None and bn_mod.affine
+        self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None,
+                       scale=bn_mod.weight if affine else None, shift=bn_mod.bias if affine else None, needs_grad=False)
+        self.wgrad_ws = C.wgrad_workspace(self.cout, self.cin, self.ks, dst_buf.device)
+        self.sums = torch.zeros(2 * self.cout, dtype=torch.float64, device=dst_buf.device)
+        self.pk = self.pkT = None
+
+    def pack(self, need_dgrad):
+        self.pk = C.pack_weights(self.conv.weight)
+        self.pkT = C.pack_weights(self.conv.weight, transposed=True) if need_dgrad else None
+
+    def forward(self, training):
+        s = self.src
+        C.conv2d(s.buf, self.pk, self.cin, self.cout, self.ks, bias=self.conv.bias, x_coff=s.coff, out=self.dst_buf,
+                 y_coff=self.dst_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu,
+                 stats=self.stats.view(-1) if (self.bn is not None and training) else None)
+        if self.bn is not None:
+            if training:
+                L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS, self.bn.running_mean,
+                               self.bn.running_var, BN_MOMENTUM)
+            else:  # eval: normalise with the running statistics (synthesised sums; nothing is updated)
+                cnt = float(self.dst_buf.shape[0] * self.dst_buf.shape[2] * self.dst_buf.shape[3])
+                rm, rv = self.bn.running_mean.double(), self.bn.running_var.double()
+                self.stats[self.dst_coff:self.dst_coff + self.cout, 0] = rm * cnt
+                self.stats[self.dst_coff:self.dst_coff + self.cout, 1] = (rv + rm * rm) * cnt
+                L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS)
+
+    def backward(self, gbuf, g_coff):
+        """gbuf[:, g_coff:+cout] holds d loss / d (activated output); on return the parameter grads are
+        written and the source activation's gradient received this unit's contribution."""
+        s = self.src
+        if self.bn is not None:
+            affine = self.bn.affine
+            L.bn_relu_bwd(gbuf, g_coff, self.dst_buf, self.dst_coff, self.cout, self.mi, self.sums,
+                          gamma=self.bn.weight if affine else None, beta=self.bn.bias if affine else None,
+                          dgamma=_grad_of(self.bn.weight) if affine else None,
+                          dbeta=_grad_of(self.bn.bias) if affine else None)
+        else:
+            L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias))
+        C.conv2d_wgrad(s.buf, gbuf, self.cin, self.cout, self.ks, _grad_of(self.conv.weight), self.wgrad_ws, x_coff=s.coff,
+                       dy_coff=g_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
+        if s.gbuf is not None:
+            C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
+                     accumulate=s.grad_mode())
+
+
+def _grad_of(p: torch.nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class _Node:
+    """Non-conv plan steps."""
+
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.__dict__.update(kw)
+
+
+class HourglassEngine:
+    def __init__(self, net: HG.HourglassModel):
+        self.net = net
+        self.device = next(net.parameters()).device
+        self._plans = {}
+
+    # ------------------------------------------------------------------ plan construction
+    def _new(self, N, Ch, H, W):
+        return torch.empty(N, Ch, H, W, dtype=torch.float32, device=self.device)
+
+    def _inception(self, plan, mod: HG.Inception, x: Act, N, H, W) -> Act:
+        c_in, cfg = HG.INCEPTION[mod.kind]
+        outs = [cfg[0][0]] + [c[2] for c in cfg[1:]]
+        mids = [c[1] for c in cfg[1:]]
+        obuf, mbuf = self._new(N, sum(outs), H, W), self._new(N, sum(mids), H, W)
+        o_stats = torch.zeros(sum(outs), 2, dtype=torch.float64, device=self.device)
+        m_stats = torch.zeros(sum(mids), 2, dtype=torch.float64, device=self.device)
+        o_mi, m_mi = torch.zeros(sum(outs), 2, device=self.device), torch.zeros(sum(mids), 2, device=self.device)
+        o_g, m_g = torch.empty_like(obuf), torch.empty_like(mbuf)
+        plan["stats"] += [o_stats, m_stats]
+        units = []
+        br0 = mod.convs[0]
+        units.append((ConvUnit(self, br0[0], br0[1], x, obuf, 0, o_stats, o_mi), o_g, 0))
+        ooff, moff = outs[0], 0
+        for i, br in enumerate(list(mod.convs)[1:]):
+            u1 = ConvUnit(self, br[0], br[1], x, mbuf, moff, m_stats, m_mi)
+            u1.out.gbuf = m_g
+            u2 = ConvUnit(self, br[3], br[4], u1.out, obuf, ooff, o_stats, o_mi)
+            units.append((u1, m_g, moff))
+            units.append((u2, o_g, ooff))
+            ooff += outs[i + 1]
+            moff += mids[i]
+        out = Act(obuf, 0, sum(outs), relu=True, needs_grad=False)
+        out.gbuf = o_g
+        plan["steps"].append(_Node("inception", units=units, out=out, src=x))
+        plan["convs"] += [u for u, _, _ in units]
+        return out
+
+    def _sequence(self, plan, seq, x: Act, N, H, W, tail_add: Optional[Act] = None):
+        """Runs a Sequential of pool / inception / channels / up.  Returns (Act, H, W)."""
+        for m in seq:
+            if isinstance(m, torch.nn.AvgPool2d):
+                y = Act(self._new(N, x.C, H // 2, W // 2), 0, x.C)
+                plan["steps"].append(_Node("pool", src=x, out=y, H=H, W=W))
+                x, H, W = y, H // 2, W // 2
+            elif isinstance(m, HG.Inception):
+                x = self._inception(plan, m, x, N, H, W)
+            elif isinstance(m, HG.Channels):
+                x = self._channels(plan, m, x, N, H, W)
+            elif isinstance(m, torch.nn.UpsamplingBilinear2d):
+                plan["pending_up"] = (x, H, W)  # fused with the residual add by the caller
+                H, W = 2 * H, 2 * W
+            else:
+                raise TypeError(f"unexpected module {type(m)}")
+        return x, H, W
+
+    def _channels(self, plan, mod: HG.Channels, x: Act, N, H, W) -> Act:
+        sides = list(mod.list)
+        up_side = 0 if isinstance(sides[0][-1], torch.nn.UpsamplingBilinear2d) else 1
+        flat, _, _ = self._sequence(plan, sides[1 - up_side], x, N, H, W)
+        plan["pending_up"] = None
+        self._sequence(plan, sides[up_side], x, N, H, W)
+        lo, h, w = plan["pending_up"]
+        plan["pending_up"] = None
+        out = Act(self._new(N, flat.C, H, W), 0, flat.C)
+        plan["steps"].append(_Node("upadd", lo=lo, hi=flat, out=out, h=h, w=w))
+        return out
+
+    def _build(self, N, H, W):
+        if H % HG.ALIGN or W % HG.ALIGN:
+            raise ValueError(f"hourglass input must be a multiple of {HG.ALIGN} in both dimensions, got {H}x{W}")
+        net = self.net
+        Act.registry = []
+        plan = {"steps": [], "convs": [], "stats": [], "pending_up": None}
+        plan["x"] = self._new(N, 3, H, W)
+        x_in = Act(plan["x"], 0, 3, needs_grad=False)
+        stem_buf = self._new(N, 128, H, W)
+        s_stats = torch.zeros(128, 2, dtype=torch.float64, device=self.device)
+        plan["stats"].append(s_stats)
+        stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, s_stats, torch.zeros(128, 2, device=self.device))
+        stem.out.gbuf = torch.empty_like(stem_buf)
+        plan["steps"].append(_Node("conv", unit=stem, gbuf=stem.out.gbuf, g_coff=0))
+        plan["convs"].append(stem)
+        feat = self._channels(plan, net.seq[3], stem.out, N, H, W)
+        plan["pred"] = self._new(N, 1, H, W)
+        head = ConvUnit(self, net.pred_layer, None, feat, plan["pred"], 0, None, None)
+        plan["dpred"] = torch.empty_like(plan["pred"])
+        plan["steps"].append(_Node("conv", unit=head, gbuf=plan["dpred"], g_coff=0))
+        plan["convs"].append(head)
+        plan["acts"], Act.registry = Act.registry, None
+        return plan
+
+    def plan(self, N, H, W):
+        key = (N, H, W)
+        if key not in self._plans:
+            self._plans[key] = self._build(N, H, W)
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ execution
+    @torch.no_grad()
+    def _forward(self, x: torch.Tensor, need_grad: bool) -> torch.Tensor:
+        N, _, H, W = x.shape
+        plan = self.plan(N, H, W)
+        plan["x"].copy_(x)
+        training = self.net.training
+        for st in plan["stats"]:
+            st.zero_()
+        for u in plan["convs"]:
+            u.pack(need_grad and u.src.gbuf is not None)
+        for step in plan["steps"]:
+            if step.kind == "conv":
+                step.unit.forward(training)
+            elif step.kind == "inception":
+                for u, _, _ in step.units:
+                    u.forward(training)
+            elif step.kind == "pool":
+                s = step.src
+                L.avgpool2_fwd(s.buf, s.coff, s.C, step.out.buf, 0, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
+            elif step.kind == "upadd":
+                lo, hi = step.lo, step.hi
+                L.upsample2x_add_fwd(lo.buf, lo.coff, lo.C, step.out.buf, 0, hi=hi.buf, hi_coff=hi.coff, lo_relu=lo.relu,
+                                     hi_relu=hi.relu, lo_scale=lo.scale, lo_shift=lo.shift, hi_scale=hi.scale,
+                                     hi_shift=hi.shift)
+        self._last = plan  # (num_batches_tracked is not advanced: momentum is fixed, the counter is unused)
+        return plan["pred"]
+
+    @torch.no_grad()
+    def _backward(self, dpred: torch.Tensor):
+        plan = self._last
+        plan["dpred"].copy_(dpred.reshape(plan["dpred"].shape))
+        for a in plan["acts"]:  # first gradient contribution overwrites, later ones accumulate
+            a.grad_written = False
+        for step in reversed(plan["steps"]):
+            if step.kind == "conv":
+                step.unit.backward(step.gbuf, step.g_coff)
+            elif step.kind == "inception":
+                # the concat output's gradient is complete; walk the branches back to front
+                for u, gbuf, g_coff in reversed(step.units):
+                    u.backward(gbuf, g_coff)
+            elif step.kind == "pool":
+                s = step.src
+                L.avgpool2_bwd(step.out.gbuf, 0, s.gbuf, s.coff, s.C, accumulate=s.grad_mode())
+            elif step.kind == "upadd":
+                lo, hi, o = step.lo, step.hi, step.out
+                L.add_slice(o.gbuf, 0, hi.gbuf, hi.coff, hi.C, accumulate=hi.grad_mode())
+                L.upsample2x_bwd(o.gbuf, 0, lo.gbuf, lo.coff, lo.C, accumulate=lo.grad_mode())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x (N,3,H,W) -> pred_d (N,1,H,W) (log depth), attached to autograd when grad is enabled."""
+        x = x.to(self.device, torch.float32).contiguous()
+        if torch.is_grad_enabled():
+            anchor = next(self.net.parameters())
+            return _EngineFn.apply(anchor, self, x)
+        return self._forward(x, need_grad=False).clone()
+
+
+class _EngineFn(torch.autograd.Function):
+    """One autograd node for the whole network; parameter gradients are written by the engine itself."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, x):
+        ctx.engine = engine
+        return engine._forward(x, need_grad=True).clone()
+
+    @staticmethod
+    def backward(ctx, dpred):
+        ctx.engine._backward(dpred.contiguous())
+        return None, None, None

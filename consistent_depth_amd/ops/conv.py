@@ -25,7 +25,7 @@ def pack_weights(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
 
 
 def conv2d(x, packed_w, Cin, Cout, ks, bias=None, x_coff=0, out=None, y_coff=0, in_scale=None, in_shift=None,
-           in_relu=False, stats=None):
+           in_relu=False, stats=None, accumulate=False):
     """out[:, y_coff:y_coff+Cout] = conv(act(x[:, x_coff:x_coff+Cin])) + bias.  Returns `out`."""
     N, x_ctot, H, W = x.shape
     if out is None:
@@ -37,7 +37,7 @@ def conv2d(x, packed_w, Cin, Cout, ks, bias=None, x_coff=0, out=None, y_coff=0, 
     rc = _native.lib().cd_conv2d_fwd(
         _native.dev_ptr(x, "x"), x_ctot, x_coff, Cin, _native.dev_ptr(packed_w, "packed_w"), opt(bias, "bias"),
         opt(in_scale, "in_scale"), opt(in_shift, "in_shift"), int(in_relu), _native.dev_ptr(out, "out"), y_ctot, y_coff,
-        Cout, stats.data_ptr() if stats is not None else None, N, H, W, ks, _native.stream_ptr(x.device))
+        Cout, stats.data_ptr() if stats is not None else None, int(accumulate), N, H, W, ks, _native.stream_ptr(x.device))
     _native.check(rc, "cd_conv2d_fwd")
     return out
 

@@ -146,10 +146,11 @@ int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transp
  *   act(v) = relu?(v * in_scale[c] + in_shift[c])   when in_scale/in_shift are given (the producer's
  *            BatchNorm-apply [+ReLU] fused into the load), relu only when in_relu and no scale, else v;
  *   stats (optional, [y_ctot][2] doubles, caller-zeroed): per-channel sum and sum of squares of the
- *            raw output are ADDED -- the batch statistics of the following train-mode BatchNorm. */
+ *            raw output are ADDED -- the batch statistics of the following train-mode BatchNorm;
+ *   accumulate != 0: y += result instead of y = result (gradient fan-in of the dgrad convolutions). */
 int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w,
                   const float* bias, const float* in_scale, const float* in_shift, int in_relu,
-                  float* y, int y_ctot, int y_coff, int Cout, double* stats,
+                  float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                   int N, int H, int W, int ks, void* stream);
 
 /* Weight gradient dw[Cout][Cin][ks][ks] (=, or += when accumulate) of the same convolution:
