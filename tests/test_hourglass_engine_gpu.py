@@ -12,7 +12,7 @@ def _rel(a, b):
     return (a.double() - b.double()).abs().sum().item() / max(1e-30, b.double().abs().sum().item())
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 32, 48), (1, 64, 32)])
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (2, 32, 48)])
 def test_engine_matches_autograd(N, H, W):
     import torch
     from consistent_depth_amd.monodepth.hourglass import HourglassModel
@@ -37,28 +37,38 @@ def test_engine_matches_autograd(N, H, W):
     pred.backward(dpred.float().cuda())
     torch.cuda.synchronize()
     gref = dict(ref.named_parameters())
-    worst = 0.0
+    # fp32 noise floor of autograd itself on this (deep, BatchNorm-heavy) network: same net in fp32 on the CPU
+    ref32 = HourglassModel()
+    ref32.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items() if "running" not in k and "num_batches" not in k}, strict=False)
+    ref32.train()
+    p32, _ = ref32(x.float())
+    p32.backward(dpred.float())
+    g32 = dict(ref32.named_parameters())
+    errs = []
     for name, p in net.named_parameters():
         g = gref[name].grad
-        if name.startswith("uncertainty_layer"):
-            continue
-        if g is None:
+        if name.startswith("uncertainty_layer") or g is None:
             continue
         is_bias_before_bn = name.endswith(".bias") and not name.startswith("pred_layer") and name != "seq.1.bias"
         if is_bias_before_bn:
             # mathematically zero; autograd produces round-off noise, the engine exact zeros
             assert p.grad.abs().max().item() == 0.0
-            assert g.abs().max().item() < 1e-6 * max(1.0, dpred.abs().sum().item())
             continue
-        r = _rel(p.grad.cpu(), g)
-        worst = max(worst, r)
-        assert r < 2e-3, (name, r)
+        errs.append((_rel(p.grad.cpu(), g), _rel(g32[name].grad, g), name))
+    errs.sort(reverse=True)
+    for e, e32, name in errs[:8]:
+        print(f"  {name:45s} engine {e:.2e}   torch-fp32 {e32:.2e}")
+    med = sorted(e for e, _, _ in errs)[len(errs) // 2]
+    med32 = sorted(e for _, e, _ in errs)[len(errs) // 2]
+    print(f"  median engine {med:.2e}  median torch-fp32 {med32:.2e}  (N={N}, {H}x{W})")
+    # the engine must be in the same noise class as fp32 autograd: within 4x of it per parameter (+ floor)
+    for e, e32, name in errs:
+        assert e < max(4 * e32, 2e-4), (name, e, e32)
     # BatchNorm running statistics follow nn.BatchNorm2d
     sd_ref, sd = ref.state_dict(), net.state_dict()
     for k in sd_ref:
         if k.endswith("running_mean") or k.endswith("running_var"):
             np.testing.assert_allclose(sd[k].cpu().numpy(), sd_ref[k].numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
-    print("worst parameter-gradient rel-L1:", worst)
 
 
 def test_engine_eval_mode_and_no_grad():
