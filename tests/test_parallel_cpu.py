@@ -1,0 +1,90 @@
+"""CPU (gloo, world_size 2): the data-parallel plumbing of consistent_depth_amd.parallel --
+pair-list sharding and the single flat all-reduce (gradients + loss slot) with the 1/world scale."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from consistent_depth_amd import parallel
+
+
+def test_shard_indices_cover_and_balance():
+    n, bs = 715, 4  # BASELINE C1: 244 frames hierarchical2 -> 715 pairs
+    for world in (1, 2, 4, 8):
+        plans = [parallel.shard_indices(n, epoch=3, seed=0, rank=r, world=world, batch_size=bs) for r in range(world)]
+        steps = {len(p) for p in plans}
+        assert len(steps) == 1, "all ranks must run the same number of steps"
+        seen = [i for p in plans for step in p for i in step]
+        assert len(seen) == len(set(seen)), "no pair may be trained twice in an epoch"
+        if world == 1:
+            assert sorted(seen) == list(range(n)) and len(plans[0]) == 179  # 179 it/epoch, last batch short
+            assert len(plans[0][-1]) == n - 178 * bs
+        else:
+            assert len(seen) >= n - bs * world
+        for s in range(len(plans[0])):
+            sizes = {len(p[s]) for p in plans}
+            assert len(sizes) == 1
+    # same (seed, epoch) -> same permutation on every rank; different epochs differ
+    a = parallel.shard_indices(n, 0, 0, 0, 1, bs)
+    b = parallel.shard_indices(n, 1, 0, 0, 1, bs)
+    assert a != b and a == parallel.shard_indices(n, 0, 0, 0, 1, bs)
+    # validation order: unshuffled
+    v = parallel.shard_indices(10, 0, 0, 0, 1, 4, shuffle=False)
+    assert v == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, lr, w = parallel.init(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.world_size() == world
+    torch.manual_seed(0)
+    # a tiny surrogate model: loss_b = mean over the rank's pairs of (w . x_b)^2
+    wvec = torch.nn.Parameter(torch.linspace(-1, 1, 37))
+    data = torch.randn(8, 37, generator=torch.Generator().manual_seed(5))
+    plan = parallel.shard_indices(8, 0, 0, rank, world, batch_size=4 // world * world // world if False else 4 // world)
+    ids = plan[0]
+    loss = ((data[ids] @ wvec) ** 2).mean()
+    loss.backward()
+    # flat reduce buffer = [grads | pad | loss slot], like FlatAdam.reduce_buffer
+    buf = torch.zeros(64 + 64)
+    buf[:37] = wvec.grad
+    buf[64] = loss.detach()
+    parallel.allreduce_sum_(buf)
+    grad_mean = buf[:37] / world          # 1/world is folded into the Adam kernel (grad_scale)
+    loss_sum = buf[64]
+    # reference: one process with the global batch
+    w2 = torch.nn.Parameter(torch.linspace(-1, 1, 37))
+    all_ids = [i for rr in range(world) for i in parallel.shard_indices(8, 0, 0, rr, world, 4 // world)[0]]
+    ref_loss = ((data[all_ids] @ w2) ** 2).mean()
+    ref_loss.backward()
+    ok = torch.allclose(grad_mean, w2.grad, rtol=1e-5, atol=1e-6) and abs(loss_sum.item() / world - ref_loss.item()) < 1e-5
+    # NaN on one rank poisons the summed guard scalar on every rank -> all ranks skip together
+    g = torch.tensor([float("nan") if rank == 1 else 1.0])
+    parallel.allreduce_sum_(g)
+    ok = ok and bool(torch.isnan(g).item())
+    t = [torch.full((3,), float(rank))]
+    parallel.broadcast_(t, src=0)
+    ok = ok and bool((t[0] == 0).all())
+    out[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce_matches_single_process():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
