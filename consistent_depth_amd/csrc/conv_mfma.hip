@@ -31,7 +31,7 @@ constexpr int CV_TX = 32;  // output tile width (2 M-tiles)
 
 template <int KS> struct ConvCfg {
     static constexpr int TY = (KS >= 7) ? 16 : 8;          // output rows per block (4 waves x TY/4 rows)
-    static constexpr int CI_CHUNK = (KS >= 7) ? 4 : 8;     // input channels staged per round
+    static constexpr int CI_CHUNK = (KS >= 7) ? 4 : (KS == 1 ? 32 : 8);  // input channels staged per round (1x1 = pure GEMM: long K chunks)
     static constexpr int RS = CV_TX + KS - 1;              // LDS row stride (floats)
     static constexpr int ROWS = TY + KS - 1;
     static constexpr int PLANE_RAW = ROWS * RS;
@@ -108,6 +108,21 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         __syncthreads();  // previous round's fragments are consumed
         // ---- stage the input tile (zero padding, fused BN-apply + ReLU of the producer)
+        if (KS == 1 && (W & 3) == 0) {
+            // 1x1: no halo, tile rows are 32 contiguous pixels -> 16-byte loads
+            for (int i = threadIdx.x; i < CI * ROWS * (RS / 4); i += kBlock) {
+                const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
+                const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
+                const int ci = chunk * CI + cc, gy = Y0 + r, gx = X0 + c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < Cin && gy < H && gx < W) {
+                    v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
+                    if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+                    if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                *reinterpret_cast<float4*>(s_in + cc * PS + r * RS + c) = v;
+            }
+        } else
         for (int i = threadIdx.x; i < CI * ROWS * RS; i += kBlock) {
             const int cc = i / (ROWS * RS), rem = i - cc * (ROWS * RS);
             const int r = rem / RS, c = rem - r * RS;
@@ -232,7 +247,7 @@ size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed)
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
     const int OC = transposed ? Cin : Cout, IC = transposed ? Cout : Cin;
     const int cot = cd::pick_co_tiles(ks, OC), cob = cot * 16, cobp = cd::co_stride_padded(cob);
-    const int ci_chunk = ks >= 7 ? 4 : 8;
+    const int ci_chunk = ks >= 7 ? 4 : (ks == 1 ? 32 : 8);
     const int groups = (OC + cob - 1) / cob, chunks = (IC + ci_chunk - 1) / ci_chunk;
     return (size_t)groups * chunks * ks * ks * ci_chunk * cobp;
 }
@@ -242,7 +257,7 @@ int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transp
     if (!w || !packed || total == 0) return CD_ERR_INVALID_ARG;
     const int OC = transposed ? Cin : Cout;
     const int cot = cd::pick_co_tiles(ks, OC), cob = cot * 16, cobp = cd::co_stride_padded(cob);
-    const int ci_chunk = ks >= 7 ? 4 : 8;
+    const int ci_chunk = ks >= 7 ? 4 : (ks == 1 ? 32 : 8);
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(cd::pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ks,

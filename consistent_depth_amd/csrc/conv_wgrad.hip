@@ -21,17 +21,18 @@ namespace cd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WG_TX = 32, WG_TY = 8;
+constexpr int WG_TX = 32;
 
 template <int KS> struct WgCfg {
+    static constexpr int TY = (KS == 1) ? 4 : 8;                     // tile rows (1x1: smaller tile -> 2 blocks per CU)
     static constexpr int NW_T = (KS >= 7) ? 4 : (KS == 5 ? 2 : 1);  // waves splitting the taps
     static constexpr int NW_R = 4 / NW_T;                            // waves splitting the rows
     static constexpr int TAPS = KS * KS;
     static constexpr int TPW = (TAPS + NW_T - 1) / NW_T;             // taps per wave
-    static constexpr int RS = WG_TX + KS - 1, ROWS = WG_TY + KS - 1;
+    static constexpr int RS = WG_TX + KS - 1, ROWS = TY + KS - 1;
     static constexpr int PS_IN_RAW = ROWS * RS;
     static constexpr int PS_IN = PS_IN_RAW + ((2 - (PS_IN_RAW % 32)) + 32) % 32;   // == 2 (mod 32)
-    static constexpr int PS_DY = WG_TY * WG_TX + 2;                                  // 258 == 2 (mod 32)
+    static constexpr int PS_DY = TY * WG_TX + 2;                                     // == 2 (mod 32)
 };
 
 template <int KS, int CO_T, int CI_T>
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
     float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y) {
     using Cfg = WgCfg<KS>;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, TPW = Cfg::TPW, NW_T = Cfg::NW_T, NW_R = Cfg::NW_R;
-    constexpr int RS = Cfg::RS, ROWS = Cfg::ROWS, PSI = Cfg::PS_IN, PSD = Cfg::PS_DY;
+    constexpr int RS = Cfg::RS, ROWS = Cfg::ROWS, PSI = Cfg::PS_IN, PSD = Cfg::PS_DY, WG_TY = Cfg::TY;
     constexpr int COB = CO_T * 16, CIB = CI_T * 16;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -73,6 +74,18 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
         __syncthreads();
         // ---- stage dY tile (zero outside the image / beyond Cout)
         const float* dyn = dy + ((size_t)n * dy_ctot + dy_coff) * HW;
+        if ((W & 3) == 0) {  // 16-byte global loads (rows of the tile are 32 contiguous pixels)
+            for (int i = threadIdx.x; i < COB * WG_TY * (WG_TX / 4); i += kBlock) {
+                const int c = i / (WG_TY * (WG_TX / 4)), rem = i - c * (WG_TY * (WG_TX / 4));
+                const int r = rem / (WG_TX / 4), col = (rem - r * (WG_TX / 4)) * 4;
+                const int co = cog * COB + c, gy = Y0 + r, gx = X0 + col;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (co < Cout && gy < H && gx < W) v = *reinterpret_cast<const float4*>(dyn + (size_t)co * HW + (size_t)gy * W + gx);
+                float* d = s_dy + c * PSD + r * WG_TX + col;   // plane stride is 2 (mod 4): 8-byte aligned only
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+            }
+        } else
         for (int i = threadIdx.x; i < COB * WG_TY * WG_TX; i += kBlock) {
             const int c = i / (WG_TY * WG_TX), rem = i - c * (WG_TY * WG_TX);
             const int r = rem / WG_TX, col = rem - r * WG_TX;
@@ -83,6 +96,22 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
         }
         // ---- stage activated input tile with halo (zero padding)
         const float* xn = x + ((size_t)n * x_ctot + x_coff) * HW;
+        if (KS == 1 && (W & 3) == 0) {
+            for (int i = threadIdx.x; i < CIB * ROWS * (RS / 4); i += kBlock) {
+                const int c = i / (ROWS * (RS / 4)), rem = i - c * (ROWS * (RS / 4));
+                const int r = rem / (RS / 4), col = (rem - r * (RS / 4)) * 4;
+                const int ci = cig * CIB + c, gy = Y0 + r, gx = X0 + col;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < Cin && gy < H && gx < W) {
+                    v = *reinterpret_cast<const float4*>(xn + (size_t)ci * HW + (size_t)gy * W + gx);
+                    if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+                    if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                float* d = s_in + c * PSI + r * RS + col;
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+            }
+        } else
         for (int i = threadIdx.x; i < CIB * ROWS * RS; i += kBlock) {
             const int c = i / (ROWS * RS), rem = i - c * (ROWS * RS);
             const int r = rem / RS, col = rem - r * RS;
@@ -175,7 +204,7 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
                           int W, hipStream_t s) {
     using Cfg = WgCfg<KS>;
     constexpr int COB = CO_T * 16, CIB = CI_T * 16;
-    const int tiles_x = (W + WG_TX - 1) / WG_TX, tiles_y = (H + WG_TY - 1) / WG_TY;
+    const int tiles_x = (W + WG_TX - 1) / WG_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
     const int cogs = (Cout + COB - 1) / COB, cigs = (Cin + CIB - 1) / CIB;
     const int items = N * tiles_x * tiles_y;
     // enough blocks to fill the chip (~3 per CU), few enough that the atomic flush stays small
@@ -214,7 +243,8 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     const size_t wsf = cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks);
     if (wsf == 0) return CD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, wsf * sizeof(float), s) != hipSuccess) return CD_ERR_LAUNCH;
+    // accumulate bit 1 (value 2): the caller has already zeroed `workspace` (one memset over an arena of many)
+    if (!(accumulate & 2) && hipMemsetAsync(workspace, 0, wsf * sizeof(float), s) != hipSuccess) return CD_ERR_LAUNCH;
     const cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
     int rc = CD_ERR_UNSUPPORTED;
 #define CD_WG(K, A, C) rc = cd::launch_wgrad_t<K, A, C>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, s)
@@ -242,7 +272,7 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     const int cob = p.co_t * 16, cib = p.ci_t * 16;
     const int total = Cout * Cin * ks * ks;
     hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
-                       workspace, Cout, Cin, ks, cob, cib, (Cin + cib - 1) / cib, dw, accumulate);
+                       workspace, Cout, Cin, ks, cob, cib, (Cin + cib - 1) / cib, dw, accumulate & 1);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -246,12 +246,12 @@ int cd_bn_normalize(float* x, int ctot, int coff, int C, const double* stats, fl
 }
 
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C, const float* gamma,
-                   const float* beta, const float* mean_invstd, double* sums, float* dgamma, float* dbeta, int N, int H,
-                   int W, void* stream) {
+                   const float* beta, const float* mean_invstd, double* sums, int sums_prezeroed, float* dgamma,
+                   float* dbeta, int N, int H, int W, void* stream) {
     CD_ARGCHK(dA && xhat && mean_invstd && sums && C > 0 && d_coff >= 0 && d_coff + C <= d_ctot && x_coff >= 0 && x_coff + C <= x_ctot);
     CD_ARGCHK((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr));
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s) != hipSuccess) return CD_ERR_LAUNCH;
+    if (!sums_prezeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s) != hipSuccess) return CD_ERR_LAUNCH;
     const dim3 grid = cd::plane_grid(H * W, C, N, 8);
     hipLaunchKernelGGL(cd::bn_relu_bwd_reduce_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
                        gamma, beta, sums, H * W);

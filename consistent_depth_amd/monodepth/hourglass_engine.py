@@ -62,8 +62,7 @@ class ConvUnit:
         affine = bn_mod is not None and bn_mod.affine
         self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None,
                        scale=bn_mod.weight if affine else None, shift=bn_mod.bias if affine else None, needs_grad=False)
-        self.wgrad_ws = C.wgrad_workspace(self.cout, self.cin, self.ks, dst_buf.device)
-        self.sums = torch.zeros(2 * self.cout, dtype=torch.float64, device=dst_buf.device)
+        self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
         self.pk = self.pkT = None
 
     def pack(self, need_dgrad):
@@ -95,11 +94,11 @@ class ConvUnit:
             L.bn_relu_bwd(gbuf, g_coff, self.dst_buf, self.dst_coff, self.cout, self.mi, self.sums,
                           gamma=self.bn.weight if affine else None, beta=self.bn.bias if affine else None,
                           dgamma=_grad_of(self.bn.weight) if affine else None,
-                          dbeta=_grad_of(self.bn.bias) if affine else None)
+                          dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True)
         else:
             L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias))
         C.conv2d_wgrad(s.buf, gbuf, self.cin, self.cout, self.ks, _grad_of(self.conv.weight), self.wgrad_ws, x_coff=s.coff,
-                       dy_coff=g_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
+                       dy_coff=g_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
         if s.gbuf is not None:
             C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode())
@@ -134,11 +133,9 @@ class HourglassEngine:
         outs = [cfg[0][0]] + [c[2] for c in cfg[1:]]
         mids = [c[1] for c in cfg[1:]]
         obuf, mbuf = self._new(N, sum(outs), H, W), self._new(N, sum(mids), H, W)
-        o_stats = torch.zeros(sum(outs), 2, dtype=torch.float64, device=self.device)
-        m_stats = torch.zeros(sum(mids), 2, dtype=torch.float64, device=self.device)
+        o_stats, m_stats = self._stats(plan, sum(outs)), self._stats(plan, sum(mids))
         o_mi, m_mi = torch.zeros(sum(outs), 2, device=self.device), torch.zeros(sum(mids), 2, device=self.device)
         o_g, m_g = torch.empty_like(obuf), torch.empty_like(mbuf)
-        plan["stats"] += [o_stats, m_stats]
         units = []
         br0 = mod.convs[0]
         units.append((ConvUnit(self, br0[0], br0[1], x, obuf, 0, o_stats, o_mi), o_g, 0))
@@ -192,12 +189,12 @@ class HourglassEngine:
             raise ValueError(f"hourglass input must be a multiple of {HG.ALIGN} in both dimensions, got {H}x{W}")
         net = self.net
         Act.registry = []
-        plan = {"steps": [], "convs": [], "stats": [], "pending_up": None}
+        plan = {"steps": [], "convs": [], "pending_up": None, "stats_used": 0,
+                "stats_arena": torch.zeros(16384, 2, dtype=torch.float64, device=self.device)}
         plan["x"] = self._new(N, 3, H, W)
         x_in = Act(plan["x"], 0, 3, needs_grad=False)
         stem_buf = self._new(N, 128, H, W)
-        s_stats = torch.zeros(128, 2, dtype=torch.float64, device=self.device)
-        plan["stats"].append(s_stats)
+        s_stats = self._stats(plan, 128)
         stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, s_stats, torch.zeros(128, 2, device=self.device))
         stem.out.gbuf = torch.empty_like(stem_buf)
         plan["steps"].append(_Node("conv", unit=stem, gbuf=stem.out.gbuf, g_coff=0))
@@ -209,7 +206,30 @@ class HourglassEngine:
         plan["steps"].append(_Node("conv", unit=head, gbuf=plan["dpred"], g_coff=0))
         plan["convs"].append(head)
         plan["acts"], Act.registry = Act.registry, None
+        self._carve_arenas(plan)
         return plan
+
+    def _stats(self, plan, channels):
+        """(channels, 2) fp64 view of the plan's statistics arena (zeroed by ONE memset per forward)."""
+        a = plan["stats_used"]
+        if a + channels > plan["stats_arena"].shape[0]:
+            raise RuntimeError("statistics arena too small")
+        plan["stats_used"] = a + channels
+        return plan["stats_arena"][a:a + channels]
+
+    def _carve_arenas(self, plan):
+        """One arena for all wgrad workspaces and one for all BN-backward sums: two memsets per backward
+        instead of two per convolution."""
+        units = plan["convs"]
+        sizes = [(C.wgrad_workspace_floats(u.cout, u.cin, u.ks) + 63) // 64 * 64 for u in units]
+        plan["wgrad_arena"] = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
+        plan["sums_arena"] = torch.zeros(sum(2 * u.cout for u in units), dtype=torch.float64, device=self.device)
+        o = so = 0
+        for u, n in zip(units, sizes):
+            u.wgrad_ws = plan["wgrad_arena"][o:o + n]
+            u.sums = plan["sums_arena"][so:so + 2 * u.cout]
+            o += n
+            so += 2 * u.cout
 
     def plan(self, N, H, W):
         key = (N, H, W)
@@ -224,8 +244,7 @@ class HourglassEngine:
         plan = self.plan(N, H, W)
         plan["x"].copy_(x)
         training = self.net.training
-        for st in plan["stats"]:
-            st.zero_()
+        plan["stats_arena"].zero_()
         for u in plan["convs"]:
             u.pack(need_grad and u.src.gbuf is not None)
         for step in plan["steps"]:
@@ -249,6 +268,8 @@ class HourglassEngine:
     def _backward(self, dpred: torch.Tensor):
         plan = self._last
         plan["dpred"].copy_(dpred.reshape(plan["dpred"].shape))
+        plan["wgrad_arena"].zero_()
+        plan["sums_arena"].zero_()
         for a in plan["acts"]:  # first gradient contribution overwrites, later ones accumulate
             a.grad_written = False
         for step in reversed(plan["steps"]):

@@ -42,19 +42,22 @@ def conv2d(x, packed_w, Cin, Cout, ks, bias=None, x_coff=0, out=None, y_coff=0, 
     return out
 
 
+def wgrad_workspace_floats(Cout, Cin, ks) -> int:
+    return _native.lib().cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks)
+
+
 def wgrad_workspace(Cout, Cin, ks, device) -> torch.Tensor:
-    n = _native.lib().cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks)
-    return torch.empty(n, dtype=torch.float32, device=device)
+    return torch.empty(wgrad_workspace_floats(Cout, Cin, ks), dtype=torch.float32, device=device)
 
 
 def conv2d_wgrad(x, dy, Cin, Cout, ks, dw, workspace, x_coff=0, dy_coff=0, in_scale=None, in_shift=None,
-                 in_relu=False, accumulate=False):
+                 in_relu=False, accumulate=False, prezeroed=False):
     """dw (Cout,Cin,ks,ks) (+)= sum dy[:, dy_coff:+Cout] * act(x[:, x_coff:+Cin]) shifted by the taps."""
     N, x_ctot, H, W = x.shape
     opt = lambda t, name: _native.dev_ptr(t, name) if t is not None else None  # noqa: E731
     rc = _native.lib().cd_conv2d_wgrad(
         _native.dev_ptr(x, "x"), x_ctot, x_coff, Cin, opt(in_scale, "in_scale"), opt(in_shift, "in_shift"), int(in_relu),
-        _native.dev_ptr(dy, "dy"), dy.shape[1], dy_coff, Cout, _native.dev_ptr(dw, "dw"), int(accumulate),
+        _native.dev_ptr(dy, "dy"), dy.shape[1], dy_coff, Cout, _native.dev_ptr(dw, "dw"), int(accumulate) | (2 if prezeroed else 0),
         _native.dev_ptr(workspace, "workspace"), N, H, W, ks, _native.stream_ptr(x.device))
     _native.check(rc, "cd_conv2d_wgrad")
     return dw

@@ -24,10 +24,12 @@ def bn_normalize(x, coff, C, stats, mean_invstd, eps=1e-5, running_mean=None, ru
     _native.check(rc, "cd_bn_normalize")
 
 
-def bn_relu_bwd(dA, d_coff, xhat, x_coff, C, mean_invstd, sums, gamma=None, beta=None, dgamma=None, dbeta=None):
+def bn_relu_bwd(dA, d_coff, xhat, x_coff, C, mean_invstd, sums, gamma=None, beta=None, dgamma=None, dbeta=None,
+                sums_prezeroed=False):
     N, d_ctot, H, W = dA.shape
     rc = _native.lib().cd_bn_relu_bwd(_p(dA), d_ctot, d_coff, _p(xhat), xhat.shape[1], x_coff, C, _o(gamma), _o(beta),
-                                      _p(mean_invstd), sums.data_ptr(), _o(dgamma), _o(dbeta), N, H, W, _s(dA))
+                                      _p(mean_invstd), sums.data_ptr(), int(sums_prezeroed), _o(dgamma), _o(dbeta), N, H, W,
+                                      _s(dA))
     _native.check(rc, "cd_bn_relu_bwd")
 
 

@@ -155,7 +155,8 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
 
 /* Weight gradient dw[Cout][Cin][ks][ks] (=, or += when accumulate) of the same convolution:
  * sum over n,y,x of dy[n][co][y][x] * act(x)[n][ci][y+ky-P][x+kx-P]  (act as in cd_conv2d_fwd).
- * workspace: cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) floats (zeroed inside). */
+ * workspace: cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) floats, zeroed inside unless bit 1 of
+ * `accumulate` (value 2) says the caller already zeroed it (one memset over an arena of many). */
 size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks);
 int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale,
                     const float* in_shift, int in_relu, const float* dy, int dy_ctot, int dy_coff,
@@ -174,10 +175,10 @@ int cd_bn_normalize(float* x, int ctot, int coff, int C, const double* stats, fl
 /* Backward of relu(gamma * x_hat + beta) + train-mode BatchNorm in one call: dA (gradient w.r.t. the
  * activated output) is replaced IN PLACE by the gradient w.r.t. the raw (pre-BN) tensor.  gamma/beta
  * NULL = BatchNorm2d(affine=False); dgamma/dbeta[C] receive the affine gradients when given.
- * sums: scratch of 2*C doubles. */
+ * sums: scratch of 2*C doubles, zeroed inside unless sums_prezeroed (one memset over an arena of many). */
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C,
                    const float* gamma, const float* beta, const float* mean_invstd, double* sums,
-                   float* dgamma, float* dbeta, int N, int H, int W, void* stream);
+                   int sums_prezeroed, float* dgamma, float* dbeta, int N, int H, int W, void* stream);
 
 /* AvgPool2d(2) of act(x) and its adjoint (dx = gradient w.r.t. the ACTIVATED input, (+)= when accumulate). */
 int cd_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* in_scale, const float* in_shift,
