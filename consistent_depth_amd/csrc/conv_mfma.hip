@@ -29,8 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CV_TX = 32;  // output tile width (2 M-tiles)
 
-template <int KS> struct ConvCfg {
-    static constexpr int TY = (KS >= 7) ? 16 : 8;          // output rows per block (4 waves x TY/4 rows)
+template <int KS, int TY_> struct ConvCfg {
+    static constexpr int TY = TY_;                          // output rows per block (4 waves x TY/4 rows): 4, 8 or 16
     static constexpr int CI_CHUNK = (KS >= 7) ? 4 : (KS == 1 ? 32 : 8);  // input channels staged per round (1x1 = pure GEMM: long K chunks)
     static constexpr int RS = CV_TX + KS - 1;              // LDS row stride (floats)
     static constexpr int ROWS = TY + KS - 1;
@@ -69,14 +69,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int C
 }
 
 // ---------------------------------------------------------------- the convolution
-template <int KS, int CO_T>
+template <int KS, int CO_T, int TYP>
 __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
     const float* __restrict__ wpk, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     float* __restrict__ y, int y_ctot, int y_coff, int Cout,
     double* __restrict__ stats, int accumulate, int H, int W, int tiles_x) {
-    using Cfg = ConvCfg<KS>;
+    using Cfg = ConvCfg<KS, TYP>;
     constexpr int TY = Cfg::TY, CI = Cfg::CI_CHUNK, RS = Cfg::RS, PS = Cfg::PS, ROWS = Cfg::ROWS;
     constexpr int P = (KS - 1) / 2, TAPS = KS * KS;
     constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
@@ -105,8 +105,59 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     const int a_lane = (lane >> 4) * PS + (lane & 15);      // A fragment: channel k = lane>>4, pixel i = lane&15
     const int b_lane = (lane >> 4) * COBP + (lane & 15);    // B fragment: channel k, out-channel j
 
+    // 1x1 (pure GEMM, little math per staged byte): software pipeline -- the next chunk's global loads are in
+    // flight in registers while the MFMAs of the current chunk run
+    constexpr int PF_IN = (KS == 1) ? (CI * ROWS * (RS / 4) + kBlock - 1) / kBlock : 1;
+    constexpr int PF_W = (KS == 1) ? (W_ELEMS / 4 + kBlock - 1) / kBlock : 1;
+    float4 pf_in[PF_IN], pf_w[PF_W];
+    const bool pipelined = (KS == 1) && ((W & 3) == 0);
+    auto pf_load = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < PF_IN; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
+            const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
+            const int ci = chunk * CI + cc, gy = Y0 + r, gx = X0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < CI * ROWS * (RS / 4) && ci < Cin && gy < H && gx < W) {
+                v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
+                if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+                if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            pf_in[q] = v;
+        }
+        const float* wsrc = wpk + ((size_t)grp * n_chunks + chunk) * W_ELEMS;
+#pragma unroll
+        for (int q = 0; q < PF_W; ++q) {
+            const int i = (threadIdx.x + q * kBlock) * 4;
+            pf_w[q] = i < W_ELEMS ? *reinterpret_cast<const float4*>(wsrc + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto pf_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < PF_IN; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            if (i < CI * ROWS * (RS / 4)) {
+                const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
+                const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
+                *reinterpret_cast<float4*>(s_in + cc * PS + r * RS + c) = pf_in[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PF_W; ++q) {
+            const int i = (threadIdx.x + q * kBlock) * 4;
+            if (i < W_ELEMS) *reinterpret_cast<float4*>(s_w + i) = pf_w[q];
+        }
+    };
+    if (pipelined) pf_load(0);
+
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         __syncthreads();  // previous round's fragments are consumed
+        if (pipelined) {
+            pf_store();
+            if (chunk + 1 < n_chunks) pf_load(chunk + 1);
+            __syncthreads();
+        } else {
         // ---- stage the input tile (zero padding, fused BN-apply + ReLU of the producer)
         if (KS == 1 && (W & 3) == 0) {
             // 1x1: no halo, tile rows are 32 contiguous pixels -> 16-byte loads
@@ -140,6 +191,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
         for (int i = threadIdx.x * 4; i < W_ELEMS; i += kBlock * 4)
             *reinterpret_cast<float4*>(s_w + i) = *reinterpret_cast<const float4*>(wsrc + i);
         __syncthreads();
+        }
 
         // ---- MFMA over (channel quad, tap)
 #pragma unroll
@@ -210,22 +262,22 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     }
 }
 
-template <int KS, int CO_T>
+template <int KS, int CO_T, int TYP>
 static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wpk, const float* bias,
                          const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff,
                          int Cout, double* stats, int accumulate, int N, int H, int W, hipStream_t s) {
-    using Cfg = ConvCfg<KS>;
+    using Cfg = ConvCfg<KS, TYP>;
     constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
     const int tiles_x = (W + CV_TX - 1) / CV_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
     const int groups = (Cout + COB - 1) / COB;
     const size_t lds = sizeof(float) * ((size_t)Cfg::CI_CHUNK * Cfg::PS + (size_t)KS * KS * Cfg::CI_CHUNK * COBP);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<KS, CO_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<KS, CO_T, TYP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T>), dim3(tiles_x * tiles_y, groups, N), dim3(kBlock), lds, s, x, x_ctot,
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T, TYP>), dim3(tiles_x * tiles_y, groups, N), dim3(kBlock), lds, s, x, x_ctot,
                        x_coff, Cin, wpk, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, H, W, tiles_x);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
@@ -241,7 +293,15 @@ static inline int pick_co_tiles(int ks, int cout) {
 
 }  // namespace cd
 
+namespace cd { static int g_force_conv_ty = 0; }
+
 extern "C" {
+
+int cd_debug_force_conv_tile_rows(int ty) {
+    if (!(ty == 0 || ty == 4 || ty == 8 || ty == 16)) return CD_ERR_INVALID_ARG;
+    cd::g_force_conv_ty = ty;
+    return CD_OK;
+}
 
 size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed) {
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
@@ -274,16 +334,29 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
     if ((in_scale == nullptr) != (in_shift == nullptr)) return CD_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int cot = cd::pick_co_tiles(ks, Cout);
-#define CD_CONV(K, T) return cd::launch_conv_t<K, T>(x, x_ctot, x_coff, Cin, packed_w, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
-#define CD_CONV_K(K)                     \
-    if (ks == K) {                       \
-        if (cot == 1) CD_CONV(K, 1);     \
-        if (cot == 2) CD_CONV(K, 2);     \
-        if (cot == 4) CD_CONV(K, 4);     \
+    // tile height: the tallest tile that still yields enough blocks to fill 256 CUs (the deep hourglass levels
+    // are only 96x56 ... 24x14 pixels)
+    const int groups = (Cout + cot * 16 - 1) / (cot * 16), tiles_x = (W + cd::CV_TX - 1) / cd::CV_TX;
+    int ty = ks >= 7 ? 16 : 8;
+    while (ty > 4 && (long long)tiles_x * ((H + ty - 1) / ty) * groups * N < 640) ty >>= 1;
+    if (cd::g_force_conv_ty) ty = cd::g_force_conv_ty;
+#define CD_CONV(K, T, Y) return cd::launch_conv_t<K, T, Y>(x, x_ctot, x_coff, Cin, packed_w, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
+#define CD_CONV_T(K, T)                     \
+    {                                       \
+        if (ty == 16) CD_CONV(K, T, 16);    \
+        if (ty == 8) CD_CONV(K, T, 8);      \
+        CD_CONV(K, T, 4);                   \
+    }
+#define CD_CONV_K(K)                        \
+    if (ks == K) {                          \
+        if (cot == 1) CD_CONV_T(K, 1)       \
+        if (cot == 2) CD_CONV_T(K, 2)       \
+        if (cot == 4) CD_CONV_T(K, 4)       \
     }
     CD_CONV_K(1) CD_CONV_K(3) CD_CONV_K(5) CD_CONV_K(7)
-    if (ks == 11 && cot == 1) CD_CONV(11, 1);
+    if (ks == 11 && cot == 1) CD_CONV_T(11, 1)
 #undef CD_CONV_K
+#undef CD_CONV_T
 #undef CD_CONV
     return CD_ERR_UNSUPPORTED;
 }

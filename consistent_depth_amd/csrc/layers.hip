@@ -208,18 +208,20 @@ __global__ __launch_bounds__(kBlock) void add_slice_kernel(const float* __restri
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) d[i] = accumulate ? d[i] + s[i] : s[i];
 }
 
-// out[c] = sum over n, y, x of src[n][coff+c]   (bias gradient of a conv that is NOT followed by BatchNorm)
+// out[c] (+)= sum over n, y, x of src[n][coff+c]   (bias gradient of a conv that is NOT followed by BatchNorm).
+// grid (chunks, C): block partials are combined with fp32 atomics into out (zeroed first unless accumulating).
 __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const float* __restrict__ src, int ctot, int coff, int N,
-                                                             int HW, float* __restrict__ out, int accumulate) {
+                                                             int HW, float* __restrict__ out) {
     __shared__ float lds[kBlock / kWave];
-    const int c = blockIdx.x;
+    const int c = blockIdx.y;
     float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float* s = src + ((size_t)n * ctot + coff + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += kBlock) acc += s[i];
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+        acc += src[((size_t)n * ctot + coff + c) * HW + p];
     }
     acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + acc : acc;
+    if (threadIdx.x == 0) atomic_add_f32(&out[c], acc);
 }
 
 static inline dim3 plane_grid(int HW, int C, int N, int per_thread) {
@@ -316,8 +318,11 @@ int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_cto
 int cd_channel_sum(const float* src, int ctot, int coff, int C, int N, int H, int W, float* out, int accumulate,
                    void* stream) {
     CD_ARGCHK(src && out && C > 0 && coff + C <= ctot);
-    hipLaunchKernelGGL(cd::channel_sum_kernel, dim3(C), dim3(cd::kBlock), 0, (hipStream_t)stream, src, ctot, coff, N, H * W, out,
-                       accumulate);
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream) != hipSuccess) return CD_ERR_LAUNCH;
+    long long chunks = ((long long)N * H * W + cd::kBlock * 16 - 1) / (cd::kBlock * 16);
+    if (chunks > 256) chunks = 256;
+    hipLaunchKernelGGL(cd::channel_sum_kernel, dim3((unsigned)chunks, C), dim3(cd::kBlock), 0, (hipStream_t)stream, src, ctot,
+                       coff, N, H * W, out);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -153,6 +153,10 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                   float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                   int N, int H, int W, int ks, void* stream);
 
+/* Test hook: force the output-tile height (4, 8, 16; 0 = automatic) of cd_conv2d_fwd so every
+ * template instantiation can be parity-tested at small sizes. */
+int cd_debug_force_conv_tile_rows(int ty);
+
 /* Weight gradient dw[Cout][Cin][ks][ks] (=, or += when accumulate) of the same convolution:
  * sum over n,y,x of dy[n][co][y][x] * act(x)[n][ci][y+ky-P][x+kx-P]  (act as in cd_conv2d_fwd).
  * workspace: cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) floats, zeroed inside unless bit 1 of

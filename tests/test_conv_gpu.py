@@ -27,17 +27,23 @@ def _ref(x, w, b, ks):
     return torch.nn.functional.conv2d(x.double(), w.double(), b.double() if b is not None else None, padding=(ks - 1) // 2)
 
 
+@pytest.mark.parametrize("ty", [0, 4, 8, 16])
 @pytest.mark.parametrize("N,Cin,Cout,H,W,ks", CASES)
-def test_conv_fwd_matches_torch(N, Cin, Cout, H, W, ks):
+def test_conv_fwd_matches_torch(N, Cin, Cout, H, W, ks, ty):
     import torch
+    from consistent_depth_amd import _native
     from consistent_depth_amd.ops import conv
+    _native.lib().cd_debug_force_conv_tile_rows(ty)
     g = torch.Generator().manual_seed(ks * 1000 + Cin + Cout)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks)
     b = torch.randn(Cout, generator=g)
     ref = _ref(x, w, b, ks)
     pk = conv.pack_weights(w.cuda())
-    y = conv.conv2d(x.cuda(), pk, Cin, Cout, ks, bias=b.cuda())
+    try:
+        y = conv.conv2d(x.cuda(), pk, Cin, Cout, ks, bias=b.cuda())
+    finally:
+        _native.lib().cd_debug_force_conv_tile_rows(0)
     err = (y.cpu().double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
