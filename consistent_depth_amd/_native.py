@@ -34,6 +34,7 @@ SIGNATURES = {
     "cd_sample_bilinear_border": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "cd_conv2d_packed_weight_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "cd_conv2d_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "cd_conv2d_pack_weights_table": (c_i, [c_p, c_i, c_p]),
     "cd_conv2d_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_debug_force_conv_tile_rows": (c_i, [c_i]),
     "cd_conv2d_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),

@@ -283,12 +283,47 @@ static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const 
 }
 
 // number of 16-wide output-channel tiles a block handles for a given (k, Cout)
-static inline int pick_co_tiles(int ks, int cout) {
+__host__ __device__ static inline int pick_co_tiles(int ks, int cout) {
     const int need = (cout + 15) / 16;
     int cap = (ks >= 11) ? 1 : 4;  // LDS: 121 taps x CI x COBP floats must leave room for >= 2 blocks per CU
     int t = need < cap ? need : cap;
     if (t == 3) t = 4;
     return t < 1 ? 1 : t;
+}
+
+// All filters of a network in ONE launch: blockIdx.y selects the descriptor, blockIdx.x grid-strides the elements
+// of its destination.  Several descriptors may target ONE packed filter (a fused convolution whose output --
+// or, for the transposed/dgrad form, input -- channels are the concatenation of several nn.Conv2d weights):
+// each writes only the (oc, ic) range it owns; padding elements are zeroed once when the arena is allocated.
+struct PackDesc {
+    const float* w; float* packed;
+    int Cout, Cin, ks, transposed;   // the source tensor w[Cout][Cin][ks][ks] and which form to pack
+    int OC, IC, oc_off, ic_off;      // logical channels of the (fused) packed conv and this source's offset in it
+};
+static_assert(sizeof(PackDesc) == 48, "cd_pack_desc layout");
+
+__global__ void pack_weights_table_kernel(const PackDesc* __restrict__ table) {
+    const PackDesc d = table[blockIdx.y];
+    const int KS = d.ks, OC = d.OC, IC = d.IC;
+    const int oc_n = d.transposed ? d.Cin : d.Cout, ic_n = d.transposed ? d.Cout : d.Cin;  // this source's extent
+    const int cot = pick_co_tiles(KS, OC), cob = cot * 16, cobp = co_stride_padded(cob);
+    const int ci_chunk = KS >= 7 ? 4 : (KS == 1 ? 32 : 8), taps = KS * KS;
+    const int n_chunks = (IC + ci_chunk - 1) / ci_chunk, groups = (OC + cob - 1) / cob;
+    const size_t total = (size_t)groups * n_chunks * taps * ci_chunk * cobp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int j = (int)(r % cobp); r /= cobp;
+        const int cc = (int)(r % ci_chunk); r /= ci_chunk;
+        const int tap = (int)(r % taps); r /= taps;
+        const int chunk = (int)(r % n_chunks); r /= n_chunks;
+        const int grp = (int)r;
+        if (j >= cob) continue;
+        const int oc = grp * cob + j - d.oc_off, ic = chunk * ci_chunk + cc - d.ic_off;
+        if ((unsigned)oc >= (unsigned)oc_n || (unsigned)ic >= (unsigned)ic_n) continue;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        d.packed[i] = d.transposed ? d.w[(((size_t)ic * d.Cin + oc) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)]
+                                   : d.w[(((size_t)oc * d.Cin + ic) * KS + ky) * KS + kx];
+    }
 }
 
 }  // namespace cd
@@ -322,6 +357,13 @@ int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transp
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(cd::pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ks,
                        ci_chunk, cob, cobp, transposed, packed, total);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream) {
+    if (!table_dev || n <= 0 || n > 65535) return CD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cd::pack_weights_table_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const cd::PackDesc*)table_dev);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

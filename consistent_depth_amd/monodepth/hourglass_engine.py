@@ -12,6 +12,10 @@ parameter / state_dict container) on the gfx950 kernels behind the C ABI:
     backward            cd_bn_relu_bwd, cd_conv2d_wgrad, cd_conv2d_fwd on transposed filters (dgrad),
                         cd_avgpool2_bwd, cd_upsample2x_bwd, cd_add_slice, cd_channel_sum
 
+Inception layout: every inception owns ONE buffer [m1|m2|m3 | b0|o1|o2|o3] (mid activations first, then
+the concat output), so its four branch-entry 1x1 convolutions are a single convolution over a contiguous
+channel range: X is read once in the forward and dX written once in the backward (PointwiseGroup).
+
 No autograd tape is built for the network: the backward pass is the explicit reverse walk of the plan.
 Towards PyTorch the engine is ONE autograd node: forward(x) returns pred_d attached to the graph, and
 loss.backward() calls `_backward`, which writes every parameter gradient into p.grad (views of the
@@ -63,11 +67,7 @@ class ConvUnit:
         self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None,
                        scale=bn_mod.weight if affine else None, shift=bn_mod.bias if affine else None, needs_grad=False)
         self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
-        self.pk = self.pkT = None
-
-    def pack(self, need_dgrad):
-        self.pk = C.pack_weights(self.conv.weight)
-        self.pkT = C.pack_weights(self.conv.weight, transposed=True) if need_dgrad else None
+        self.pk, self.pkT = eng.packed(conv_mod)
 
     def forward(self, training):
         s = self.src
@@ -104,6 +104,61 @@ class ConvUnit:
                      accumulate=s.grad_mode())
 
 
+class _Member:
+    """One of the fused 1x1 convolutions (keeps its own parameters, BN module and weight-gradient workspace)."""
+
+    def __init__(self, conv_mod, bn_mod, coff):
+        self.conv, self.bn, self.coff = conv_mod, bn_mod, coff
+        self.ks, self.cin, self.cout = 1, conv_mod.in_channels, conv_mod.out_channels
+        self.wgrad_ws = self.sums = None
+
+
+class PointwiseGroup:
+    """The four branch-entry 1x1 convolutions of an inception as ONE convolution X -> P[:, 0:ctot]."""
+
+    def __init__(self, eng, members, src: Act, P, Pg, stats, mean_invstd, filt, filtT):
+        self.eng, self.members, self.src, self.P, self.Pg, self.stats, self.mi = eng, members, src, P, Pg, stats, mean_invstd
+        self.ctot = sum(m.cout for m in members)
+        self.cin = members[0].cin
+        self._filt, self._filtT = filt, filtT
+        self._bias = torch.empty(self.ctot, device=P.device)
+        self._bias_versions = None
+
+    def _fused_bias(self):
+        v = tuple((m.conv.bias.data_ptr(), m.conv.bias._version) for m in self.members)
+        if v != self._bias_versions:
+            torch.cat([m.conv.bias.detach() for m in self.members], out=self._bias)
+            self._bias_versions = v
+        return self._bias
+
+    def forward(self, training):
+        s, pk = self.src, self.eng._pack.view(self._filt)
+        C.conv2d(s.buf, pk, self.cin, self.ctot, 1, bias=self._fused_bias(), x_coff=s.coff, out=self.P, y_coff=0,
+                 in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, stats=self.stats.view(-1) if training else None)
+        cnt = float(self.P.shape[0] * self.P.shape[2] * self.P.shape[3])
+        for m in self.members:
+            if training:
+                L.bn_normalize(self.P, m.coff, m.cout, self.stats, self.mi, BN_EPS, m.bn.running_mean, m.bn.running_var,
+                               BN_MOMENTUM)
+            else:
+                rm, rv = m.bn.running_mean.double(), m.bn.running_var.double()
+                self.stats[m.coff:m.coff + m.cout, 0] = rm * cnt
+                self.stats[m.coff:m.coff + m.cout, 1] = (rv + rm * rm) * cnt
+                L.bn_normalize(self.P, m.coff, m.cout, self.stats, self.mi, BN_EPS)
+
+    def backward(self):
+        s = self.src
+        sums = self.members[0].sums  # the members' sums are consecutive views of one arena
+        sums = torch.as_strided(sums, (2 * self.ctot,), (1,))
+        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, sums, sums_prezeroed=True)
+        for m in self.members:
+            C.conv2d_wgrad(s.buf, self.Pg, m.cin, m.cout, 1, _grad_of(m.conv.weight), m.wgrad_ws, x_coff=s.coff,
+                           dy_coff=m.coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
+        if s.gbuf is not None:
+            C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
+                     accumulate=s.grad_mode())
+
+
 def _grad_of(p: torch.nn.Parameter) -> torch.Tensor:
     if p.grad is None:
         p.grad = torch.zeros_like(p)
@@ -123,6 +178,31 @@ class HourglassEngine:
         self.net = net
         self.device = next(net.parameters()).device
         self._plans = {}
+        # every filter (forward + flipped/transposed dgrad twin) is re-packed by ONE launch per forward
+        self._pack = C.PackTable(self.device)
+        self._pack_index = {}
+        self._group_filters = {}
+        grouped = set()
+        for inc in net.modules():
+            if isinstance(inc, HG.Inception):
+                entry = [br[0] for br in list(inc.convs)[1:]] + [inc.convs[0][0]]   # [m1, m2, m3, b0]
+                ctot, cin = sum(c.out_channels for c in entry), entry[0].in_channels
+                f, fT = self._pack.new_filter(ctot, cin, 1), self._pack.new_filter(cin, ctot, 1)
+                off = 0
+                for c in entry:
+                    self._pack.source(f, c.weight, False, oc_off=off)    # forward: concatenated output channels
+                    self._pack.source(fT, c.weight, True, ic_off=off)    # dgrad: concatenated input channels
+                    off += c.out_channels
+                    grouped.add(id(c))
+                self._group_filters[id(inc)] = (f, fT)
+        for m in net.modules():
+            if isinstance(m, torch.nn.Conv2d) and m is not net.uncertainty_layer[0] and id(m) not in grouped:
+                self._pack_index[id(m)] = (self._pack.add(m.weight, False), self._pack.add(m.weight, True))
+        self._pack.build()
+
+    def packed(self, conv_mod):
+        i, j = self._pack_index[id(conv_mod)]
+        return self._pack.view(i), self._pack.view(j)
 
     # ------------------------------------------------------------------ plan construction
     def _new(self, N, Ch, H, W):
@@ -130,28 +210,34 @@ class HourglassEngine:
 
     def _inception(self, plan, mod: HG.Inception, x: Act, N, H, W) -> Act:
         c_in, cfg = HG.INCEPTION[mod.kind]
-        outs = [cfg[0][0]] + [c[2] for c in cfg[1:]]
+        a0 = cfg[0][0]
+        outs = [a0] + [c[2] for c in cfg[1:]]
         mids = [c[1] for c in cfg[1:]]
-        obuf, mbuf = self._new(N, sum(outs), H, W), self._new(N, sum(mids), H, W)
-        o_stats, m_stats = self._stats(plan, sum(outs)), self._stats(plan, sum(mids))
-        o_mi, m_mi = torch.zeros(sum(outs), 2, device=self.device), torch.zeros(sum(mids), 2, device=self.device)
-        o_g, m_g = torch.empty_like(obuf), torch.empty_like(mbuf)
-        units = []
-        br0 = mod.convs[0]
-        units.append((ConvUnit(self, br0[0], br0[1], x, obuf, 0, o_stats, o_mi), o_g, 0))
-        ooff, moff = outs[0], 0
+        M, Co = sum(mids), sum(outs)
+        P = self._new(N, M + Co, H, W)            # [m1|m2|m3 | b0|o1|o2|o3]
+        Pg = torch.empty_like(P)
+        stats = self._stats(plan, M + Co)
+        mi = torch.zeros(M + Co, 2, device=self.device)
+        # the fused entry convolution: output channels [m1|m2|m3|b0] = P[:, 0:M+a0]
+        members, moff = [], 0
         for i, br in enumerate(list(mod.convs)[1:]):
-            u1 = ConvUnit(self, br[0], br[1], x, mbuf, moff, m_stats, m_mi)
-            u1.out.gbuf = m_g
-            u2 = ConvUnit(self, br[3], br[4], u1.out, obuf, ooff, o_stats, o_mi)
-            units.append((u1, m_g, moff))
-            units.append((u2, o_g, ooff))
+            members.append(_Member(br[0], br[1], moff))
+            moff += mids[i]
+        members.append(_Member(mod.convs[0][0], mod.convs[0][1], M))
+        filt, filtT = self._group_filters[id(mod)]
+        group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT)
+        # the k x k convolutions: P[:, m_i] -> P[:, M + a0 + ...]
+        units, ooff, moff = [], M + a0, 0
+        for i, br in enumerate(list(mod.convs)[1:]):
+            mid = Act(P, moff, mids[i], relu=True, needs_grad=False)
+            mid.gbuf = Pg
+            units.append((ConvUnit(self, br[3], br[4], mid, P, ooff, stats, mi), Pg, ooff))
             ooff += outs[i + 1]
             moff += mids[i]
-        out = Act(obuf, 0, sum(outs), relu=True, needs_grad=False)
-        out.gbuf = o_g
-        plan["steps"].append(_Node("inception", units=units, out=out, src=x))
-        plan["convs"] += [u for u, _, _ in units]
+        out = Act(P, M, Co, relu=True, needs_grad=False)
+        out.gbuf = Pg
+        plan["steps"].append(_Node("inception", group=group, units=units, out=out, src=x))
+        plan["convs"] += members + [u for u, _, _ in units]
         return out
 
     def _sequence(self, plan, seq, x: Act, N, H, W, tail_add: Optional[Act] = None):
@@ -245,12 +331,12 @@ class HourglassEngine:
         plan["x"].copy_(x)
         training = self.net.training
         plan["stats_arena"].zero_()
-        for u in plan["convs"]:
-            u.pack(need_grad and u.src.gbuf is not None)
+        self._pack.run()
         for step in plan["steps"]:
             if step.kind == "conv":
                 step.unit.forward(training)
             elif step.kind == "inception":
+                step.group.forward(training)
                 for u, _, _ in step.units:
                     u.forward(training)
             elif step.kind == "pool":
@@ -276,9 +362,11 @@ class HourglassEngine:
             if step.kind == "conv":
                 step.unit.backward(step.gbuf, step.g_coff)
             elif step.kind == "inception":
-                # the concat output's gradient is complete; walk the branches back to front
+                # the concat output's gradient is complete: k x k convolutions first (they fill the gradient of
+                # the mid activations), then the fused entry convolution
                 for u, gbuf, g_coff in reversed(step.units):
                     u.backward(gbuf, g_coff)
+                step.group.backward()
             elif step.kind == "pool":
                 s = step.src
                 L.avgpool2_bwd(step.out.gbuf, 0, s.gbuf, s.coff, s.C, accumulate=s.grad_mode())

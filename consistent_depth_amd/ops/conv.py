@@ -61,3 +61,68 @@ def conv2d_wgrad(x, dy, Cin, Cout, ks, dw, workspace, x_coff=0, dy_coff=0, in_sc
         _native.dev_ptr(workspace, "workspace"), N, H, W, ks, _native.stream_ptr(x.device))
     _native.check(rc, "cd_conv2d_wgrad")
     return dw
+
+
+class PackTable:
+    """All filters of a network packed by ONE kernel launch (cd_conv2d_pack_weights_table).
+
+    new_filter(OC, IC, ks) reserves a packed filter of the logical conv IC -> OC; source(filter, param,
+    transposed, oc_off, ic_off) registers a parameter that fills part of it (several parameters may be
+    concatenated into one fused filter); build() allocates one zeroed arena and the device descriptor table.
+    Parameters may be re-homed later (FlatAdam moves them into its flat buffer): run() re-checks the source
+    pointers and refreshes the table when they moved."""
+
+    _DT = [("w", "<u8"), ("packed", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("tr", "<i4"),
+           ("OC", "<i4"), ("IC", "<i4"), ("oc_off", "<i4"), ("ic_off", "<i4")]
+
+    def __init__(self, device):
+        self.device, self._filters, self._sources = device, [], []
+        self._arena = self._table = self._ptrs = None
+        self.views = []
+
+    def new_filter(self, OC: int, IC: int, ks: int) -> int:
+        n = _native.lib().cd_conv2d_packed_weight_floats(OC, IC, ks, 0)
+        self._filters.append((OC, IC, ks, n))
+        return len(self._filters) - 1
+
+    def source(self, filt: int, param: torch.nn.Parameter, transposed: bool, oc_off: int = 0, ic_off: int = 0):
+        self._sources.append((filt, param, bool(transposed), oc_off, ic_off))
+
+    def add(self, param: torch.nn.Parameter, transposed: bool) -> int:
+        """One parameter = one filter (forward form, or its dgrad twin)."""
+        Cout, Cin, k, _ = param.shape
+        f = self.new_filter(Cin if transposed else Cout, Cout if transposed else Cin, k)
+        self.source(f, param, transposed)
+        return f
+
+    def build(self):
+        total = sum((n + 63) // 64 * 64 for _, _, _, n in self._filters)
+        self._arena = torch.zeros(total, dtype=torch.float32, device=self.device)  # padding stays zero forever
+        self.views, off = [], 0
+        for _, _, _, n in self._filters:
+            self.views.append(self._arena[off:off + n])
+            off += (n + 63) // 64 * 64
+        self._refresh_table()
+        return self
+
+    def _refresh_table(self):
+        import numpy as np
+        tab = np.zeros(len(self._sources), np.dtype(self._DT))
+        for j, (f, p, tr, oo, io) in enumerate(self._sources):
+            if not (p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda):
+                raise RuntimeError("conv weights must be contiguous fp32 on the HIP device")
+            OC, IC, ks, _ = self._filters[f]
+            assert p.shape[2] == ks
+            tab[j] = (p.data_ptr(), self.views[f].data_ptr(), p.shape[0], p.shape[1], ks, int(tr), OC, IC, oo, io)
+        self._ptrs = [p.data_ptr() for _, p, _, _, _ in self._sources]
+        self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+
+    def view(self, index: int) -> torch.Tensor:
+        return self.views[index]
+
+    def run(self):
+        if any(p.data_ptr() != q for (_, p, _, _, _), q in zip(self._sources, self._ptrs)):
+            self._refresh_table()
+        rc = _native.lib().cd_conv2d_pack_weights_table(self._table.data_ptr(), len(self._sources),
+                                                        _native.stream_ptr(self.device))
+        _native.check(rc, "cd_conv2d_pack_weights_table")

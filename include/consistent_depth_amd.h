@@ -141,6 +141,19 @@ size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed)
 int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transposed, float* packed,
                            void* stream);
 
+/* Pack many filters in ONE launch: table_dev = device array of n cd_pack_desc (48 bytes each).
+ * Several descriptors may target one `packed` buffer: a fused convolution whose output channels (forward
+ * form) or input channels (transposed form) concatenate several weights -- OC/IC are the logical channel
+ * counts of the fused conv (they size the layout: cd_conv2d_packed_weight_floats(OC, IC, ks, 0)), oc_off/ic_off
+ * this source's position.  Padding elements are never written: zero the buffer once. */
+typedef struct cd_pack_desc {
+    const float* w;   /* [Cout][Cin][ks][ks] */
+    float* packed;
+    int Cout, Cin, ks, transposed;
+    int OC, IC, oc_off, ic_off;
+} cd_pack_desc;
+int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream);
+
 /* y[:, y_coff : y_coff+Cout] = conv2d(act(x[:, x_coff : x_coff+Cin]), w) + bias, stride 1, zero
  * padding (ks-1)/2, ks in {1,3,5,7,11}, on the fp32 matrix cores (exact fp32).
  *   act(v) = relu?(v * in_scale[c] + in_shift[c])   when in_scale/in_shift are given (the producer's
