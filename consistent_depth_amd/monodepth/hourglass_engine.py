@@ -120,6 +120,9 @@ class PointwiseGroup:
         self.eng, self.members, self.src, self.P, self.Pg, self.stats, self.mi = eng, members, src, P, Pg, stats, mean_invstd
         self.ctot = sum(m.cout for m in members)
         self.cin = members[0].cin
+        self.cout, self.ks = self.ctot, 1          # the group is ONE unit for the arenas (wgrad workspace, BN sums)
+        self.wgrad_ws = self.sums = None
+        self._dw = torch.empty(self.ctot, self.cin, 1, 1, device=P.device)   # fused weight gradient [m1;m2;m3;b0]
         self._filt, self._filtT = filt, filtT
         self._bias = torch.empty(self.ctot, device=P.device)
         self._bias_versions = None
@@ -148,12 +151,12 @@ class PointwiseGroup:
 
     def backward(self):
         s = self.src
-        sums = self.members[0].sums  # the members' sums are consecutive views of one arena
-        sums = torch.as_strided(sums, (2 * self.ctot,), (1,))
-        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, sums, sums_prezeroed=True)
+        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True)
+        # ONE weight-gradient GEMM for the four filters (X is read once), then split the rows
+        C.conv2d_wgrad(s.buf, self.Pg, self.cin, self.ctot, 1, self._dw, self.wgrad_ws, x_coff=s.coff, dy_coff=0,
+                       in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
         for m in self.members:
-            C.conv2d_wgrad(s.buf, self.Pg, m.cin, m.cout, 1, _grad_of(m.conv.weight), m.wgrad_ws, x_coff=s.coff,
-                           dy_coff=m.coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
+            _grad_of(m.conv.weight).copy_(self._dw[m.coff:m.coff + m.cout])
         if s.gbuf is not None:
             C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode())
@@ -237,7 +240,7 @@ class HourglassEngine:
         out = Act(P, M, Co, relu=True, needs_grad=False)
         out.gbuf = Pg
         plan["steps"].append(_Node("inception", group=group, units=units, out=out, src=x))
-        plan["convs"] += members + [u for u, _, _ in units]
+        plan["convs"] += [group] + [u for u, _, _ in units]
         return out
 
     def _sequence(self, plan, seq, x: Act, N, H, W, tail_add: Optional[Act] = None):
