@@ -207,8 +207,9 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
     const int tiles_x = (W + WG_TX - 1) / WG_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
     const int cogs = (Cout + COB - 1) / COB, cigs = (Cin + CIB - 1) / CIB;
     const int items = N * tiles_x * tiles_y;
-    // enough blocks to fill the chip (~3 per CU), few enough that the atomic flush stays small
-    int splits = (256 * 3 + cogs * cigs - 1) / (cogs * cigs);
+    // enough blocks to fill the chip (~2 per CU: the LDS tiles allow 2 resident blocks), few enough that the
+    // atomic flush of the partial sums (one per block, all splits hit the same addresses) stays small
+    int splits = (256 * 2 + cogs * cigs - 1) / (cogs * cigs);
     if (splits > items) splits = items;
     if (splits < 1) splits = 1;
     const size_t lds = sizeof(float) * ((size_t)COB * Cfg::PS_DY + (size_t)CIB * Cfg::PS_IN);

@@ -16,6 +16,11 @@ Inception layout: every inception owns ONE buffer [m1|m2|m3 | b0|o1|o2|o3] (mid 
 the concat output), so its four branch-entry 1x1 convolutions are a single convolution over a contiguous
 channel range: X is read once in the forward and dX written once in the backward (PointwiseGroup).
 
+Streams: the three k x k branches of an inception are independent, in the forward and in the backward
+pass; they run on three side HIP streams (fork/join with events around every inception), which keeps the
+256 CUs busy on the deep 96x56 ... 24x14 levels where a single convolution has too few workgroups, and
+overlaps the memory-bound BatchNorm kernels of one branch with the MFMA-bound convolutions of another.
+
 No autograd tape is built for the network: the backward pass is the explicit reverse walk of the plan.
 Towards PyTorch the engine is ONE autograd node: forward(x) returns pred_d attached to the graph, and
 loss.backward() calls `_backward`, which writes every parameter gradient into p.grad (views of the
@@ -202,6 +207,25 @@ class HourglassEngine:
             if isinstance(m, torch.nn.Conv2d) and m is not net.uncertainty_layer[0] and id(m) not in grouped:
                 self._pack_index[id(m)] = (self._pack.add(m.weight, False), self._pack.add(m.weight, True))
         self._pack.build()
+        self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        self.use_streams = True
+
+    def _fork_join(self, jobs):
+        """Run the callables of `jobs` concurrently on the side streams (fork from / join into the current one)."""
+        if not self.use_streams or len(jobs) < 2:
+            for j in jobs:
+                j()
+            return
+        main = torch.cuda.current_stream(self.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for j, st in zip(jobs, self._side):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                j()
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
 
     def packed(self, conv_mod):
         i, j = self._pack_index[id(conv_mod)]
@@ -340,8 +364,7 @@ class HourglassEngine:
                 step.unit.forward(training)
             elif step.kind == "inception":
                 step.group.forward(training)
-                for u, _, _ in step.units:
-                    u.forward(training)
+                self._fork_join([(lambda u=u: u.forward(training)) for u, _, _ in step.units])
             elif step.kind == "pool":
                 s = step.src
                 L.avgpool2_fwd(s.buf, s.coff, s.C, step.out.buf, 0, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
@@ -367,8 +390,7 @@ class HourglassEngine:
             elif step.kind == "inception":
                 # the concat output's gradient is complete: k x k convolutions first (they fill the gradient of
                 # the mid activations), then the fused entry convolution
-                for u, gbuf, g_coff in reversed(step.units):
-                    u.backward(gbuf, g_coff)
+                self._fork_join([(lambda u=u, g=gbuf, o=g_coff: u.backward(g, o)) for u, gbuf, g_coff in step.units])
                 step.group.backward()
             elif step.kind == "pool":
                 s = step.src
