@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=4)
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=224)
-    ap.add_argument("--backend", default=os.environ.get("CD_AMD_MC_BACKEND", "torch"), choices=["torch", "hip"])
+    ap.add_argument("--backend", default=os.environ.get("CD_AMD_MC_BACKEND", "hip"), choices=["torch", "hip"],
+                    help="convolutions: hip = hand-written gfx950 engine (BASELINE configs[2]); "
+                         "torch = PyTorch-ROCm/MIOpen (configs[1], ~2 min of MIOpen start-up)")
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic batches cycled through")
     ap.add_argument("--loss-batch", type=int, default=256, help="pairs per launch of the roofline micro-benchmark")
     ap.add_argument("--loss-iters", type=int, default=20)
@@ -71,8 +73,11 @@ def make_pool(n, B, H, W, seed, device):
         t = lambda a: torch.tensor(a, device=device)  # noqa: E731
         meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
                 "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
-        from consistent_depth_amd.loss.consistency_loss import mask_sums
-        meta["geometry_consistency"]["mask_sums"] = mask_sums(*meta["geometry_consistency"]["masks"])
+        # dataset constants, cached per pair exactly like loaders/pair_store.py does
+        from consistent_depth_amd.loss.consistency_loss import mask_sums, tile_windows
+        geom = meta["geometry_consistency"]
+        geom["mask_sums"] = mask_sums(*geom["masks"])
+        geom["tile_windows"] = tile_windows(geom["flows"], geom["masks"])
         pool.append((t(images), meta, b, images))
     return pool
 
@@ -98,14 +103,16 @@ def loss_microbench(lib, B, H, W, iters, device):
     depth += 0.01 * torch.randn_like(depth)
     flows, masks = [t(f) for f in base["flows"]], [t(m) for m in base["masks"]]
     intr, extr = t(base["intrinsics"]), t(base["extrinsics"])
-    msum = CL.mask_sums(masks[0], masks[1])
+    msum, twin = CL.mask_sums(masks[0], masks[1]), CL.tile_windows(flows, masks)
     depth.requires_grad_(True)
+    call = lambda: CL.consistency_loss(depth, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=CL.DEPTH_EXP,  # noqa: E731
+                                       tile_windows=twin)
     for _ in range(2):
-        CL.consistency_loss(depth, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=CL.DEPTH_EXP)
+        call()
     torch.cuda.synchronize()
     assert lib.cd_profile_begin(iters) == 0
     for _ in range(iters):
-        CL.consistency_loss(depth, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=CL.DEPTH_EXP)
+        call()
     torch.cuda.synchronize()
     ms, _ = profile_collect(lib, iters)
     return ms
@@ -175,7 +182,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"mc hourglass (random init, seed 0) test-time fine-tuning step, {H}x{W}, "
-                               f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{2 if args.backend == 'hip' else 1}])",
+                               f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{2 if args.backend == 'hip' else 1}]: "
+                               + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"),
                    "conv_backend": args.backend, "global_batch": B * world, "parallelism": f"dp{world}",
                    "last_loss": float(last_loss.item())},
     }
@@ -185,7 +193,7 @@ def main():
         in_step_ms = float(np.mean(ms_step)) if len(ms_step) else None
         if in_step_ms:
             ach = LOSS_BYTES_PER_PAIR_PX * px * B / (in_step_ms * 1e-3) / 1e9
-            out["roofline_in_step"] = {"kernel": "loss_main_kernel", "bound": "hbm", "achieved": round(ach, 1),
+            out["roofline_in_step"] = {"kernel": "loss_owner_kernel", "bound": "hbm", "achieved": round(ach, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                        "traffic": None, "launch_pairs": B, "avg_ms": round(in_step_ms, 5),
                                        "note": "13.8 MB per launch: cache resident, launch-latency bound"}
@@ -194,7 +202,7 @@ def main():
             ms = loss_microbench(lib, args.loss_batch, H, W, args.loss_iters, device)
             avg = float(np.mean(ms))
             ach = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch / (avg * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "loss_main_kernel", "bound": "hbm", "achieved": round(ach, 1),
+            out["roofline"] = {"kernel": "loss_owner_kernel", "bound": "hbm", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": None, "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}

@@ -10,8 +10,8 @@ Differences, all forced by the environment and stated here:
   * two execution back ends for the same parameters:
       backend="torch": convolutions through PyTorch-ROCm/MIOpen (BASELINE config 2),
       backend="hip":   the hand-written gfx950 hourglass engine (BASELINE config 3);
-    selected by the constructor argument or $CD_AMD_MC_BACKEND (default "torch" until the
-    HIP engine covers every layer).
+    selected by the constructor argument or $CD_AMD_MC_BACKEND (default "hip": every layer of the
+    hourglass runs on the hand-written engine, forward and backward).
 """
 from __future__ import annotations
 
@@ -41,7 +41,7 @@ class MannequinChallengeModel(DepthModel):
 
     def __init__(self, backend: str = None, seed: int = DEFAULT_SEED, device=None):
         super().__init__()
-        self.backend = backend or os.environ.get("CD_AMD_MC_BACKEND", "torch")
+        self.backend = backend or os.environ.get("CD_AMD_MC_BACKEND", "hip")
         if self.backend not in ("torch", "hip"):
             raise ValueError(f"unknown mc backend '{self.backend}'")
         self.device = torch.device(device) if device is not None else _device()

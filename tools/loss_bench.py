@@ -44,8 +44,9 @@ def main():
         x = (x + 0.01 * torch.randn_like(x)).requires_grad_(not args.fwd_only)
         flows, masks = [t(f) for f in base["flows"]], [t(m) for m in base["masks"]]
         intr, extr = t(base["intrinsics"]), t(base["extrinsics"])
-        msum = CL.mask_sums(masks[0], masks[1])
-        call = lambda: CL.consistency_loss(x, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=args.mode)  # noqa: E731
+        msum, twin = CL.mask_sums(masks[0], masks[1]), CL.tile_windows(flows, masks)  # dataset constants, cached
+        call = lambda: CL.consistency_loss(x, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=args.mode,  # noqa: E731
+                                           tile_windows=None if args.fwd_only else twin)
         for _ in range(3):
             call()
         torch.cuda.synchronize()
