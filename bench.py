@@ -41,6 +41,18 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss-microbench", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-timeout", type=int, default=150, help="seconds the CPU-baseline subprocess may take")
     ap.add_argument("--miopen-find", action="store_true",
                     help="torch backend only: let MIOpen benchmark-search every conv (minutes of start-up)")
     return ap.parse_args()
@@ -207,17 +220,33 @@ def main():
                                "traffic": None, "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
         if world == 1 and not args.no_cpu_baseline:
+            # the reference step restated on the host (oracle/cpu_step.py), in a bounded subprocess so a slow
+            # host can never stall the benchmark: 1 warm-up + --cpu-steps timed steps of the same BS4 workload
             log("cpu baseline")
-            from oracle import cpu_step  # checker only: the CPU restatement of the reference step
-            cores = os.cpu_count()
-            torch.set_num_threads(cores)
+            import pickle
+            import subprocess
+            import tempfile
+            cores = usable_cores()
             _, _, b_np, images_np = pool[0]
-            sd = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
-            sec = cpu_step.time_steps(sd, images_np, b_np, n_steps=args.cpu_steps, warmup=1, threads=cores)
-            out["cpu_baseline"] = {"value": round(B / sec, 4), "unit": "frame-pairs/s", "cores": cores,
-                                   "kind": "port",
-                                   "sample": f"{args.cpu_steps} full steps (+1 warm-up) of the same BS{B} {H}x{W} workload, "
-                                             f"torch CPU fp32 hourglass fwd+bwd + C oracle loss + torch Adam, {sec:.2f} s/step"}
+            with tempfile.TemporaryDirectory() as td:
+                blob = os.path.join(td, "in.pkl")
+                with open(blob, "wb") as f:
+                    pickle.dump({"state": {k: v.detach().cpu() for k, v in model.netG.state_dict().items()},
+                                 "images": images_np, "batch": b_np, "steps": args.cpu_steps, "threads": cores}, f)
+                code = ("import pickle,sys,torch;sys.path.insert(0,%r);from oracle import cpu_step;"
+                        "d=pickle.load(open(%r,'rb'));"
+                        "print('SEC',cpu_step.time_steps(d['state'],d['images'],d['batch'],n_steps=d['steps'],warmup=1,threads=d['threads']))"
+                        % (REPO, blob))
+                env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+                try:
+                    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+                    sec = float([ln for ln in r.stdout.splitlines() if ln.startswith("SEC")][-1].split()[1])
+                    out["cpu_baseline"] = {"value": round(B / sec, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                                           "sample": f"{args.cpu_steps} full steps (+1 warm-up) of the same BS{B} {H}x{W} workload: torch CPU fp32 "
+                                                     f"hourglass fwd+bwd (train-mode BN) + C-oracle loss + torch Adam, {sec:.2f} s/step, {cores} threads"}
+                except (subprocess.TimeoutExpired, IndexError, ValueError) as e:
+                    out["cpu_baseline"] = {"value": None, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                                           "sample": f"not completed within {args.cpu_timeout}s ({type(e).__name__})"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,123 @@
+"""MiDaS v2 network (config 5 backbone), restated.
+
+The reference imports it from an un-vendored submodule (`monodepth/midas_v2/midas_net.py`,
+/root/reference/.gitmodules:7-9; call sites monodepth/midas_v2_model.py:8,29,61) and its weights come from
+torch.hub (unreachable).  Restated from the published intel-isl/MiDaS v2 `MidasNet`:
+ResNeXt-101 32x8d (WSL) encoder -- Bottleneck blocks [3, 4, 23, 3], groups 32, width 8 -- whose four stage
+outputs (256/512/1024/2048 ch at 1/4..1/32) are reduced to 256 features by 3x3 convs (`scratch.layerN_rn`),
+fused top-down by four FeatureFusionBlocks (two ResidualConvUnits + bilinear x2, align_corners=True) and
+decoded by conv3x3(256->128) -> x2 -> conv3x3(128->32) -> ReLU -> conv1x1(32->1) -> ReLU.
+Output: inverse depth (N, H, W).  State-dict keys follow upstream (`pretrained.layer1.0...`,
+`scratch.refinenet4.resConfUnit1.conv1.weight`, `scratch.output_conv.0.weight`): a real checkpoint loads by
+key.  "Parity unpinned" (no source, no weights, no golden vectors in /root/reference); ~105 M parameters.
+
+Convolutions of this backbone run through PyTorch-ROCm (grouped 3x3 convs and strided stems are outside the
+stride-1 MFMA engine built for the hourglass); loss, optimiser and data parallelism are the HIP/RCCL path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=32, base_width=8):
+        super().__init__()
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * self.expansion, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+def _stage(inplanes, planes, blocks, stride):
+    down = None
+    if stride != 1 or inplanes != planes * 4:
+        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, down)]
+    layers += [Bottleneck(planes * 4, planes) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+class _Encoder(nn.Module):
+    """`pretrained` of upstream: layer1 = stem + resnet.layer1, layer2..4 = resnet.layer2..4."""
+
+    def __init__(self):
+        super().__init__()
+        stem = [nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)]
+        self.layer1 = nn.Sequential(*stem, _stage(64, 64, 3, 1))
+        self.layer2 = _stage(256, 128, 4, 2)
+        self.layer3 = _stage(512, 256, 23, 2)
+        self.layer4 = _stage(1024, 512, 3, 2)
+
+
+class ResidualConvUnit(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+
+    def forward(self, x):
+        out = self.conv1(F.relu(x))
+        out = self.conv2(F.relu(out))
+        return out + x
+
+
+class FeatureFusionBlock(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.resConfUnit1 = ResidualConvUnit(features)
+        self.resConfUnit2 = ResidualConvUnit(features)
+
+    def forward(self, *xs):
+        out = xs[0]
+        if len(xs) == 2:
+            out = out + self.resConfUnit1(xs[1])
+        out = self.resConfUnit2(out)
+        return F.interpolate(out, scale_factor=2, mode="bilinear", align_corners=True)
+
+
+class _Interpolate(nn.Module):
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+
+
+class MidasNet(nn.Module):
+    def __init__(self, path=None, features=256, non_negative=True):
+        super().__init__()
+        self.pretrained = _Encoder()
+        self.scratch = nn.Module()
+        for i, c in enumerate((256, 512, 1024, 2048), start=1):
+            setattr(self.scratch, f"layer{i}_rn", nn.Conv2d(c, features, 3, 1, 1, bias=False))
+        for i in (4, 3, 2, 1):
+            setattr(self.scratch, f"refinenet{i}", FeatureFusionBlock(features))
+        self.scratch.output_conv = nn.Sequential(
+            nn.Conv2d(features, 128, 3, 1, 1), _Interpolate(), nn.Conv2d(128, 32, 3, 1, 1), nn.ReLU(True),
+            nn.Conv2d(32, 1, 1, 1, 0), nn.ReLU(True) if non_negative else nn.Identity())
+        if path:
+            self.load_state_dict(torch.load(path, map_location="cpu"))
+
+    def forward(self, x):
+        l1 = self.pretrained.layer1(x)
+        l2 = self.pretrained.layer2(l1)
+        l3 = self.pretrained.layer3(l2)
+        l4 = self.pretrained.layer4(l3)
+        p4 = self.scratch.refinenet4(self.scratch.layer4_rn(l4))
+        p3 = self.scratch.refinenet3(p4, self.scratch.layer3_rn(l3))
+        p2 = self.scratch.refinenet2(p3, self.scratch.layer2_rn(l2))
+        p1 = self.scratch.refinenet1(p2, self.scratch.layer1_rn(l1))
+        return torch.squeeze(self.scratch.output_conv(p1), dim=1)
