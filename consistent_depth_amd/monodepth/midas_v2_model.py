@@ -8,6 +8,8 @@ blocks, random init) -- "parity unpinned" for real checkpoints.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..loss.consistency_loss import DEPTH_RECIPROCAL
@@ -30,6 +32,17 @@ class MidasV2Model(DepthModel):
         torch.manual_seed(seed)
         self.model = MidasNet(non_negative=True)
         torch.random.set_rng_state(st)
+        weights = os.environ.get("CD_AMD_MIDAS_WEIGHTS", os.path.join("checkpoints", "midas_v2.pt"))
+        self.pretrained = os.path.isfile(weights)
+        if self.pretrained:
+            self.model.load_state_dict(torch.load(weights, map_location="cpu"))
+        else:
+            # random-init stand-in (no network for model-f46da743.pt): keep the predicted inverse depth strictly
+            # positive so depth = 1/out is finite -- the final ReLU would otherwise zero about half the pixels
+            with torch.no_grad():
+                head = self.model.scratch.output_conv[4]
+                head.weight.mul_(0.1)
+                head.bias.fill_(1.0)
         self.model.to(self.device)
         self.register_buffer("norm_mean", torch.tensor([0.485, 0.456, 0.406]).reshape(1, -1, 1, 1).to(self.device))
         self.register_buffer("norm_stdev", torch.tensor([0.229, 0.224, 0.225]).reshape(1, -1, 1, 1).to(self.device))
