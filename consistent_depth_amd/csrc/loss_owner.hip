@@ -37,7 +37,7 @@ namespace cd {
 
 constexpr int TW = 32, TH = 32;            // owned tile
 constexpr int WMAXW = 64, WMAXH = 64;      // cap of the staged window of the other frame
-constexpr int EXPAND = 3;                  // px margin around the predicted source window
+constexpr int EXPAND = 2;                  // px slack around the predicted source window (beyond it: overflow list)
 constexpr int MAXT_LDS = 512;              // window table of one plane kept in LDS up to this many tiles
 constexpr int SBW = TW + 2, SBH = TH + 2;  // own tile + 1 px halo
 
@@ -222,10 +222,12 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
         if (REPROJ) {
             const float mx = xf + fx, my = yf + fy;
             const float ex = (cj.cx_t - cj.fx_t * X * iZ) - mx, ey = (cj.cy_t + cj.fy_t * Y * iZ) - my;
-            const float e = __builtin_amdgcn_sqrtf(ex * ex + ey * ey);
+            const float e2 = ex * ex + ey * ey;
+            // one transcendental for both e and 1/e; e2 == 0 -> e = 0 and subgradient 0 (like torch.norm's backward)
+            const float ie = e2 > 0.f ? __builtin_amdgcn_rsqf(e2) : 0.f;
+            const float e = e2 * ie;
             acc_r += valid ? m * e : 0.f;  // lanes outside a partial tile carry garbage
             const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
-            const float ie = e > 0.f ? __builtin_amdgcn_rcpf(e) : 0.f;
             g += cj.gr * m * (ex * dpx + ey * dpy) * ie;
         }
         const Taps t = tap_coords(xf, yf, fx, fy, cj.sx, cj.sy, W, H);
