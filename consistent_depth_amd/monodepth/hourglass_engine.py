@@ -207,35 +207,72 @@ class HourglassEngine:
             if isinstance(m, torch.nn.Conv2d) and m is not net.uncertainty_layer[0] and id(m) not in grouped:
                 self._pack_index[id(m)] = (self._pack.add(m.weight, False), self._pack.add(m.weight, True))
         self._pack.build()
-        self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        # streams: one per Channels level for its full-resolution side, and three branch streams per parent stream
         self.use_streams = True
-
-    def _fork_join(self, jobs):
-        """Run the callables of `jobs` concurrently on the side streams (fork from / join into the current one)."""
-        if not self.use_streams or len(jobs) < 2:
-            for j in jobs:
-                j()
-            return
-        main = torch.cuda.current_stream(self.device)
-        fork = torch.cuda.Event()
-        fork.record(main)
-        for j, st in zip(jobs, self._side):
-            st.wait_event(fork)
-            with torch.cuda.stream(st):
-                j()
-            done = torch.cuda.Event()
-            done.record(st)
-            main.wait_event(done)
+        self._level_streams = {lvl: torch.cuda.Stream(device=self.device) for lvl in (1, 2, 3, 4)}
+        self._branch_streams = {}
 
     def packed(self, conv_mod):
         i, j = self._pack_index[id(conv_mod)]
         return self._pack.view(i), self._pack.view(j)
 
-    # ------------------------------------------------------------------ plan construction
+    # ------------------------------------------------------------------ stream helpers
+    def _branches_of(self, parent):
+        key = parent.cuda_stream
+        if key not in self._branch_streams:
+            self._branch_streams[key] = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        return self._branch_streams[key]
+
+    def _fork_join(self, jobs):
+        """Run the callables concurrently on the branch streams of the current stream (fork/join with events)."""
+        if not self.use_streams or len(jobs) < 2:
+            for j in jobs:
+                j()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        for j, st in zip(jobs, self._branches_of(cur)):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                j()
+            done = torch.cuda.Event()
+            done.record(st)
+            cur.wait_event(done)
+
+    def _on_side(self, level, job):
+        """Run `job` on the level's side stream, forked from the current stream; returns the completion event
+        (None when streams are off: the job has simply run)."""
+        if not self.use_streams:
+            job()
+            return None
+        cur, st = torch.cuda.current_stream(self.device), self._level_streams[level]
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        st.wait_event(fork)
+        with torch.cuda.stream(st):
+            job()
+        done = torch.cuda.Event()
+        done.record(st)
+        return done
+
+    def _join(self, ev):
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    # ------------------------------------------------------------------ plan construction (a tree of steps)
     def _new(self, N, Ch, H, W):
         return torch.empty(N, Ch, H, W, dtype=torch.float32, device=self.device)
 
-    def _inception(self, plan, mod: HG.Inception, x: Act, N, H, W) -> Act:
+    def _stats(self, plan, channels):
+        """(channels, 2) fp64 view of the plan's statistics arena (zeroed by ONE memset per forward)."""
+        a = plan["stats_used"]
+        if a + channels > plan["stats_arena"].shape[0]:
+            raise RuntimeError("statistics arena too small")
+        plan["stats_used"] = a + channels
+        return plan["stats_arena"][a:a + channels]
+
+    def _inception(self, plan, steps, mod: HG.Inception, x: Act, N, H, W) -> Act:
         c_in, cfg = HG.INCEPTION[mod.kind]
         a0 = cfg[0][0]
         outs = [a0] + [c[2] for c in cfg[1:]]
@@ -245,7 +282,6 @@ class HourglassEngine:
         Pg = torch.empty_like(P)
         stats = self._stats(plan, M + Co)
         mi = torch.zeros(M + Co, 2, device=self.device)
-        # the fused entry convolution: output channels [m1|m2|m3|b0] = P[:, 0:M+a0]
         members, moff = [], 0
         for i, br in enumerate(list(mod.convs)[1:]):
             members.append(_Member(br[0], br[1], moff))
@@ -253,7 +289,6 @@ class HourglassEngine:
         members.append(_Member(mod.convs[0][0], mod.convs[0][1], M))
         filt, filtT = self._group_filters[id(mod)]
         group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT)
-        # the k x k convolutions: P[:, m_i] -> P[:, M + a0 + ...]
         units, ooff, moff = [], M + a0, 0
         for i, br in enumerate(list(mod.convs)[1:]):
             mid = Act(P, moff, mids[i], relu=True, needs_grad=False)
@@ -263,38 +298,43 @@ class HourglassEngine:
             moff += mids[i]
         out = Act(P, M, Co, relu=True, needs_grad=False)
         out.gbuf = Pg
-        plan["steps"].append(_Node("inception", group=group, units=units, out=out, src=x))
+        steps.append(_Node("inception", group=group, units=units, out=out, src=x))
         plan["convs"] += [group] + [u for u, _, _ in units]
         return out
 
-    def _sequence(self, plan, seq, x: Act, N, H, W, tail_add: Optional[Act] = None):
-        """Runs a Sequential of pool / inception / channels / up.  Returns (Act, H, W)."""
+    def _sequence(self, plan, steps, seq, x: Act, N, H, W):
+        """Appends the steps of a Sequential of pool / inception / channels [/ up] to `steps`.
+        Returns (Act, H, W, pending_up) where pending_up says the sequence ended with an upsample that the
+        caller fuses with its residual add."""
+        pending_up = False
         for m in seq:
             if isinstance(m, torch.nn.AvgPool2d):
                 y = Act(self._new(N, x.C, H // 2, W // 2), 0, x.C)
-                plan["steps"].append(_Node("pool", src=x, out=y, H=H, W=W))
+                steps.append(_Node("pool", src=x, out=y))
                 x, H, W = y, H // 2, W // 2
             elif isinstance(m, HG.Inception):
-                x = self._inception(plan, m, x, N, H, W)
+                x = self._inception(plan, steps, m, x, N, H, W)
             elif isinstance(m, HG.Channels):
-                x = self._channels(plan, m, x, N, H, W)
+                x = self._channels(plan, steps, m, x, N, H, W)
             elif isinstance(m, torch.nn.UpsamplingBilinear2d):
-                plan["pending_up"] = (x, H, W)  # fused with the residual add by the caller
-                H, W = 2 * H, 2 * W
+                pending_up = True
             else:
                 raise TypeError(f"unexpected module {type(m)}")
-        return x, H, W
+        return x, H, W, pending_up
 
-    def _channels(self, plan, mod: HG.Channels, x: Act, N, H, W) -> Act:
+    def _channels(self, plan, steps, mod: HG.Channels, x: Act, N, H, W) -> Act:
         sides = list(mod.list)
         up_side = 0 if isinstance(sides[0][-1], torch.nn.UpsamplingBilinear2d) else 1
-        flat, _, _ = self._sequence(plan, sides[1 - up_side], x, N, H, W)
-        plan["pending_up"] = None
-        self._sequence(plan, sides[up_side], x, N, H, W)
-        lo, h, w = plan["pending_up"]
-        plan["pending_up"] = None
+        # the full-resolution side reads x through an alias with its OWN gradient buffer, so the two sides can run
+        # their backward passes concurrently; the alias' gradient is added into x's at the join
+        x_alias = Act(x.buf, x.coff, x.C, relu=x.relu, scale=x.scale, shift=x.shift, needs_grad=x.gbuf is not None)
+        flat_steps, up_steps = [], []
+        flat, _, _, _ = self._sequence(plan, flat_steps, sides[1 - up_side], x_alias, N, H, W)
+        lo, h, w, pending = self._sequence(plan, up_steps, sides[up_side], x, N, H, W)
+        assert pending
         out = Act(self._new(N, flat.C, H, W), 0, flat.C)
-        plan["steps"].append(_Node("upadd", lo=lo, hi=flat, out=out, h=h, w=w))
+        steps.append(_Node("channels", level=mod.level, flat=flat_steps, up=up_steps, lo=lo, hi=flat, out=out, x=x,
+                           x_alias=x_alias))
         return out
 
     def _build(self, N, H, W):
@@ -302,17 +342,16 @@ class HourglassEngine:
             raise ValueError(f"hourglass input must be a multiple of {HG.ALIGN} in both dimensions, got {H}x{W}")
         net = self.net
         Act.registry = []
-        plan = {"steps": [], "convs": [], "pending_up": None, "stats_used": 0,
+        plan = {"steps": [], "convs": [], "stats_used": 0,
                 "stats_arena": torch.zeros(16384, 2, dtype=torch.float64, device=self.device)}
         plan["x"] = self._new(N, 3, H, W)
         x_in = Act(plan["x"], 0, 3, needs_grad=False)
         stem_buf = self._new(N, 128, H, W)
-        s_stats = self._stats(plan, 128)
-        stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, s_stats, torch.zeros(128, 2, device=self.device))
+        stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, self._stats(plan, 128), torch.zeros(128, 2, device=self.device))
         stem.out.gbuf = torch.empty_like(stem_buf)
         plan["steps"].append(_Node("conv", unit=stem, gbuf=stem.out.gbuf, g_coff=0))
         plan["convs"].append(stem)
-        feat = self._channels(plan, net.seq[3], stem.out, N, H, W)
+        feat = self._channels(plan, plan["steps"], net.seq[3], stem.out, N, H, W)
         plan["pred"] = self._new(N, 1, H, W)
         head = ConvUnit(self, net.pred_layer, None, feat, plan["pred"], 0, None, None)
         plan["dpred"] = torch.empty_like(plan["pred"])
@@ -321,14 +360,6 @@ class HourglassEngine:
         plan["acts"], Act.registry = Act.registry, None
         self._carve_arenas(plan)
         return plan
-
-    def _stats(self, plan, channels):
-        """(channels, 2) fp64 view of the plan's statistics arena (zeroed by ONE memset per forward)."""
-        a = plan["stats_used"]
-        if a + channels > plan["stats_arena"].shape[0]:
-            raise RuntimeError("statistics arena too small")
-        plan["stats_used"] = a + channels
-        return plan["stats_arena"][a:a + channels]
 
     def _carve_arenas(self, plan):
         """One arena for all wgrad workspaces and one for all BN-backward sums: two memsets per backward
@@ -351,15 +382,8 @@ class HourglassEngine:
         return self._plans[key]
 
     # ------------------------------------------------------------------ execution
-    @torch.no_grad()
-    def _forward(self, x: torch.Tensor, need_grad: bool) -> torch.Tensor:
-        N, _, H, W = x.shape
-        plan = self.plan(N, H, W)
-        plan["x"].copy_(x)
-        training = self.net.training
-        plan["stats_arena"].zero_()
-        self._pack.run()
-        for step in plan["steps"]:
+    def _run_forward(self, steps, training):
+        for step in steps:
             if step.kind == "conv":
                 step.unit.forward(training)
             elif step.kind == "inception":
@@ -368,11 +392,46 @@ class HourglassEngine:
             elif step.kind == "pool":
                 s = step.src
                 L.avgpool2_fwd(s.buf, s.coff, s.C, step.out.buf, 0, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
-            elif step.kind == "upadd":
+            elif step.kind == "channels":
+                done = self._on_side(step.level, lambda: self._run_forward(step.flat, training))
+                self._run_forward(step.up, training)
+                self._join(done)
                 lo, hi = step.lo, step.hi
                 L.upsample2x_add_fwd(lo.buf, lo.coff, lo.C, step.out.buf, 0, hi=hi.buf, hi_coff=hi.coff, lo_relu=lo.relu,
                                      hi_relu=hi.relu, lo_scale=lo.scale, lo_shift=lo.shift, hi_scale=hi.scale,
                                      hi_shift=hi.shift)
+
+    def _run_backward(self, steps):
+        for step in reversed(steps):
+            if step.kind == "conv":
+                step.unit.backward(step.gbuf, step.g_coff)
+            elif step.kind == "inception":
+                # the concat output's gradient is complete: k x k convolutions first (they fill the gradient of the
+                # mid activations), then the fused entry convolution
+                self._fork_join([(lambda u=u, g=gbuf, o=g_coff: u.backward(g, o)) for u, gbuf, g_coff in step.units])
+                step.group.backward()
+            elif step.kind == "pool":
+                s = step.src
+                L.avgpool2_bwd(step.out.gbuf, 0, s.gbuf, s.coff, s.C, accumulate=s.grad_mode())
+            elif step.kind == "channels":
+                lo, hi, o = step.lo, step.hi, step.out
+                L.add_slice(o.gbuf, 0, hi.gbuf, hi.coff, hi.C, accumulate=hi.grad_mode())
+                L.upsample2x_bwd(o.gbuf, 0, lo.gbuf, lo.coff, lo.C, accumulate=lo.grad_mode())
+                done = self._on_side(step.level, lambda: self._run_backward(step.flat))
+                self._run_backward(step.up)
+                self._join(done)
+                x, xa = step.x, step.x_alias
+                if x.gbuf is not None:
+                    L.add_slice(xa.gbuf, xa.coff, x.gbuf, x.coff, x.C, accumulate=x.grad_mode())
+
+    @torch.no_grad()
+    def _forward(self, x: torch.Tensor, need_grad: bool) -> torch.Tensor:
+        N, _, H, W = x.shape
+        plan = self.plan(N, H, W)
+        plan["x"].copy_(x)
+        plan["stats_arena"].zero_()
+        self._pack.run()
+        self._run_forward(plan["steps"], self.net.training)
         self._last = plan  # (num_batches_tracked is not advanced: momentum is fixed, the counter is unused)
         return plan["pred"]
 
@@ -384,21 +443,7 @@ class HourglassEngine:
         plan["sums_arena"].zero_()
         for a in plan["acts"]:  # first gradient contribution overwrites, later ones accumulate
             a.grad_written = False
-        for step in reversed(plan["steps"]):
-            if step.kind == "conv":
-                step.unit.backward(step.gbuf, step.g_coff)
-            elif step.kind == "inception":
-                # the concat output's gradient is complete: k x k convolutions first (they fill the gradient of
-                # the mid activations), then the fused entry convolution
-                self._fork_join([(lambda u=u, g=gbuf, o=g_coff: u.backward(g, o)) for u, gbuf, g_coff in step.units])
-                step.group.backward()
-            elif step.kind == "pool":
-                s = step.src
-                L.avgpool2_bwd(step.out.gbuf, 0, s.gbuf, s.coff, s.C, accumulate=s.grad_mode())
-            elif step.kind == "upadd":
-                lo, hi, o = step.lo, step.hi, step.out
-                L.add_slice(o.gbuf, 0, hi.gbuf, hi.coff, hi.C, accumulate=hi.grad_mode())
-                L.upsample2x_bwd(o.gbuf, 0, lo.gbuf, lo.coff, lo.C, accumulate=lo.grad_mode())
+        self._run_backward(plan["steps"])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (N,3,H,W) -> pred_d (N,1,H,W) (log depth), attached to autograd when grad is enabled."""
