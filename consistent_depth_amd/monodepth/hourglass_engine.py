@@ -32,6 +32,7 @@ removes them); the engine leaves those gradients at exactly 0 instead of computi
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -208,7 +209,9 @@ class HourglassEngine:
                 self._pack_index[id(m)] = (self._pack.add(m.weight, False), self._pack.add(m.weight, True))
         self._pack.build()
         # streams: one per Channels level for its full-resolution side, and three branch streams per parent stream
-        self.use_streams = True
+        mode = os.environ.get("CD_AMD_ENGINE_STREAMS", "branch")   # none | branch | level | both
+        self.use_branch_streams = mode in ("branch", "both")
+        self.use_level_streams = mode in ("level", "both")
         self._level_streams = {lvl: torch.cuda.Stream(device=self.device) for lvl in (1, 2, 3, 4)}
         self._branch_streams = {}
 
@@ -225,7 +228,7 @@ class HourglassEngine:
 
     def _fork_join(self, jobs):
         """Run the callables concurrently on the branch streams of the current stream (fork/join with events)."""
-        if not self.use_streams or len(jobs) < 2:
+        if not self.use_branch_streams or len(jobs) < 2:
             for j in jobs:
                 j()
             return
@@ -243,7 +246,7 @@ class HourglassEngine:
     def _on_side(self, level, job):
         """Run `job` on the level's side stream, forked from the current stream; returns the completion event
         (None when streams are off: the job has simply run)."""
-        if not self.use_streams:
+        if not self.use_level_streams:
             job()
             return None
         cur, st = torch.cuda.current_stream(self.device), self._level_streams[level]
