@@ -15,6 +15,11 @@ SHAPES = [  # H, W, ks, Cin, Cout, share of forward MACs
     (384, 224, 7, 3, 128, 3.1), (96, 56, 7, 32, 64, 3.1), (192, 112, 1, 128, 32, 2.8), (192, 112, 3, 64, 32, 1.5),
     (48, 28, 7, 32, 64, 1.3), (24, 14, 7, 32, 64, 0.1),
 ]
+DGRAD_SHAPES = [  # the input-gradient convolutions (channels swapped) of the dominant shapes
+    (384, 224, 11, 16, 64, 20.2), (192, 112, 11, 32, 64, 10.1), (192, 112, 7, 32, 64, 8.2), (384, 224, 7, 16, 64, 8.2),
+    (192, 112, 7, 32, 32, 6.1), (96, 56, 11, 64, 64, 5.0), (192, 112, 5, 32, 32, 3.1), (96, 56, 7, 64, 32, 3.1),
+    (192, 112, 3, 32, 64, 1.5), (384, 224, 1, 208, 128, 4.6), (192, 112, 1, 128, 128, 2.8),
+]
 
 
 def main():
@@ -22,10 +27,12 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--torch", action="store_true", help="also time torch (MIOpen) on the same shape")
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--dgrad", action="store_true", help="bench the dgrad-shaped convolutions instead")
+    ap.add_argument("--wgrad", action="store_true", help="bench the weight-gradient kernel on the forward shapes")
     args = ap.parse_args()
     from consistent_depth_amd.ops import conv
     N = 8
-    for i, (H, W, ks, Cin, Cout, share) in enumerate(SHAPES):
+    for i, (H, W, ks, Cin, Cout, share) in enumerate(DGRAD_SHAPES if args.dgrad else SHAPES):
         if args.only >= 0 and i != args.only:
             continue
         x = torch.randn(N, Cin, H, W, device="cuda")
@@ -47,7 +54,13 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / args.iters
 
-        ms = timeit(lambda: conv.conv2d(x, pk, Cin, Cout, ks, bias=b, out=out))
+        if args.wgrad:
+            dy = torch.randn(N, Cout, H, W, device="cuda")
+            dw = torch.empty(Cout, Cin, ks, ks, device="cuda")
+            ws = conv.wgrad_workspace(Cout, Cin, ks, "cuda")
+            ms = timeit(lambda: conv.conv2d_wgrad(x, dy, Cin, Cout, ks, dw, ws, in_relu=True))
+        else:
+            ms = timeit(lambda: conv.conv2d(x, pk, Cin, Cout, ks, bias=b, out=out))
         rec = {"shape": [H, W, ks, Cin, Cout], "share_pct": share, "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1)}
         if args.torch:
             ms_t = timeit(lambda: torch.nn.functional.conv2d(x, w, b, padding=(ks - 1) // 2))
