@@ -10,8 +10,8 @@
 //   B[k = lane>>4][j = lane&15] = act(X)[ci0+j][y+ky][x0+k+kx]  (LDS input tile with halo)
 //   D: lane holds ci0+(lane&15), co0 + 4*(lane>>4) + {0..3}.
 // A block stages a TY x 32 pixel tile of dY (CO_T*16 channels) and of the input (CI_T*16 channels,
-// + halo) in LDS; its 4 waves split the filter taps (k >= 7), taps x rows (k = 5) or rows (k <= 3)
-// and keep one accumulator tile per (tap, co tile, ci tile) in registers while the block walks all the
+// + halo) in LDS; its 4 waves partition the accumulator set (taps for k >= 5, co x ci tiles for k <= 3 -- never
+// the pixels) and keep one accumulator tile per owned (tap, co tile, ci tile) in registers while the block walks all the
 // image tiles assigned to it (grid-stride over (image, tile)); partial sums are flushed ONCE per block
 // with fp32 atomics into a zeroed packed buffer [co grp][ci grp][tap][co][ci] (64-byte contiguous per
 // (tap, co)), which unpack_wgrad_kernel transposes into the [Cout][Cin][k][k] gradient.
@@ -23,12 +23,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_TX = 32;
 
-template <int KS> struct WgCfg {
-    static constexpr int TY = (KS == 1) ? 4 : 8;                     // tile rows (1x1: smaller tile -> 2 blocks per CU)
-    static constexpr int NW_T = (KS >= 7) ? 4 : (KS == 5 ? 2 : 1);  // waves splitting the taps
-    static constexpr int NW_R = 4 / NW_T;                            // waves splitting the rows
+// The 4 waves of a block partition the accumulator set (tap, co tile, ci tile) -- never the pixels, so no two
+// waves hold partial sums of the same dW element (no redundant flush):
+//   k >= 5 : taps round-robin over the 4 waves;   k <= 3 : 2 x 2 over (co tiles, ci tiles) when both have >= 2 tiles,
+//   else taps (k = 3) / whichever tile dimension has 4 (k = 1).
+template <int KS, int CO_T, int CI_T> struct WgSplit {
+    static constexpr bool by_tiles = (KS <= 3) && (CO_T >= 2) && (CI_T >= 2);
+    static constexpr bool by_co4 = (KS == 1) && !by_tiles && (CO_T >= 4);
+    static constexpr bool by_ci4 = (KS == 1) && !by_tiles && !by_co4 && (CI_T >= 4);
+    static constexpr int NW_A = by_tiles ? 2 : (by_co4 ? 4 : 1);     // waves over co tiles
+    static constexpr int NW_C = by_tiles ? 2 : (by_ci4 ? 4 : 1);     // waves over ci tiles
+    static constexpr int NW_T = 4 / (NW_A * NW_C);                   // waves over taps
     static constexpr int TAPS = KS * KS;
     static constexpr int TPW = (TAPS + NW_T - 1) / NW_T;             // taps per wave
+    static constexpr int APW = CO_T / NW_A, CPW = CI_T / NW_C;       // tiles per wave
+};
+
+template <int KS> struct WgCfg {
+    static constexpr int TY = (KS == 1) ? 4 : 8;                     // tile rows (1x1: smaller tile -> 2 blocks per CU)
+    static constexpr int TAPS = KS * KS;
     static constexpr int RS = WG_TX + KS - 1, ROWS = TY + KS - 1;
     static constexpr int PS_IN_RAW = ROWS * RS;
     static constexpr int PS_IN = PS_IN_RAW + ((2 - (PS_IN_RAW % 32)) + 32) % 32;   // == 2 (mod 32)
@@ -42,7 +55,9 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
     const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
     float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y) {
     using Cfg = WgCfg<KS>;
-    constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, TPW = Cfg::TPW, NW_T = Cfg::NW_T, NW_R = Cfg::NW_R;
+    using Sp = WgSplit<KS, CO_T, CI_T>;
+    constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, TPW = Sp::TPW, NW_T = Sp::NW_T, NW_A = Sp::NW_A, NW_C = Sp::NW_C;
+    constexpr int APW = Sp::APW, CPW = Sp::CPW;
     constexpr int RS = Cfg::RS, ROWS = Cfg::ROWS, PSI = Cfg::PS_IN, PSD = Cfg::PS_DY, WG_TY = Cfg::TY;
     constexpr int COB = CO_T * 16, CIB = CI_T * 16;
 
@@ -52,17 +67,17 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
 
     const int cig = blockIdx.y, cog = blockIdx.z;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int wt = wid % NW_T, wr = wid / NW_T;   // this wave's tap slot / row slot
+    const int wt = wid % NW_T, wa = (wid / NW_T) % NW_A, wc = wid / (NW_T * NW_A);   // this wave's tap / co-tile / ci-tile slot
     const size_t HW = (size_t)H * W;
     const int items = N * tiles_x * tiles_y;
 
-    f32x4 acc[TPW][CO_T][CI_T];
+    f32x4 acc[TPW][APW][CPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int a = 0; a < CO_T; ++a)
+        for (int a = 0; a < APW; ++a)
 #pragma unroll
-            for (int c = 0; c < CI_T; ++c) acc[t][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < CPW; ++c) acc[t][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int a_lane = (lane & 15) * PSD + (lane >> 4);   // dY fragment: channel i = lane&15, pixel k = lane>>4
     const int b_lane = (lane & 15) * PSI + (lane >> 4);   // input fragment: channel j = lane&15, pixel k
@@ -125,24 +140,24 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
             s_in[c * PSI + r * RS + col] = v;
         }
         __syncthreads();
-        // ---- MFMA: this wave's rows x all 4-pixel groups x this wave's taps
+        // ---- MFMA: all rows x all 4-pixel groups x this wave's (taps, co tiles, ci tiles)
 #pragma unroll 1
-        for (int r = wr; r < WG_TY; r += NW_R) {
+        for (int r = 0; r < WG_TY; ++r) {
 #pragma unroll 2
             for (int c4 = 0; c4 < WG_TX / 4; ++c4) {
-                float af[CO_T];
+                float af[APW];
 #pragma unroll
-                for (int a = 0; a < CO_T; ++a) af[a] = s_dy[a * 16 * PSD + r * WG_TX + c4 * 4 + a_lane];
+                for (int a = 0; a < APW; ++a) af[a] = s_dy[(a * NW_A + wa) * 16 * PSD + r * WG_TX + c4 * 4 + a_lane];
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     const int tap = t * NW_T + wt;   // compile-time stride, wave-uniform offset
                     if (tap < TAPS) {
                         const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
-                        for (int c = 0; c < CI_T; ++c) {
-                            const float bf = s_in[c * 16 * PSI + (r + ky) * RS + c4 * 4 + kx + b_lane];
+                        for (int c = 0; c < CPW; ++c) {
+                            const float bf = s_in[(c * NW_C + wc) * 16 * PSI + (r + ky) * RS + c4 * 4 + kx + b_lane];
 #pragma unroll
-                            for (int a = 0; a < CO_T; ++a)
+                            for (int a = 0; a < APW; ++a)
                                 acc[t][a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf, acc[t][a][c], 0, 0, 0);
                         }
                     }
@@ -159,10 +174,10 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
         const int tap = t * NW_T + wt;
         if (tap < TAPS) {
 #pragma unroll
-            for (int a = 0; a < CO_T; ++a)
+            for (int a = 0; a < APW; ++a)
 #pragma unroll
-                for (int c = 0; c < CI_T; ++c) {
-                    float* dst = dw_packed + base + ((size_t)tap * COB + a * 16 + co4) * CIB + c * 16 + ci_l;
+                for (int c = 0; c < CPW; ++c) {
+                    float* dst = dw_packed + base + ((size_t)tap * COB + (a * NW_A + wa) * 16 + co4) * CIB + (c * NW_C + wc) * 16 + ci_l;
                     const f32x4 v = acc[t][a][c];
                     atomic_add_f32(dst, v.x);
                     atomic_add_f32(dst + CIB, v.y);
