@@ -82,7 +82,77 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
     const int a_lane = (lane & 15) * PSD + (lane >> 4);   // dY fragment: channel i = lane&15, pixel k = lane>>4
     const int b_lane = (lane & 15) * PSI + (lane >> 4);   // input fragment: channel j = lane&15, pixel k
 
+    // 1x1 (pure GEMM over pixels): software pipeline -- the next tile's global loads are in flight in registers
+    // while the MFMAs of the current tile run (the staged bytes per MFMA are highest here)
+    constexpr int PF_DY = (KS == 1) ? (COB * WG_TY * (WG_TX / 4) + kBlock - 1) / kBlock : 1;
+    constexpr int PF_IN = (KS == 1) ? (CIB * WG_TY * (WG_TX / 4) + kBlock - 1) / kBlock : 1;
+    float4 pf_dy[PF_DY], pf_in[PF_IN];
+    const bool pipelined = (KS == 1) && ((W & 3) == 0);
+    auto pf_load = [&](int item) {
+        const int n = item / (tiles_x * tiles_y), tile = item - n * (tiles_x * tiles_y);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int X0 = tx * WG_TX, Y0 = ty * WG_TY;
+        const float* dyn = dy + ((size_t)n * dy_ctot + dy_coff) * HW;
+        const float* xn = x + ((size_t)n * x_ctot + x_coff) * HW;
+#pragma unroll
+        for (int q = 0; q < PF_DY; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            const int c = i / (WG_TY * (WG_TX / 4)), rem = i - c * (WG_TY * (WG_TX / 4));
+            const int r = rem / (WG_TX / 4), col = (rem - r * (WG_TX / 4)) * 4;
+            const int co = cog * COB + c, gy = Y0 + r, gx = X0 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < COB * WG_TY * (WG_TX / 4) && co < Cout && gy < H && gx < W)
+                v = *reinterpret_cast<const float4*>(dyn + (size_t)co * HW + (size_t)gy * W + gx);
+            pf_dy[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < PF_IN; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            const int c = i / (WG_TY * (WG_TX / 4)), rem = i - c * (WG_TY * (WG_TX / 4));
+            const int r = rem / (WG_TX / 4), col = (rem - r * (WG_TX / 4)) * 4;
+            const int ci = cig * CIB + c, gy = Y0 + r, gx = X0 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < CIB * WG_TY * (WG_TX / 4) && ci < Cin && gy < H && gx < W) {
+                v = *reinterpret_cast<const float4*>(xn + (size_t)ci * HW + (size_t)gy * W + gx);
+                if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+                if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            pf_in[q] = v;
+        }
+    };
+    auto pf_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < PF_DY; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            if (i < COB * WG_TY * (WG_TX / 4)) {
+                const int c = i / (WG_TY * (WG_TX / 4)), rem = i - c * (WG_TY * (WG_TX / 4));
+                const int r = rem / (WG_TX / 4), col = (rem - r * (WG_TX / 4)) * 4;
+                float* d = s_dy + c * PSD + r * WG_TX + col;
+                *reinterpret_cast<float2*>(d) = make_float2(pf_dy[q].x, pf_dy[q].y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(pf_dy[q].z, pf_dy[q].w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PF_IN; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            if (i < CIB * WG_TY * (WG_TX / 4)) {
+                const int c = i / (WG_TY * (WG_TX / 4)), rem = i - c * (WG_TY * (WG_TX / 4));
+                const int r = rem / (WG_TX / 4), col = (rem - r * (WG_TX / 4)) * 4;
+                float* d = s_in + c * PSI + r * RS + col;
+                *reinterpret_cast<float2*>(d) = make_float2(pf_in[q].x, pf_in[q].y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(pf_in[q].z, pf_in[q].w);
+            }
+        }
+    };
+    if (pipelined && (int)blockIdx.x < items) pf_load(blockIdx.x);
+
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        if (pipelined) {
+            __syncthreads();
+            pf_store();
+            if (item + (int)gridDim.x < items) pf_load(item + gridDim.x);
+            __syncthreads();
+        } else {
         const int n = item / (tiles_x * tiles_y), tile = item - n * (tiles_x * tiles_y);
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int X0 = tx * WG_TX, Y0 = ty * WG_TY;
@@ -140,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
             s_in[c * PSI + r * RS + col] = v;
         }
         __syncthreads();
+        }
         // ---- MFMA: all rows x all 4-pixel groups x this wave's (taps, co tiles, ci tiles)
 #pragma unroll 1
         for (int r = 0; r < WG_TY; ++r) {
