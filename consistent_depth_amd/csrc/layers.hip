@@ -52,6 +52,32 @@ __global__ __launch_bounds__(kBlock) void bn_normalize_kernel(float* __restrict_
     }
 }
 
+// BatchNorm (train) WITHOUT a pass over the activation: from the conv epilogue's (sum, sumsq) compute per channel
+//   scale = gamma * invstd,  shift = beta - gamma * mean * invstd     (gamma = 1, beta = 0 when not affine)
+// so that consumers evaluate relu(raw * scale + shift) while loading the RAW conv output; also saves
+// (mean, invstd) for the backward and updates the running statistics.  One thread per channel.
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int coff, int C, double count, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float* __restrict__ mean_invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean_d = stats[2 * (coff + c)] / count;
+    double var_d = stats[2 * (coff + c) + 1] / count - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    mean_invstd[2 * (coff + c)] = mean;
+    mean_invstd[2 * (coff + c) + 1] = invstd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[coff + c] = g * invstd;
+    shift[coff + c] = b - g * mean * invstd;
+    if (running_mean) {
+        const double unb = count > 1.0 ? var_d * count / (count - 1.0) : var_d;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
 // ---------------------------------------------------------------- BN(train)+ReLU backward
 // Given dA = d loss / d a with a = relu(gamma*x_hat + beta):
 //   pass 1: T1[c] = sum dA*mask, T2[c] = sum dA*mask*x_hat          (mask = gamma*x_hat + beta > 0)
@@ -61,15 +87,18 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_reduce_kernel(const float*
                                                                     const float* __restrict__ xhat, int x_ctot,
                                                                     int x_coff, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
+                                                                    const float* __restrict__ mean_invstd, int x_is_raw,
                                                                     double* __restrict__ sums, int HW) {
     __shared__ float lds[kBlock / kWave];
     const int c = blockIdx.y, n = blockIdx.z;
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    // x_is_raw: `xhat` holds the RAW conv output; x_hat = (raw - mean) * invstd is formed on the fly
+    const float xm = x_is_raw ? mean_invstd[2 * (x_coff + c)] : 0.f, xs = x_is_raw ? mean_invstd[2 * (x_coff + c) + 1] : 1.f;
     const float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
     float t1 = 0.f, t2 = 0.f;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
-        const float xv = xh[i];
+        const float xv = (xh[i] - xm) * xs;
         const float dv = (g * xv + b > 0.f) ? d[i] : 0.f;
         t1 += dv;
         t2 += dv * xv;
@@ -87,11 +116,12 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
                                                                    const double* __restrict__ sums, double count,
-                                                                   const float* __restrict__ mean_invstd,
+                                                                   const float* __restrict__ mean_invstd, int x_is_raw,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                    int HW) {
     const int c = blockIdx.y, n = blockIdx.z;
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float xm = x_is_raw ? mean_invstd[2 * (x_coff + c)] : 0.f, xs = x_is_raw ? mean_invstd[2 * (x_coff + c) + 1] : 1.f;
     const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
     const float k = g * mean_invstd[2 * (x_coff + c) + 1];
     if (dgamma && blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
@@ -101,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
     float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
-        const float xv = xh[i];
+        const float xv = (xh[i] - xm) * xs;
         const float dv = (g * xv + b > 0.f) ? d[i] : 0.f;
         d[i] = k * (dv - m1 - xv * m2);
     }
@@ -247,19 +277,31 @@ int cd_bn_normalize(float* x, int ctot, int coff, int C, const double* stats, fl
     return CD_OK;
 }
 
+int cd_bn_finalize(const double* stats, int ctot, int coff, int C, double count, float eps, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum, float* mean_invstd,
+                   float* scale, float* shift, void* stream) {
+    CD_ARGCHK(stats && mean_invstd && scale && shift && C > 0 && coff >= 0 && coff + C <= ctot && count > 0);
+    CD_ARGCHK((running_mean == nullptr) == (running_var == nullptr) && (gamma == nullptr) == (beta == nullptr));
+    hipLaunchKernelGGL(cd::bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, coff, C, count, eps,
+                       gamma, beta, running_mean, running_var, momentum, mean_invstd, scale, shift);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C, const float* gamma,
-                   const float* beta, const float* mean_invstd, double* sums, int sums_prezeroed, float* dgamma,
+                   const float* beta, const float* mean_invstd, double* sums, int flags, float* dgamma,
                    float* dbeta, int N, int H, int W, void* stream) {
+    const int sums_prezeroed = flags & 1, x_is_raw = (flags >> 1) & 1;
     CD_ARGCHK(dA && xhat && mean_invstd && sums && C > 0 && d_coff >= 0 && d_coff + C <= d_ctot && x_coff >= 0 && x_coff + C <= x_ctot);
     CD_ARGCHK((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr));
     hipStream_t s = (hipStream_t)stream;
     if (!sums_prezeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s) != hipSuccess) return CD_ERR_LAUNCH;
     const dim3 grid = cd::plane_grid(H * W, C, N, 8);
     hipLaunchKernelGGL(cd::bn_relu_bwd_reduce_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
-                       gamma, beta, sums, H * W);
+                       gamma, beta, mean_invstd, x_is_raw, sums, H * W);
     CD_CHECK_LAUNCH();
     hipLaunchKernelGGL(cd::bn_relu_bwd_apply_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
-                       gamma, beta, sums, (double)N * H * W, mean_invstd, dgamma, dbeta, H * W);
+                       gamma, beta, sums, (double)N * H * W, mean_invstd, x_is_raw, dgamma, dbeta, H * W);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

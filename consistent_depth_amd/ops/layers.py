@@ -24,11 +24,21 @@ def bn_normalize(x, coff, C, stats, mean_invstd, eps=1e-5, running_mean=None, ru
     _native.check(rc, "cd_bn_normalize")
 
 
+def bn_finalize(stats, coff, C, count, mean_invstd, scale, shift, eps=1e-5, gamma=None, beta=None, running_mean=None,
+                running_var=None, momentum=0.1):
+    """stats (ctot,2) fp64 -> scale/shift (ctot,) for relu(raw*scale+shift) on load; no pass over the activation."""
+    rc = _native.lib().cd_bn_finalize(stats.data_ptr(), stats.shape[0], coff, C, float(count), float(eps), _o(gamma), _o(beta),
+                                      _o(running_mean), _o(running_var), float(momentum), _p(mean_invstd), _p(scale), _p(shift),
+                                      _native.stream_ptr(scale.device))
+    _native.check(rc, "cd_bn_finalize")
+
+
 def bn_relu_bwd(dA, d_coff, xhat, x_coff, C, mean_invstd, sums, gamma=None, beta=None, dgamma=None, dbeta=None,
-                sums_prezeroed=False):
+                sums_prezeroed=False, x_is_raw=False):
     N, d_ctot, H, W = dA.shape
     rc = _native.lib().cd_bn_relu_bwd(_p(dA), d_ctot, d_coff, _p(xhat), xhat.shape[1], x_coff, C, _o(gamma), _o(beta),
-                                      _p(mean_invstd), sums.data_ptr(), int(sums_prezeroed), _o(dgamma), _o(dbeta), N, H, W,
+                                      _p(mean_invstd), sums.data_ptr(), int(sums_prezeroed) | (2 if x_is_raw else 0), _o(dgamma),
+                                      _o(dbeta), N, H, W,
                                       _s(dA))
     _native.check(rc, "cd_bn_relu_bwd")
 

@@ -189,13 +189,22 @@ int cd_bn_normalize(float* x, int ctot, int coff, int C, const double* stats, fl
                     float* running_mean, float* running_var, float momentum, float* mean_invstd,
                     int N, int H, int W, void* stream);
 
+/* The same BatchNorm WITHOUT a pass over the activation: from stats compute per channel (buffer-indexed arrays of
+ * ctot floats) scale = gamma*invstd and shift = beta - gamma*mean*invstd, so consumers evaluate
+ * relu(raw*scale + shift) while loading the RAW conv output; saves mean_invstd, updates running stats.
+ * count = N*H*W.  gamma/beta/running_* are slice-local ([C]) and optional. */
+int cd_bn_finalize(const double* stats, int ctot, int coff, int C, double count, float eps,
+                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float momentum, float* mean_invstd, float* scale, float* shift, void* stream);
+
 /* Backward of relu(gamma * x_hat + beta) + train-mode BatchNorm in one call: dA (gradient w.r.t. the
  * activated output) is replaced IN PLACE by the gradient w.r.t. the raw (pre-BN) tensor.  gamma/beta
  * NULL = BatchNorm2d(affine=False); dgamma/dbeta[C] receive the affine gradients when given.
- * sums: scratch of 2*C doubles, zeroed inside unless sums_prezeroed (one memset over an arena of many). */
+ * sums: scratch of 2*C doubles.  flags bit 0: sums already zeroed by the caller (one memset over an arena of
+ * many); bit 1: `xhat` holds the RAW conv output (cd_bn_finalize path) and x_hat is formed on the fly. */
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C,
                    const float* gamma, const float* beta, const float* mean_invstd, double* sums,
-                   int sums_prezeroed, float* dgamma, float* dbeta, int N, int H, int W, void* stream);
+                   int flags, float* dgamma, float* dbeta, int N, int H, int W, void* stream);
 
 /* AvgPool2d(2) of act(x) and its adjoint (dx = gradient w.r.t. the ACTIVATED input, (+)= when accumulate). */
 int cd_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* in_scale, const float* in_shift,
