@@ -41,7 +41,7 @@ SIGNATURES = {
     "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_bn_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "cd_bn_finalize": (c_i, [c_p, c_i, c_i, c_i, ctypes.c_double, c_f, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
-    "cd_bn_relu_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "cd_bn_relu_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),
     "cd_avgpool2_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_avgpool2_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_upsample2x_add_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

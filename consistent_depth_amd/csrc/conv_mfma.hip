@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < CI * ROWS * (RS / 4) && ci < Cin && gy < H && gx < W) {
                 v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
-                if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+                if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
                 if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             pf_in[q] = v;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ci < Cin && gy < H && gx < W) {
                     v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
-                    if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+                    if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
                     if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 }
                 *reinterpret_cast<float4*>(s_in + cc * PS + r * RS + c) = v;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
             float v = 0.f;
             if (ci < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
                 v = xin[(size_t)ci * HW + (size_t)gy * W + gx];
-                if (in_scale) v = v * in_scale[ci] + in_shift[ci];
+                if (in_scale) v = __fmaf_rn(v, in_scale[ci], in_shift[ci]);  // same fma as the BN backward's mask
                 if (in_relu) v = fmaxf(v, 0.f);
             }
             s_in[cc * PS + r * RS + c] = v;

@@ -12,7 +12,7 @@
 namespace cd {
 
 __device__ __forceinline__ float act(float v, const float* sc, const float* sh, int c, int relu) {
-    if (sc) v = v * sc[c] + sh[c];
+    if (sc) v = __fmaf_rn(v, sc[c], sh[c]);  // explicit fma: the BN backward re-evaluates exactly this expression
     return relu ? fmaxf(v, 0.f) : v;
 }
 
@@ -87,19 +87,26 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_reduce_kernel(const float*
                                                                     const float* __restrict__ xhat, int x_ctot,
                                                                     int x_coff, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
-                                                                    const float* __restrict__ mean_invstd, int x_is_raw,
+                                                                    const float* __restrict__ mean_invstd,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
                                                                     double* __restrict__ sums, int HW) {
     __shared__ float lds[kBlock / kWave];
     const int c = blockIdx.y, n = blockIdx.z;
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    // x_is_raw: `xhat` holds the RAW conv output; x_hat = (raw - mean) * invstd is formed on the fly
-    const float xm = x_is_raw ? mean_invstd[2 * (x_coff + c)] : 0.f, xs = x_is_raw ? mean_invstd[2 * (x_coff + c) + 1] : 1.f;
+    // raw mode (scale != NULL): `xhat` holds the RAW conv output.  The ReLU mask is evaluated on EXACTLY the
+    // expression the consumers applied on load, fma(raw, scale, shift) = gamma*x_hat + beta.
+    const bool raw = scale != nullptr;
+    const float sc = raw ? scale[x_coff + c] : 0.f, sh = raw ? shift[x_coff + c] : 0.f;
+    const float xm = raw ? mean_invstd[2 * (x_coff + c)] : 0.f, xs = raw ? mean_invstd[2 * (x_coff + c) + 1] : 1.f;
     const float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
     float t1 = 0.f, t2 = 0.f;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
-        const float xv = (xh[i] - xm) * xs;
-        const float dv = (g * xv + b > 0.f) ? d[i] : 0.f;
+        const float rv = xh[i];
+        const float pre = raw ? __fmaf_rn(rv, sc, sh) : g * rv + b;
+        const float xv = raw ? (gamma ? (rv - xm) * xs : pre) : rv;
+        const float dv = pre > 0.f ? d[i] : 0.f;
         t1 += dv;
         t2 += dv * xv;
     }
@@ -116,12 +123,16 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
                                                                    const double* __restrict__ sums, double count,
-                                                                   const float* __restrict__ mean_invstd, int x_is_raw,
+                                                                   const float* __restrict__ mean_invstd,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                    int HW) {
     const int c = blockIdx.y, n = blockIdx.z;
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float xm = x_is_raw ? mean_invstd[2 * (x_coff + c)] : 0.f, xs = x_is_raw ? mean_invstd[2 * (x_coff + c) + 1] : 1.f;
+    const bool raw = scale != nullptr;
+    const float sc = raw ? scale[x_coff + c] : 0.f, sh = raw ? shift[x_coff + c] : 0.f;
+    const float xm = raw ? mean_invstd[2 * (x_coff + c)] : 0.f, xs = raw ? mean_invstd[2 * (x_coff + c) + 1] : 1.f;
     const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
     const float k = g * mean_invstd[2 * (x_coff + c) + 1];
     if (dgamma && blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
@@ -131,8 +142,10 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
     float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
-        const float xv = (xh[i] - xm) * xs;
-        const float dv = (g * xv + b > 0.f) ? d[i] : 0.f;
+        const float rv = xh[i];
+        const float pre = raw ? __fmaf_rn(rv, sc, sh) : g * rv + b;
+        const float xv = raw ? (gamma ? (rv - xm) * xs : pre) : rv;
+        const float dv = pre > 0.f ? d[i] : 0.f;
         d[i] = k * (dv - m1 - xv * m2);
     }
 }
@@ -289,19 +302,19 @@ int cd_bn_finalize(const double* stats, int ctot, int coff, int C, double count,
 }
 
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C, const float* gamma,
-                   const float* beta, const float* mean_invstd, double* sums, int flags, float* dgamma,
-                   float* dbeta, int N, int H, int W, void* stream) {
-    const int sums_prezeroed = flags & 1, x_is_raw = (flags >> 1) & 1;
+                   const float* beta, const float* mean_invstd, const float* scale, const float* shift, double* sums,
+                   int sums_prezeroed, float* dgamma, float* dbeta, int N, int H, int W, void* stream) {
+    CD_ARGCHK((scale == nullptr) == (shift == nullptr));
     CD_ARGCHK(dA && xhat && mean_invstd && sums && C > 0 && d_coff >= 0 && d_coff + C <= d_ctot && x_coff >= 0 && x_coff + C <= x_ctot);
     CD_ARGCHK((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr));
     hipStream_t s = (hipStream_t)stream;
     if (!sums_prezeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s) != hipSuccess) return CD_ERR_LAUNCH;
     const dim3 grid = cd::plane_grid(H * W, C, N, 8);
     hipLaunchKernelGGL(cd::bn_relu_bwd_reduce_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
-                       gamma, beta, mean_invstd, x_is_raw, sums, H * W);
+                       gamma, beta, mean_invstd, scale, shift, sums, H * W);
     CD_CHECK_LAUNCH();
     hipLaunchKernelGGL(cd::bn_relu_bwd_apply_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
-                       gamma, beta, sums, (double)N * H * W, mean_invstd, x_is_raw, dgamma, dbeta, H * W);
+                       gamma, beta, sums, (double)N * H * W, mean_invstd, scale, shift, dgamma, dbeta, H * W);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -97,7 +97,7 @@ class ConvUnit:
             L.bn_relu_bwd(gbuf, g_coff, self.dst_buf, self.dst_coff, self.cout, self.mi, self.sums,
                           gamma=self.bn.weight if affine else None, beta=self.bn.bias if affine else None,
                           dgamma=_grad_of(self.bn.weight) if affine else None,
-                          dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True, x_is_raw=True)
+                          dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True, scale=self.sc, shift=self.sh)
         else:
             L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias))
         C.conv2d_wgrad(s.buf, gbuf, self.cin, self.cout, self.ks, _grad_of(self.conv.weight), self.wgrad_ws, x_coff=s.coff,
@@ -147,7 +147,7 @@ class PointwiseGroup:
 
     def backward(self):
         s = self.src
-        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True, x_is_raw=True)
+        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True, scale=self.sc, shift=self.sh)
         # ONE weight-gradient GEMM for the four filters (X is read once), then split the rows
         C.conv2d_wgrad(s.buf, self.Pg, self.cin, self.ctot, 1, self._dw, self.wgrad_ws, x_coff=s.coff, dy_coff=0,
                        in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)

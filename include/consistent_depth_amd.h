@@ -200,11 +200,13 @@ int cd_bn_finalize(const double* stats, int ctot, int coff, int C, double count,
 /* Backward of relu(gamma * x_hat + beta) + train-mode BatchNorm in one call: dA (gradient w.r.t. the
  * activated output) is replaced IN PLACE by the gradient w.r.t. the raw (pre-BN) tensor.  gamma/beta
  * NULL = BatchNorm2d(affine=False); dgamma/dbeta[C] receive the affine gradients when given.
- * sums: scratch of 2*C doubles.  flags bit 0: sums already zeroed by the caller (one memset over an arena of
- * many); bit 1: `xhat` holds the RAW conv output (cd_bn_finalize path) and x_hat is formed on the fly. */
+ * scale/shift (buffer-indexed, from cd_bn_finalize) given: `xhat` holds the RAW conv output and the ReLU mask is
+ * evaluated on exactly fma(raw, scale, shift), the expression the consumers applied on load; NULL: `xhat` is the
+ * normalised tensor of cd_bn_normalize.  sums: scratch of 2*C doubles, zeroed inside unless sums_prezeroed. */
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C,
-                   const float* gamma, const float* beta, const float* mean_invstd, double* sums,
-                   int flags, float* dgamma, float* dbeta, int N, int H, int W, void* stream);
+                   const float* gamma, const float* beta, const float* mean_invstd, const float* scale,
+                   const float* shift, double* sums, int sums_prezeroed, float* dgamma, float* dbeta,
+                   int N, int H, int W, void* stream);
 
 /* AvgPool2d(2) of act(x) and its adjoint (dx = gradient w.r.t. the ACTIVATED input, (+)= when accumulate). */
 int cd_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* in_scale, const float* in_shift,
