@@ -6,9 +6,7 @@ parameter / state_dict container) on the gfx950 kernels behind the C ABI:
     conv (all 157)      cd_conv2d_fwd        fp32 MFMA direct convolution; the producer's ReLU (and the stem's
                                              affine) is applied while loading, the batch statistics of the
                                              raw output are accumulated in the epilogue
-    BatchNorm (train)   cd_bn_finalize       NO pass over the activation: per-channel (scale, shift) from the conv
-                                             epilogue's statistics; the raw conv output stays in memory and every
-                                             consumer applies relu(raw*scale+shift) on load; running stats as PyTorch
+    BatchNorm (train)   cd_bn_normalize      in place -> x_hat (pre-ReLU); running stats updated like PyTorch
     AvgPool2d(2)        cd_avgpool2_fwd
     Upsample x2 + add   cd_upsample2x_add_fwd   (the residual add of every Channels block is fused in)
     backward            cd_bn_relu_bwd, cd_conv2d_wgrad, cd_conv2d_fwd on transposed filters (dgrad),
@@ -67,16 +65,13 @@ class Act:
 
 
 class ConvUnit:
-    def __init__(self, eng, conv_mod, bn_mod, src: Act, dst_buf, dst_coff, stats, mean_invstd, sc=None, sh=None):
+    def __init__(self, eng, conv_mod, bn_mod, src: Act, dst_buf, dst_coff, stats, mean_invstd):
         self.eng, self.conv, self.bn, self.src = eng, conv_mod, bn_mod, src
         self.ks, self.cin, self.cout = conv_mod.kernel_size[0], conv_mod.in_channels, conv_mod.out_channels
-        self.dst_buf, self.dst_coff, self.stats, self.mi, self.sc, self.sh = dst_buf, dst_coff, stats, mean_invstd, sc, sh
-        # the RAW conv output stays in memory; BatchNorm (+ the stem's affine) and ReLU are the per-channel
-        # (scale, shift) every consumer applies while loading
-        has_bn = bn_mod is not None
-        self.out = Act(dst_buf, dst_coff, self.cout, relu=has_bn,
-                       scale=sc[dst_coff:dst_coff + self.cout] if has_bn else None,
-                       shift=sh[dst_coff:dst_coff + self.cout] if has_bn else None, needs_grad=False)
+        self.dst_buf, self.dst_coff, self.stats, self.mi = dst_buf, dst_coff, stats, mean_invstd
+        affine = bn_mod is not None and bn_mod.affine
+        self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None,
+                       scale=bn_mod.weight if affine else None, shift=bn_mod.bias if affine else None, needs_grad=False)
         self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
         self.pk, self.pkT = eng.packed(conv_mod)
 
@@ -86,7 +81,15 @@ class ConvUnit:
                  y_coff=self.dst_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu,
                  stats=self.stats.view(-1) if (self.bn is not None and training) else None)
         if self.bn is not None:
-            _bn_finalize(self.bn, self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, self.sc, self.sh, training)
+            if training:
+                L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS, self.bn.running_mean,
+                               self.bn.running_var, BN_MOMENTUM)
+            else:  # eval: normalise with the running statistics (synthesised sums; nothing is updated)
+                cnt = float(self.dst_buf.shape[0] * self.dst_buf.shape[2] * self.dst_buf.shape[3])
+                rm, rv = self.bn.running_mean.double(), self.bn.running_var.double()
+                self.stats[self.dst_coff:self.dst_coff + self.cout, 0] = rm * cnt
+                self.stats[self.dst_coff:self.dst_coff + self.cout, 1] = (rv + rm * rm) * cnt
+                L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS)
 
     def backward(self, gbuf, g_coff):
         """gbuf[:, g_coff:+cout] holds d loss / d (activated output); on return the parameter grads are
@@ -97,7 +100,7 @@ class ConvUnit:
             L.bn_relu_bwd(gbuf, g_coff, self.dst_buf, self.dst_coff, self.cout, self.mi, self.sums,
                           gamma=self.bn.weight if affine else None, beta=self.bn.bias if affine else None,
                           dgamma=_grad_of(self.bn.weight) if affine else None,
-                          dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True, scale=self.sc, shift=self.sh)
+                          dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True)
         else:
             L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias))
         C.conv2d_wgrad(s.buf, gbuf, self.cin, self.cout, self.ks, _grad_of(self.conv.weight), self.wgrad_ws, x_coff=s.coff,
@@ -119,9 +122,8 @@ class _Member:
 class PointwiseGroup:
     """The four branch-entry 1x1 convolutions of an inception as ONE convolution X -> P[:, 0:ctot]."""
 
-    def __init__(self, eng, members, src: Act, P, Pg, stats, mean_invstd, sc, sh, filt, filtT):
+    def __init__(self, eng, members, src: Act, P, Pg, stats, mean_invstd, filt, filtT):
         self.eng, self.members, self.src, self.P, self.Pg, self.stats, self.mi = eng, members, src, P, Pg, stats, mean_invstd
-        self.sc, self.sh = sc, sh
         self.ctot = sum(m.cout for m in members)
         self.cin = members[0].cin
         self.cout, self.ks = self.ctot, 1          # the group is ONE unit for the arenas (wgrad workspace, BN sums)
@@ -142,12 +144,20 @@ class PointwiseGroup:
         s, pk = self.src, self.eng._pack.view(self._filt)
         C.conv2d(s.buf, pk, self.cin, self.ctot, 1, bias=self._fused_bias(), x_coff=s.coff, out=self.P, y_coff=0,
                  in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, stats=self.stats.view(-1) if training else None)
+        cnt = float(self.P.shape[0] * self.P.shape[2] * self.P.shape[3])
         for m in self.members:
-            _bn_finalize(m.bn, self.P, m.coff, m.cout, self.stats, self.mi, self.sc, self.sh, training)
+            if training:
+                L.bn_normalize(self.P, m.coff, m.cout, self.stats, self.mi, BN_EPS, m.bn.running_mean, m.bn.running_var,
+                               BN_MOMENTUM)
+            else:
+                rm, rv = m.bn.running_mean.double(), m.bn.running_var.double()
+                self.stats[m.coff:m.coff + m.cout, 0] = rm * cnt
+                self.stats[m.coff:m.coff + m.cout, 1] = (rv + rm * rm) * cnt
+                L.bn_normalize(self.P, m.coff, m.cout, self.stats, self.mi, BN_EPS)
 
     def backward(self):
         s = self.src
-        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True, scale=self.sc, shift=self.sh)
+        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True)
         # ONE weight-gradient GEMM for the four filters (X is read once), then split the rows
         C.conv2d_wgrad(s.buf, self.Pg, self.cin, self.ctot, 1, self._dw, self.wgrad_ws, x_coff=s.coff, dy_coff=0,
                        in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
@@ -156,23 +166,6 @@ class PointwiseGroup:
         if s.gbuf is not None:
             C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode())
-
-
-def _bn_finalize(bn, buf, coff, C, stats, mi, sc, sh, training):
-    """Train: batch statistics from the conv epilogue -> (scale, shift), running stats updated like nn.BatchNorm2d.
-    Eval: the running statistics (as synthesised sums), nothing updated.  No pass over the activation."""
-    cnt = float(buf.shape[0] * buf.shape[2] * buf.shape[3])
-    affine = bn.affine
-    if training:
-        L.bn_finalize(stats, coff, C, cnt, mi, sc, sh, BN_EPS, gamma=bn.weight if affine else None,
-                      beta=bn.bias if affine else None, running_mean=bn.running_mean, running_var=bn.running_var,
-                      momentum=BN_MOMENTUM)
-    else:
-        rm, rv = bn.running_mean.double(), bn.running_var.double()
-        stats[coff:coff + C, 0] = rm * cnt
-        stats[coff:coff + C, 1] = (rv + rm * rm) * cnt
-        L.bn_finalize(stats, coff, C, cnt, mi, sc, sh, BN_EPS, gamma=bn.weight if affine else None,
-                      beta=bn.bias if affine else None)
 
 
 def _grad_of(p: torch.nn.Parameter) -> torch.Tensor:
@@ -292,22 +285,21 @@ class HourglassEngine:
         Pg = torch.empty_like(P)
         stats = self._stats(plan, M + Co)
         mi = torch.zeros(M + Co, 2, device=self.device)
-        sc, sh = torch.ones(M + Co, device=self.device), torch.zeros(M + Co, device=self.device)
         members, moff = [], 0
         for i, br in enumerate(list(mod.convs)[1:]):
             members.append(_Member(br[0], br[1], moff))
             moff += mids[i]
         members.append(_Member(mod.convs[0][0], mod.convs[0][1], M))
         filt, filtT = self._group_filters[id(mod)]
-        group = PointwiseGroup(self, members, x, P, Pg, stats, mi, sc, sh, filt, filtT)
+        group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT)
         units, ooff, moff = [], M + a0, 0
         for i, br in enumerate(list(mod.convs)[1:]):
-            mid = Act(P, moff, mids[i], relu=True, scale=sc[moff:moff + mids[i]], shift=sh[moff:moff + mids[i]], needs_grad=False)
+            mid = Act(P, moff, mids[i], relu=True, needs_grad=False)
             mid.gbuf = Pg
-            units.append((ConvUnit(self, br[3], br[4], mid, P, ooff, stats, mi, sc, sh), Pg, ooff))
+            units.append((ConvUnit(self, br[3], br[4], mid, P, ooff, stats, mi), Pg, ooff))
             ooff += outs[i + 1]
             moff += mids[i]
-        out = Act(P, M, Co, relu=True, scale=sc[M:M + Co], shift=sh[M:M + Co], needs_grad=False)
+        out = Act(P, M, Co, relu=True, needs_grad=False)
         out.gbuf = Pg
         steps.append(_Node("inception", group=group, units=units, out=out, src=x))
         plan["convs"] += [group] + [u for u, _, _ in units]
@@ -358,8 +350,7 @@ class HourglassEngine:
         plan["x"] = self._new(N, 3, H, W)
         x_in = Act(plan["x"], 0, 3, needs_grad=False)
         stem_buf = self._new(N, 128, H, W)
-        stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, self._stats(plan, 128), torch.zeros(128, 2, device=self.device),
-                        torch.ones(128, device=self.device), torch.zeros(128, device=self.device))
+        stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, self._stats(plan, 128), torch.zeros(128, 2, device=self.device))
         stem.out.gbuf = torch.empty_like(stem_buf)
         plan["steps"].append(_Node("conv", unit=stem, gbuf=stem.out.gbuf, g_coff=0))
         plan["convs"].append(stem)

@@ -63,6 +63,20 @@ def test_bn_normalize_and_backward_match_torch():
         if affine:
             kw = dict(gamma=gamma.float().cuda(), beta=beta.float().cuda(), dgamma=torch.zeros(C).cuda(), dbeta=torch.zeros(C).cuda())
         layers.bn_relu_bwd(d, coff, buf, coff, C, mi, sums, **kw)
+        # the pass-free variant: (scale, shift) from the statistics, raw tensor + apply-on-load semantics
+        raw_buf = torch.zeros(N, ctot, H, W).cuda()
+        raw_buf[:, coff:coff + C] = raw.float().cuda()
+        mi2, sc, sh = torch.zeros(ctot, 2).cuda(), torch.ones(ctot).cuda(), torch.zeros(ctot).cuda()
+        layers.bn_finalize(stats, coff, C, N * H * W, mi2, sc, sh, gamma=kw.get("gamma"), beta=kw.get("beta"))
+        act = torch.relu(raw_buf[:, coff:coff + C] * sc[coff:coff + C].view(1, -1, 1, 1) + sh[coff:coff + C].view(1, -1, 1, 1))
+        assert (act.cpu().double() - a.detach()).abs().max().item() < 3e-5
+        d2 = torch.zeros(N, ctot, H, W).cuda()
+        d2[:, coff:coff + C] = dA.float().cuda()
+        kw2 = dict(kw)
+        if affine:
+            kw2.update(dgamma=torch.zeros(C).cuda(), dbeta=torch.zeros(C).cuda())
+        layers.bn_relu_bwd(d2, coff, raw_buf, coff, C, mi2, torch.zeros(2 * C, dtype=torch.float64).cuda(), scale=sc, shift=sh, **kw2)
+        assert (d2[:, coff:coff + C].cpu().double() - x.grad).abs().max().item() < 3e-5 * x.grad.abs().max().item()
         assert (d[:, coff:coff + C].cpu().double() - x.grad).abs().max().item() < 3e-5 * x.grad.abs().max().item()
         if affine:
             np.testing.assert_allclose(kw["dgamma"].cpu().numpy(), bn.weight.grad.numpy(), rtol=2e-5, atol=1e-4)
