@@ -141,8 +141,8 @@ def main():
     rank, local_rank, world = parallel.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = parallel.local_device(local_rank)
+    torch.cuda.set_device(device)
     lib = _native.lib()
     B, H, W = args.batch_size, args.height, args.width
 

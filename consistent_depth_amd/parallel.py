@@ -34,13 +34,20 @@ def init(backend: str = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # CD_AMD_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses duplicate devices): used by the
+        # single-GPU test of the multi-rank path; production is "nccl" (= RCCL on ROCm), one GPU per rank
+        backend = backend or os.environ.get("CD_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
     return rank, local_rank, world
+
+
+def local_device(local_rank: int) -> torch.device:
+    """cuda:<local_rank>, wrapped onto the visible devices (several ranks may share a GPU in tests)."""
+    return torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
 
 
 def world_size() -> int:
