@@ -4,7 +4,9 @@
 //   [tile_window_kernel]   only with gradients and when the caller passes no cached tile windows
 //   prep_kernel            per-(pair, direction) camera constants + gradient scales (128 B each)
 //   forward only :  loss_main_kernel<GRAD=false>          (v1, pure streaming, no atomics)
-//   with gradient:  loss_owner_kernel (v2, no global atomics) -> overflow_apply_kernel
+//   with gradient:  loss_source_kernel + loss_gather_kernel (v3: evaluate once, reduce slabs; no global atomics)
+//                   [or loss_owner_kernel (v2) when selected with cd_debug_set_loss_variant(2)]
+//                   -> overflow_apply_kernel
 //                   -> zero_guarded + loss_main_kernel<GRAD=true> (idle unless the overflow list overflowed)
 //   finalize_pairs / finalize_total   fixed-order fp64 reduction -> reproj[B], disp[B], total[1]
 #include "loss_common.h"
@@ -144,6 +146,7 @@ struct Workspace {
     void* wins;        // tile windows     (when the caller passes none)
     void* ovf;         // 256 B header + idx[cap] + val[cap]
     int ovf_cap;
+    float* slabs;      // v3: [B*2][ntiles][64*64] floats (only each tile's window is touched)
 };
 
 static inline int ovf_capacity(int B, int HW) {
@@ -165,15 +168,18 @@ static inline size_t ws_layout(int B, int H, int W, void* base, Workspace* w) {
     const size_t o_wins = take(owner_windows_bytes(B, H, W));
     const int cap = ovf_capacity(B, HW);
     const size_t o_ovf = take(256 + (size_t)cap * 8);
+    const size_t o_slab = take(sizeof(float) * slab_floats(B, H, W));
     if (w) {
         char* p = (char*)base;
         w->cams = (PairCam*)(p + o_cams); w->mask_sum = (float*)(p + o_msum); w->partial = (float*)(p + o_part);
         w->partial_fb = (float*)(p + o_pfb); w->wins = p + o_wins; w->ovf = p + o_ovf; w->ovf_cap = cap;
+        w->slabs = (float*)(p + o_slab);
     }
     return off;
 }
 
 static int g_force_overflow_cap = -1;  // test hook: shrink the overflow list (cd_debug_set_overflow_capacity)
+static int g_loss_variant = 3;         // 3 = evaluate-once + slab reduce (default), 2 = owner-computes
 
 static int run_loss(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb,
                     const float* mask_sum, const void* tile_windows, const float* intr, const float* extr,
@@ -215,8 +221,12 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         }
         g_prof.pending_batch = B;
         const int cap = (g_force_overflow_cap >= 0 && g_force_overflow_cap < w.ovf_cap) ? g_force_overflow_cap : w.ovf_cap;
-        rc = launch_owner(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf,
-                          cap, s, prof_before, prof_after);
+        if (g_loss_variant == 2)
+            rc = launch_owner(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf,
+                              cap, s, prof_before, prof_after);
+        else
+            rc = launch_slab(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.slabs,
+                             w.ovf, cap, s, prof_before, prof_after);
         if (rc != CD_OK) return rc;
         // device-side fallback: idle unless the overflow list overflowed (then it recomputes the gradient)
         const int* flag = owner_fallback_flag(w.ovf);
@@ -268,6 +278,12 @@ int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out) {
     for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
     delete[] g_prof.start; delete[] g_prof.stop; delete[] g_prof.batch;
     g_prof = cd::Profiler();
+    return CD_OK;
+}
+
+int cd_debug_set_loss_variant(int v) {
+    if (v != 2 && v != 3) return CD_ERR_INVALID_ARG;
+    cd::g_loss_variant = v;
     return CD_OK;
 }
 

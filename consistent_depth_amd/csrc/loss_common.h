@@ -77,5 +77,13 @@ int launch_owner(const float* depth, const float* ff, const float* fb, const flo
                  float* grad, void* ovf_mem, int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t),
                  void (*after_main)(hipStream_t));
 const int* owner_fallback_flag(void* ovf_mem);
+int launch_overflow_apply(void* ovf_mem, int ovf_cap, float* grad, hipStream_t s);
+
+// ---- v3 (loss_slab.hip): source pass + gather pass; slabs = slab_floats(B,H,W) floats of scratch
+size_t slab_floats(int B, int H, int W);
+int launch_slab(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb,
+                const void* cams, const void* wins, int mode, bool reproj, int B, int H, int W, float* partial,
+                float* grad, float* slabs, void* ovf_mem, int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t),
+                void (*after_main)(hipStream_t));
 
 }  // namespace cd

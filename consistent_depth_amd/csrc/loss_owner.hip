@@ -31,25 +31,11 @@
 //
 // Sampling positions are computed by ONE inline function with explicit fma/add intrinsics so the
 // "will the owner see me" test and the owner's own scan agree bit for bit.
-#include "loss_common.h"
+#include "loss_tiles.h"
 
 namespace cd {
 
-constexpr int TW = 32, TH = 32;            // owned tile
-constexpr int WMAXW = 64, WMAXH = 64;      // cap of the staged window of the other frame
-constexpr int EXPAND = 2;                  // px slack around the predicted source window (beyond it: overflow list)
-constexpr int MAXT_LDS = 512;              // window table of one plane kept in LDS up to this many tiles
-constexpr int SBW = TW + 2, SBH = TH + 2;  // own tile + 1 px halo
-
-struct TileWin { short x0, y0, w, h; };    // window in the OTHER frame's pixel grid (w*h may be 0)
-
-struct Overflow {          // global overflow list (workspace)
-    int count;             // number of pushes attempted
-    int cap;               // capacity of idx/val
-    int fallback;          // set by overflow_apply when count > cap
-    int pad;
-};
-
+// ---------------------------------------------------------------- the owner kernel
 __device__ __forceinline__ int imin_wave(int v) {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, kWave));
@@ -63,7 +49,7 @@ __device__ __forceinline__ int imax_wave(int v) {
 
 // ---------------------------------------------------------------- per-tile source windows
 // wins[(b*2 + j)*ntiles + tile] = where the VALID pixels of tile T of frame j sample frame k = 1-j
-// (tap bounding box + EXPAND, clamped to the image, centre-cropped to WMAXW x WMAXH).
+// (tight tap bounding box, centre-cropped to WMAXW x WMAXH; v2 widens it on the fly with expand_win).
 // Depends only on flows and masks, i.e. on the dataset: callers cache it per pair.
 __global__ __launch_bounds__(kBlock) void tile_window_kernel(const float* __restrict__ flow_fwd,
                                                              const float* __restrict__ flow_bwd,
@@ -102,50 +88,12 @@ __global__ __launch_bounds__(kBlock) void tile_window_kernel(const float* __rest
         TileWin w;
         if (x1 < 0) { w.x0 = 0; w.y0 = 0; w.w = 0; w.h = 0; }
         else {
-            x0 = max(x0 - EXPAND, 0); y0 = max(y0 - EXPAND, 0);
-            x1 = min(x1 + EXPAND, W - 1); y1 = min(y1 + EXPAND, H - 1);
             int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
             if (ww > WMAXW) { x0 += (ww - WMAXW) / 2; ww = WMAXW; }
             if (wh > WMAXH) { y0 += (wh - WMAXH) / 2; wh = WMAXH; }
             w.x0 = (short)x0; w.y0 = (short)y0; w.w = (short)ww; w.h = (short)wh;
         }
         wins[(size_t)(b * 2 + j) * ntiles + tile] = w;
-    }
-}
-
-// ---------------------------------------------------------------- fixed-point scatter accumulator
-constexpr double FX_ONE = 1099511627776.0;           // 2^40
-constexpr double FX_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: adding it rounds to an integer in the low mantissa bits
-constexpr float FX_LIMIT = 2047.f;                   // saturation (|x| * 2^40 must stay below 2^51)
-
-__device__ __forceinline__ unsigned long long to_fixed(float c) {
-    c = fminf(fmaxf(c, -FX_LIMIT), FX_LIMIT);
-    const double d = __fma_rn((double)c, FX_ONE, FX_MAGIC);
-    return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(FX_MAGIC));
-}
-__device__ __forceinline__ float from_fixed(unsigned long long v) {
-    return (float)((double)(long long)v * (1.0 / FX_ONE));
-}
-
-// ---------------------------------------------------------------- the owner kernel
-__device__ __forceinline__ bool in_win(const TileWin& w, int x, int y) {
-    return (unsigned)(x - w.x0) < (unsigned)w.w && (unsigned)(y - w.y0) < (unsigned)w.h;
-}
-
-// Wave-aggregated append to the overflow list: ONE returning atomic per wave per call (a same-address
-// returning atomic costs ~11 ns on this chip, so per-lane pushes would serialise).  Must be called by all
-// lanes of the wave (convergent); `need` selects the lanes that append.
-__device__ __forceinline__ void ovf_push(bool need, Overflow* ovf, unsigned* oidx, float* oval, unsigned idx, float v) {
-    const unsigned long long mask = __ballot(need);
-    if (mask == 0ull) return;  // wave-uniform
-    const int lane = threadIdx.x & (kWave - 1);
-    const int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&ovf->count, (int)__popcll(mask));
-    base = __shfl(base, leader, kWave);
-    if (need) {
-        const int i = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
-        if (i < ovf->cap) { oidx[i] = idx; oval[i] = v; }
     }
 }
 
@@ -167,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
     const int X0 = txi * TW, Y0 = tyi * TH;
     const PairCam& cj = cams[b * 2 + j];  // direction j: ref = frame j, tgt = frame k
     const PairCam& ck = cams[b * 2 + k];  // direction k: ref = frame k, tgt = frame j
-    const TileWin win = wins[(size_t)(b * 2 + j) * ntiles + tile];
+    const TileWin win = expand_win(wins[(size_t)(b * 2 + j) * ntiles + tile], EXPAND_V2, W, H);
     const TileWin* __restrict__ wins_k = wins + (size_t)(b * 2 + k) * ntiles;
     const float* __restrict__ v_j = depth + (size_t)(b * 2 + j) * HW;
     const float* __restrict__ v_k = depth + (size_t)(b * 2 + k) * HW;
@@ -192,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
     }
     for (int i = threadIdx.x; i < TH * TW; i += kBlock) sG[i] = 0ull;
     if (table_in_lds)
-        for (int i = threadIdx.x; i < ntiles; i += kBlock) sWin[i] = wins_k[i];
+        for (int i = threadIdx.x; i < ntiles; i += kBlock) sWin[i] = expand_win(wins_k[i], EXPAND_V2, W, H);
     __syncthreads();
 
     // ---------------- phase 1: direction j over the pixels of T
@@ -259,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
         // will the owners of the taps' tiles (plane (b,k)) see this source?  All four taps in one tile (the
         // common case) = one table lookup; anything else goes through the (wave-uniform) slow path.
         const int ta = (t.ya / TH) * tiles_x + t.xa / TW, tb = (t.yb / TH) * tiles_x + t.xb / TW;
-        const bool seen = ta == tb && in_win(table_in_lds ? sWin[ta] : wins_k[ta], x, y);
+        const bool seen = ta == tb && in_win(table_in_lds ? sWin[ta] : expand_win(wins_k[ta], EXPAND_V2, W, H), x, y);
         const bool check = m != 0.f && !seen;
         if (__any(check)) {
             const int xs[4] = {t.xa, t.xb, t.xa, t.xb}, ys[4] = {t.ya, t.ya, t.yb, t.yb};
@@ -268,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
             for (int q = 0; q < 4; ++q) {
                 const int tq = (ys[q] / TH) * tiles_x + xs[q] / TW;
                 const float cv = -gz * ws[q] * depth_jac<MODE>(ds[q]);
-                const bool need = check && cv != 0.f && !in_win(table_in_lds ? sWin[tq] : wins_k[tq], x, y);
+                const bool need = check && cv != 0.f && !in_win(table_in_lds ? sWin[tq] : expand_win(wins_k[tq], EXPAND_V2, W, H), x, y);
                 ovf_push(need, ovf, oidx, oval, base_k + (unsigned)(ys[q] * W + xs[q]), cv);
             }
         }
@@ -391,5 +339,13 @@ int launch_owner(const float* depth, const float* ff, const float* fb, const flo
 }
 
 const int* owner_fallback_flag(void* ovf_mem) { return &((Overflow*)ovf_mem)->fallback; }
+
+int launch_overflow_apply(void* ovf_mem, int ovf_cap, float* grad, hipStream_t s) {
+    Overflow* ovf = (Overflow*)ovf_mem;
+    unsigned* oidx = (unsigned*)((char*)ovf_mem + 256);
+    float* oval = (float*)(oidx + ovf_cap);
+    hipLaunchKernelGGL(overflow_apply_kernel, dim3(64), dim3(kBlock), 0, s, ovf, oidx, oval, grad);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
 
 }  // namespace cd

@@ -1,0 +1,233 @@
+// Fused geometric-consistency loss, v3: "evaluate once, reduce slabs" -- the training path.
+//
+// Same math as loss_owner.hip (v2) and loss_fused.hip (v1); different decomposition of the scatter part
+// of d loss / d depth (the 4 bilinear taps of the OTHER frame's depth per source pixel):
+//
+//   pass A  loss_source_kernel   one workgroup = one 32x32 tile of SOURCE pixels of plane (b, j):
+//             stage the tap window of frame k = 1-j (tight bounding box of where the tile's valid pixels
+//             sample frame k, <= 64x64) in LDS; evaluate every source ONCE (loss partial sums, direct
+//             gradient -> plain store); accumulate its 4 tap contributions into an LDS accumulator laid out
+//             like the window (64-bit fixed point, ds_add_u64: integer LDS atomics are full rate on gfx950,
+//             float ones are ~37x slower, and integer sums are order-independent); write the accumulator
+//             out as a float SLAB (plain coalesced stores).
+//   pass B  loss_gather_kernel   one workgroup = one 32x32 tile of TARGET pixels of plane (b, k): add the
+//             overlapping part of every slab of plane j to the direct gradient (fixed order: bit-reproducible),
+//             one plain read-modify-write of the tile.
+//
+// No global atomics, no zero-initialised gradient, every source evaluated exactly once (v2 evaluates ~2.07x),
+// and exactness does not depend on forward/backward flow consistency: a tap is outside its tile's window only
+// when the window hit the 64x64 cap (wild flow) or the pixel is masked out (no contribution); those few go
+// through the same overflow list / guarded v1 fallback as in v2.
+#include "loss_tiles.h"
+
+namespace cd {
+
+constexpr int SLAB_STRIDE = WMAXW * WMAXH;  // floats reserved per (plane, tile) slab; only w*h are touched
+
+template <int MODE, bool REPROJ>
+__global__ __launch_bounds__(kBlock) void loss_source_kernel(
+    const float* __restrict__ depth, const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd,
+    const float* __restrict__ mask_fwd, const float* __restrict__ mask_bwd, const PairCam* __restrict__ cams,
+    const TileWin* __restrict__ wins, int H, int W, int tiles_x, int ntiles, float* __restrict__ partial,
+    float* __restrict__ grad, float* __restrict__ slabs, Overflow* ovf, unsigned* __restrict__ oidx,
+    float* __restrict__ oval) {
+    __shared__ float sA[WMAXH * WMAXW];                 // depth of frame k over the window
+    __shared__ unsigned long long sW[WMAXH * WMAXW];    // scatter accumulator over the same window (2^-40 fixed point)
+    __shared__ float red[kBlock / kWave];
+
+    const int j = blockIdx.y, b = blockIdx.z, tile = blockIdx.x, k = 1 - j;
+    const int HW = H * W;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int X0 = txi * TW, Y0 = tyi * TH;
+    const PairCam& cj = cams[b * 2 + j];
+    const TileWin win = wins[(size_t)(b * 2 + j) * ntiles + tile];
+    const float* __restrict__ v_j = depth + (size_t)(b * 2 + j) * HW;
+    const float* __restrict__ v_k = depth + (size_t)(b * 2 + k) * HW;
+    const float* __restrict__ fl_j = (j == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
+    const float* __restrict__ mk_j = (j == 0 ? mask_fwd : mask_bwd) + (size_t)b * HW;
+    float* __restrict__ g_j = grad + (size_t)(b * 2 + j) * HW;
+    const unsigned base_k = (unsigned)(b * 2 + k) * (unsigned)HW;
+
+    // ---- stage the window, clear the accumulator
+    const int wn = (int)win.w * (int)win.h;
+    const float inv_ww = win.w > 0 ? 1.f / (float)win.w : 0.f;
+    for (int i = threadIdx.x; i < wn; i += kBlock) {
+        const int r = (int)(((float)i + 0.5f) * inv_ww), c = i - r * win.w;
+        sA[r * WMAXW + c] = to_depth<MODE>(v_k[(win.y0 + r) * W + win.x0 + c]);
+        sW[r * WMAXW + c] = 0ull;
+    }
+    __syncthreads();
+
+    // ---- evaluate every source pixel of the tile once
+    constexpr int ROWS_PER_IT = kBlock / TW, ITERS = TH / ROWS_PER_IT;
+    const int lx = threadIdx.x & (TW - 1), ly0 = threadIdx.x / TW;
+    float acc_r = 0.f, acc_d = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int ly = ly0 + it * ROWS_PER_IT;
+        const int x = X0 + lx, y = Y0 + ly;
+        const bool valid = x < W && y < H;
+        const int p = valid ? y * W + x : 0;
+        const float d = to_depth<MODE>(v_j[p]);
+        const float m = valid ? mk_j[p] : 0.f;
+        const float fx = fl_j[p], fy = fl_j[HW + p];
+        const float xf = (float)x, yf = (float)y;
+        const float r0 = (xf - cj.cx_r) * cj.ifx_r, r1 = -(yf - cj.cy_r) * cj.ify_r;
+        const float a0 = cj.M[0] * r0 + cj.M[1] * r1 - cj.M[2];
+        const float a1 = cj.M[3] * r0 + cj.M[4] * r1 - cj.M[5];
+        const float a2 = cj.M[6] * r0 + cj.M[7] * r1 - cj.M[8];
+        const float X = d * a0 + cj.c[0], Y = d * a1 + cj.c[1], Z = d * a2 + cj.c[2];
+        const float iZ = __builtin_amdgcn_rcpf(Z);
+        float g = 0.f;
+        if (REPROJ) {
+            const float mx = xf + fx, my = yf + fy;
+            const float ex = (cj.cx_t - cj.fx_t * X * iZ) - mx, ey = (cj.cy_t + cj.fy_t * Y * iZ) - my;
+            const float e2 = ex * ex + ey * ey;
+            const float ie = e2 > 0.f ? __builtin_amdgcn_rsqf(e2) : 0.f;  // subgradient 0 at e = 0
+            acc_r += valid ? m * (e2 * ie) : 0.f;   // multiply, not select: 0*inf = NaN exactly like the reference
+            const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
+            g += cj.gr * m * (ex * dpx + ey * dpy) * ie;
+        }
+        const Taps t = tap_coords(xf, yf, fx, fy, cj.sx, cj.sy, W, H);
+        const int ra = t.ya - win.y0, ca = t.xa - win.x0, dyb = t.yb - t.ya, dxb = t.xb - t.xa;
+        const bool inside = (unsigned)ra < (unsigned)max(win.h - dyb, 0) && (unsigned)ca < (unsigned)max(win.w - dxb, 0);
+        const int i00 = inside ? ra * WMAXW + ca : 0;
+        float d00, d01, d10, d11;
+        const bool fast = __all(inside || !valid);   // the whole wave's taps are inside the window: the common case
+        if (fast) {
+            d00 = sA[i00]; d01 = sA[i00 + dxb]; d10 = sA[i00 + dyb * WMAXW]; d11 = sA[i00 + dyb * WMAXW + dxb];
+        } else {
+            const int rb = ra + dyb, cb = ca + dxb;
+            const bool ina = (unsigned)ra < (unsigned)win.h, inb = (unsigned)rb < (unsigned)win.h;
+            const bool inca = (unsigned)ca < (unsigned)win.w, incb = (unsigned)cb < (unsigned)win.w;
+            d00 = (ina && inca) ? sA[ra * WMAXW + ca] : to_depth<MODE>(v_k[t.ya * W + t.xa]);
+            d01 = (ina && incb) ? sA[ra * WMAXW + cb] : to_depth<MODE>(v_k[t.ya * W + t.xb]);
+            d10 = (inb && inca) ? sA[rb * WMAXW + ca] : to_depth<MODE>(v_k[t.yb * W + t.xa]);
+            d11 = (inb && incb) ? sA[rb * WMAXW + cb] : to_depth<MODE>(v_k[t.yb * W + t.xb]);
+        }
+        const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
+        const float izs = __builtin_amdgcn_rcpf(zs);
+        const float dd = iZ - izs;
+        acc_d += valid ? m * fabsf(dd) : 0.f;
+        const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+        const float gm = cj.gb * m * sg;
+        g -= gm * a2 * iZ * iZ;
+        const float gz = gm * izs * izs;
+        if (valid) g_j[p] = g * depth_jac<MODE>(d);   // direct term; pass B adds the scatter term
+        // scatter term of the 4 taps of frame k: LDS window accumulator (or the overflow list outside the window)
+        const float c00 = -gz * t.w00 * depth_jac<MODE>(d00), c01 = -gz * t.w01 * depth_jac<MODE>(d01);
+        const float c10 = -gz * t.w10 * depth_jac<MODE>(d10), c11 = -gz * t.w11 * depth_jac<MODE>(d11);
+        if (fast) {
+            if (m != 0.f) {   // valid lanes only have m != 0
+                atomicAdd(&sW[i00], to_fixed(c00));
+                atomicAdd(&sW[i00 + dxb], to_fixed(c01));
+                atomicAdd(&sW[i00 + dyb * WMAXW], to_fixed(c10));
+                atomicAdd(&sW[i00 + dyb * WMAXW + dxb], to_fixed(c11));
+            }
+        } else {
+            const int xs[4] = {t.xa, t.xb, t.xa, t.xb}, ys[4] = {t.ya, t.ya, t.yb, t.yb};
+            const float cs[4] = {c00, c01, c10, c11};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rq = ys[q] - win.y0, cq = xs[q] - win.x0;
+                const bool inq = (unsigned)rq < (unsigned)win.h && (unsigned)cq < (unsigned)win.w;
+                const bool live = m != 0.f && cs[q] != 0.f;
+                if (live && inq) atomicAdd(&sW[rq * WMAXW + cq], to_fixed(cs[q]));
+                ovf_push(live && !inq, ovf, oidx, oval, base_k + (unsigned)(ys[q] * W + xs[q]), cs[q]);   // convergent
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the window accumulator leaves as a float slab (compact rows of win.w)
+    float* __restrict__ slab = slabs + ((size_t)(b * 2 + j) * ntiles + tile) * SLAB_STRIDE;
+    for (int i = threadIdx.x; i < wn; i += kBlock) {
+        const int r = (int)(((float)i + 0.5f) * inv_ww), c = i - r * win.w;
+        slab[i] = from_fixed(sW[r * WMAXW + c]);
+    }
+    acc_r = block_sum(acc_r, red);
+    acc_d = block_sum(acc_d, red);
+    if (threadIdx.x == 0) {
+        float* o = partial + ((size_t)(b * 2 + j) * ntiles + tile) * 2;
+        o[0] = acc_r;
+        o[1] = acc_d;
+    }
+}
+
+// pass B: grad[b, k, T] += sum over the source tiles s of plane j of slab_s restricted to T
+__global__ __launch_bounds__(kBlock) void loss_gather_kernel(const TileWin* __restrict__ wins,
+                                                             const float* __restrict__ slabs, int H, int W,
+                                                             int tiles_x, int ntiles, float* __restrict__ grad) {
+    __shared__ float sAcc[TH * TW];
+    const int k = blockIdx.y, b = blockIdx.z, tile = blockIdx.x, j = 1 - k;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int X0 = txi * TW, Y0 = tyi * TH, X1 = min(X0 + TW, W), Y1 = min(Y0 + TH, H);
+    for (int i = threadIdx.x; i < TH * TW; i += kBlock) sAcc[i] = 0.f;
+    const TileWin* __restrict__ wj = wins + (size_t)(b * 2 + j) * ntiles;
+    const float* __restrict__ sl = slabs + (size_t)(b * 2 + j) * ntiles * SLAB_STRIDE;
+    __syncthreads();
+    for (int s = 0; s < ntiles; ++s) {
+        const TileWin w = wj[s];   // block-uniform (scalar) loads and tests
+        const int x0 = max((int)w.x0, X0), y0 = max((int)w.y0, Y0);
+        const int x1 = min((int)w.x0 + w.w, X1), y1 = min((int)w.y0 + w.h, Y1);
+        const int rw = x1 - x0, rh = y1 - y0;
+        if (rw <= 0 || rh <= 0) continue;
+        const float* __restrict__ src = sl + (size_t)s * SLAB_STRIDE;
+        const float inv = 1.f / (float)rw;
+        for (int i = threadIdx.x; i < rw * rh; i += kBlock) {
+            const int r = (int)(((float)i + 0.5f) * inv), c = i - r * rw;
+            const int y = y0 + r, x = x0 + c;
+            sAcc[(y - Y0) * TW + (x - X0)] += src[(y - w.y0) * w.w + (x - w.x0)];   // distinct elements within one slab
+        }
+        __syncthreads();   // the next slab may touch the same elements from other threads
+    }
+    float* __restrict__ g = grad + (size_t)(b * 2 + k) * H * W;
+    for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
+        const int ly = i / TW, lx = i - ly * TW, y = Y0 + ly, x = X0 + lx;
+        if (x < W && y < H) g[y * W + x] += sAcc[i];
+    }
+}
+
+// ---------------------------------------------------------------- host side
+size_t slab_floats(int B, int H, int W) { return (size_t)B * 2 * owner_ntiles(H, W) * SLAB_STRIDE; }
+
+template <int MODE>
+static void launch_source_mode(bool reproj, dim3 grid, hipStream_t s, const float* depth, const float* ff,
+                               const float* fb, const float* mf, const float* mb, const PairCam* cams,
+                               const TileWin* wins, int H, int W, int tx, int nt, float* partial, float* grad,
+                               float* slabs, Overflow* ovf, unsigned* oidx, float* oval) {
+    if (reproj)
+        hipLaunchKernelGGL((loss_source_kernel<MODE, true>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins, H, W,
+                           tx, nt, partial, grad, slabs, ovf, oidx, oval);
+    else
+        hipLaunchKernelGGL((loss_source_kernel<MODE, false>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins, H, W,
+                           tx, nt, partial, grad, slabs, ovf, oidx, oval);
+}
+
+// Enqueues: overflow header reset, [before_main] source pass, gather pass [after_main], overflow apply.
+int launch_slab(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb,
+                const void* cams, const void* wins, int mode, bool reproj, int B, int H, int W, float* partial,
+                float* grad, float* slabs, void* ovf_mem, int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t),
+                void (*after_main)(hipStream_t)) {
+    const int tx = owner_tiles_x(W), nt = owner_ntiles(H, W);
+    Overflow* ovf = (Overflow*)ovf_mem;
+    unsigned* oidx = (unsigned*)((char*)ovf_mem + 256);
+    float* oval = (float*)(oidx + ovf_cap);
+    if (hipMemsetAsync(ovf, 0, sizeof(Overflow), s) != hipSuccess) return CD_ERR_LAUNCH;
+    if (hipMemsetD32Async((hipDeviceptr_t)&ovf->cap, ovf_cap, 1, s) != hipSuccess) return CD_ERR_LAUNCH;
+    const dim3 grid(nt, 2, B);
+    if (before_main) before_main(s);
+    if (mode == CD_DEPTH_EXP)
+        launch_source_mode<CD_DEPTH_EXP>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval);
+    else if (mode == CD_DEPTH_RECIPROCAL)
+        launch_source_mode<CD_DEPTH_RECIPROCAL>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval);
+    else
+        launch_source_mode<CD_DEPTH_IDENTITY>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval);
+    hipLaunchKernelGGL(loss_gather_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, grad);
+    if (after_main) after_main(s);
+    if (hipGetLastError() != hipSuccess) return CD_ERR_LAUNCH;
+    launch_overflow_apply(ovf_mem, ovf_cap, grad, s);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+}  // namespace cd

@@ -121,6 +121,8 @@ int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out);
 /* Test hook: cap the gradient kernel's overflow list at `cap` records (< 0 restores the default), to
  * force the overflow-apply and the device-side fallback paths in tests. */
 int cd_debug_set_overflow_capacity(int cap);
+/* Test / A-B hook: gradient-kernel formulation, 3 = evaluate once + slab reduce (default), 2 = owner-computes. */
+int cd_debug_set_loss_variant(int variant);
 
 /* utils/geometry.py:201-208 `sample`: bilinear, border padding, align_corners=False on an
  * align_corners=True style normalisation.  data [B,C,H,W], uv [B,2,H,W] px -> out [B,C,H,W]. */

@@ -38,8 +38,18 @@ def _run(torch, batch, lr, lb, mode=0, mask_sums=None):
     return total.item(), reproj.cpu().numpy(), disp.cpu().numpy(), g
 
 
+@pytest.fixture(params=[3, 2], ids=["slab", "owner"])
+def variant(request):
+    """Both formulations of the gradient kernel (v3 evaluate-once + slab reduce = default, v2 owner-computes)."""
+    from consistent_depth_amd import _native
+    lib = _native.lib()
+    assert lib.cd_debug_set_loss_variant(request.param) == 0
+    yield request.param
+    lib.cd_debug_set_loss_variant(3)
+
+
 @pytest.mark.parametrize("name", golden_loss_cases())
-def test_golden_vectors(torch_cuda, oracle, name):
+def test_golden_vectors(torch_cuda, oracle, name, variant):
     batch, lr, lb, ref64, _ = load_loss_case(name)
     total, reproj, disp, grad = _run(torch_cuda, batch, lr, lb)
     np.testing.assert_allclose(total, ref64["total"][0], rtol=LOSS_RTOL)
@@ -52,7 +62,7 @@ def test_golden_vectors(torch_cuda, oracle, name):
 
 @pytest.mark.parametrize("gen", ["scene", "unrelated"])
 @pytest.mark.parametrize("H,W", [(384, 224), (224, 384)])
-def test_baseline_size_vs_oracle(torch_cuda, oracle, H, W, gen):
+def test_baseline_size_vs_oracle(torch_cuda, oracle, H, W, gen, variant):
     """BASELINE size (B=4, 384x224 and its transpose) on consistent-scene data (what real video looks
     like: the owner kernel's windows see every source) and on the adversarial generator (unrelated
     depth per frame: a few % of the scatter goes through the overflow list)."""
@@ -68,7 +78,7 @@ def test_baseline_size_vs_oracle(torch_cuda, oracle, H, W, gen):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-def test_fused_depth_heads(torch_cuda, oracle, mode):
+def test_fused_depth_heads(torch_cuda, oracle, mode, variant):
     """depth = exp(x) (mc) / 1/x (midas) fused into the kernel, gradient w.r.t. x."""
     from consistent_depth_amd import synthetic
     batch = synthetic.make_pair_batch(2, 64, 96, seed=5)
@@ -106,7 +116,7 @@ def test_forward_only_and_cached_mask_sums(torch_cuda):
 
 @pytest.mark.parametrize("cap", [0, 7, 1000])
 @pytest.mark.parametrize("name", ["stress_b2_32x48", "basic_b3_48x40"])
-def test_overflow_list_and_device_fallback(torch_cuda, oracle, name, cap):
+def test_overflow_list_and_device_fallback(torch_cuda, oracle, name, cap, variant):
     """The owner-computes kernel is exact for ANY flow: sources outside the predicted windows go
     through the overflow list (cap large), and when the list itself overflows (cap tiny) the
     device-side fallback recomputes the gradient.  Forced here with the debug capacity hook."""
@@ -123,7 +133,7 @@ def test_overflow_list_and_device_fallback(torch_cuda, oracle, name, cap):
     assert oracle.rel_l1(grad, ref64["grad_depth"]) < tol
 
 
-def test_wild_flow_full_size_vs_oracle(torch_cuda, oracle):
+def test_wild_flow_full_size_vs_oracle(torch_cuda, oracle, variant):
     """Flows with +-40 px noise and strong in-tile variation: windows get capped, most scatter goes
     through the overflow list (or the fallback) -- still the reference's numbers."""
     from consistent_depth_amd import synthetic
