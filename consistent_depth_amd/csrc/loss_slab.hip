@@ -22,7 +22,16 @@
 
 namespace cd {
 
-constexpr int SLAB_STRIDE = WMAXW * WMAXH;  // floats reserved per (plane, tile) slab; only w*h are touched
+// v3 keeps TWO window-shaped arrays in LDS (depth + 64-bit accumulator), so its window cap is smaller than the
+// table's (64x64): table windows are centre-cropped to 48x48 on the fly, identically in both passes.
+constexpr int V3W = 48;
+constexpr int SLAB_STRIDE = V3W * V3W;      // floats reserved per (plane, tile) slab; only w*h are touched
+
+__device__ __forceinline__ TileWin crop_win(TileWin w) {
+    if (w.w > V3W) { w.x0 = (short)(w.x0 + (w.w - V3W) / 2); w.w = (short)V3W; }
+    if (w.h > V3W) { w.y0 = (short)(w.y0 + (w.h - V3W) / 2); w.h = (short)V3W; }
+    return w;
+}
 
 template <int MODE, bool REPROJ>
 __global__ __launch_bounds__(kBlock) void loss_source_kernel(
@@ -31,8 +40,8 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     const TileWin* __restrict__ wins, int H, int W, int tiles_x, int ntiles, float* __restrict__ partial,
     float* __restrict__ grad, float* __restrict__ slabs, Overflow* ovf, unsigned* __restrict__ oidx,
     float* __restrict__ oval) {
-    __shared__ float sA[WMAXH * WMAXW];                 // depth of frame k over the window
-    __shared__ unsigned long long sW[WMAXH * WMAXW];    // scatter accumulator over the same window (2^-40 fixed point)
+    __shared__ float sA[V3W * V3W];                     // depth of frame k over the window
+    __shared__ unsigned long long sW[V3W * V3W];        // scatter accumulator over the same window (2^-40 fixed point)
     __shared__ float red[kBlock / kWave];
 
     const int j = blockIdx.y, b = blockIdx.z, tile = blockIdx.x, k = 1 - j;
@@ -40,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int X0 = txi * TW, Y0 = tyi * TH;
     const PairCam& cj = cams[b * 2 + j];
-    const TileWin win = wins[(size_t)(b * 2 + j) * ntiles + tile];
+    const TileWin win = crop_win(wins[(size_t)(b * 2 + j) * ntiles + tile]);
     const float* __restrict__ v_j = depth + (size_t)(b * 2 + j) * HW;
     const float* __restrict__ v_k = depth + (size_t)(b * 2 + k) * HW;
     const float* __restrict__ fl_j = (j == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
@@ -53,8 +62,8 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     const float inv_ww = win.w > 0 ? 1.f / (float)win.w : 0.f;
     for (int i = threadIdx.x; i < wn; i += kBlock) {
         const int r = (int)(((float)i + 0.5f) * inv_ww), c = i - r * win.w;
-        sA[r * WMAXW + c] = to_depth<MODE>(v_k[(win.y0 + r) * W + win.x0 + c]);
-        sW[r * WMAXW + c] = 0ull;
+        sA[r * V3W + c] = to_depth<MODE>(v_k[(win.y0 + r) * W + win.x0 + c]);
+        sW[r * V3W + c] = 0ull;
     }
     __syncthreads();
 
@@ -91,19 +100,19 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
         const Taps t = tap_coords(xf, yf, fx, fy, cj.sx, cj.sy, W, H);
         const int ra = t.ya - win.y0, ca = t.xa - win.x0, dyb = t.yb - t.ya, dxb = t.xb - t.xa;
         const bool inside = (unsigned)ra < (unsigned)max(win.h - dyb, 0) && (unsigned)ca < (unsigned)max(win.w - dxb, 0);
-        const int i00 = inside ? ra * WMAXW + ca : 0;
+        const int i00 = inside ? ra * V3W + ca : 0;
         float d00, d01, d10, d11;
         const bool fast = __all(inside || !valid);   // the whole wave's taps are inside the window: the common case
         if (fast) {
-            d00 = sA[i00]; d01 = sA[i00 + dxb]; d10 = sA[i00 + dyb * WMAXW]; d11 = sA[i00 + dyb * WMAXW + dxb];
+            d00 = sA[i00]; d01 = sA[i00 + dxb]; d10 = sA[i00 + dyb * V3W]; d11 = sA[i00 + dyb * V3W + dxb];
         } else {
             const int rb = ra + dyb, cb = ca + dxb;
             const bool ina = (unsigned)ra < (unsigned)win.h, inb = (unsigned)rb < (unsigned)win.h;
             const bool inca = (unsigned)ca < (unsigned)win.w, incb = (unsigned)cb < (unsigned)win.w;
-            d00 = (ina && inca) ? sA[ra * WMAXW + ca] : to_depth<MODE>(v_k[t.ya * W + t.xa]);
-            d01 = (ina && incb) ? sA[ra * WMAXW + cb] : to_depth<MODE>(v_k[t.ya * W + t.xb]);
-            d10 = (inb && inca) ? sA[rb * WMAXW + ca] : to_depth<MODE>(v_k[t.yb * W + t.xa]);
-            d11 = (inb && incb) ? sA[rb * WMAXW + cb] : to_depth<MODE>(v_k[t.yb * W + t.xb]);
+            d00 = (ina && inca) ? sA[ra * V3W + ca] : to_depth<MODE>(v_k[t.ya * W + t.xa]);
+            d01 = (ina && incb) ? sA[ra * V3W + cb] : to_depth<MODE>(v_k[t.ya * W + t.xb]);
+            d10 = (inb && inca) ? sA[rb * V3W + ca] : to_depth<MODE>(v_k[t.yb * W + t.xa]);
+            d11 = (inb && incb) ? sA[rb * V3W + cb] : to_depth<MODE>(v_k[t.yb * W + t.xb]);
         }
         const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
         const float izs = __builtin_amdgcn_rcpf(zs);
@@ -121,8 +130,8 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
             if (m != 0.f) {   // valid lanes only have m != 0
                 atomicAdd(&sW[i00], to_fixed(c00));
                 atomicAdd(&sW[i00 + dxb], to_fixed(c01));
-                atomicAdd(&sW[i00 + dyb * WMAXW], to_fixed(c10));
-                atomicAdd(&sW[i00 + dyb * WMAXW + dxb], to_fixed(c11));
+                atomicAdd(&sW[i00 + dyb * V3W], to_fixed(c10));
+                atomicAdd(&sW[i00 + dyb * V3W + dxb], to_fixed(c11));
             }
         } else {
             const int xs[4] = {t.xa, t.xb, t.xa, t.xb}, ys[4] = {t.ya, t.ya, t.yb, t.yb};
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
                 const int rq = ys[q] - win.y0, cq = xs[q] - win.x0;
                 const bool inq = (unsigned)rq < (unsigned)win.h && (unsigned)cq < (unsigned)win.w;
                 const bool live = m != 0.f && cs[q] != 0.f;
-                if (live && inq) atomicAdd(&sW[rq * WMAXW + cq], to_fixed(cs[q]));
+                if (live && inq) atomicAdd(&sW[rq * V3W + cq], to_fixed(cs[q]));
                 ovf_push(live && !inq, ovf, oidx, oval, base_k + (unsigned)(ys[q] * W + xs[q]), cs[q]);   // convergent
             }
         }
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     float* __restrict__ slab = slabs + ((size_t)(b * 2 + j) * ntiles + tile) * SLAB_STRIDE;
     for (int i = threadIdx.x; i < wn; i += kBlock) {
         const int r = (int)(((float)i + 0.5f) * inv_ww), c = i - r * win.w;
-        slab[i] = from_fixed(sW[r * WMAXW + c]);
+        slab[i] = from_fixed(sW[r * V3W + c]);
     }
     acc_r = block_sum(acc_r, red);
     acc_d = block_sum(acc_d, red);
@@ -154,32 +163,54 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     }
 }
 
-// pass B: grad[b, k, T] += sum over the source tiles s of plane j of slab_s restricted to T
+// pass B: grad[b, k, T] += sum over the source tiles s of plane j of slab_s restricted to T.
+// Which slabs overlap T is found in parallel (one thread per source tile -> bitmask in LDS); the overlapping
+// ones are then visited in increasing s (fixed order -> bit-reproducible sums), each contributing a rectangle of
+// distinct elements of the LDS tile accumulator.
 __global__ __launch_bounds__(kBlock) void loss_gather_kernel(const TileWin* __restrict__ wins,
                                                              const float* __restrict__ slabs, int H, int W,
                                                              int tiles_x, int ntiles, float* __restrict__ grad) {
     __shared__ float sAcc[TH * TW];
+    __shared__ unsigned sBits[MAXT_LDS / 32];
+    __shared__ TileWin sWin[MAXT_LDS];
     const int k = blockIdx.y, b = blockIdx.z, tile = blockIdx.x, j = 1 - k;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int X0 = txi * TW, Y0 = tyi * TH, X1 = min(X0 + TW, W), Y1 = min(Y0 + TH, H);
-    for (int i = threadIdx.x; i < TH * TW; i += kBlock) sAcc[i] = 0.f;
     const TileWin* __restrict__ wj = wins + (size_t)(b * 2 + j) * ntiles;
     const float* __restrict__ sl = slabs + (size_t)(b * 2 + j) * ntiles * SLAB_STRIDE;
+    for (int i = threadIdx.x; i < TH * TW; i += kBlock) sAcc[i] = 0.f;
+    if (threadIdx.x < MAXT_LDS / 32) sBits[threadIdx.x] = 0u;
     __syncthreads();
-    for (int s = 0; s < ntiles; ++s) {
-        const TileWin w = wj[s];   // block-uniform (scalar) loads and tests
-        const int x0 = max((int)w.x0, X0), y0 = max((int)w.y0, Y0);
-        const int x1 = min((int)w.x0 + w.w, X1), y1 = min((int)w.y0 + w.h, Y1);
-        const int rw = x1 - x0, rh = y1 - y0;
-        if (rw <= 0 || rh <= 0) continue;
-        const float* __restrict__ src = sl + (size_t)s * SLAB_STRIDE;
-        const float inv = 1.f / (float)rw;
-        for (int i = threadIdx.x; i < rw * rh; i += kBlock) {
-            const int r = (int)(((float)i + 0.5f) * inv), c = i - r * rw;
-            const int y = y0 + r, x = x0 + c;
-            sAcc[(y - Y0) * TW + (x - X0)] += src[(y - w.y0) * w.w + (x - w.x0)];   // distinct elements within one slab
+    const bool use_bits = ntiles <= MAXT_LDS;
+    if (use_bits) {
+        for (int s = threadIdx.x; s < ntiles; s += kBlock) {
+            const TileWin w = crop_win(wj[s]);
+            sWin[s] = w;
+            const bool hit = min((int)w.x0 + w.w, X1) > max((int)w.x0, X0) && min((int)w.y0 + w.h, Y1) > max((int)w.y0, Y0);
+            if (hit) atomicOr(&sBits[s >> 5], 1u << (s & 31));
         }
-        __syncthreads();   // the next slab may touch the same elements from other threads
+        __syncthreads();
+    }
+    const int nwords = use_bits ? (ntiles + 31) / 32 : ntiles;
+    for (int wd = 0; wd < nwords; ++wd) {
+        unsigned bits = use_bits ? sBits[wd] : 1u;   // block-uniform
+        while (bits) {
+            const int s = use_bits ? wd * 32 + __ffs((int)bits) - 1 : wd;
+            bits &= bits - 1u;
+            const TileWin w = use_bits ? sWin[s] : crop_win(wj[s]);
+            const int x0 = max((int)w.x0, X0), y0 = max((int)w.y0, Y0);
+            const int x1 = min((int)w.x0 + w.w, X1), y1 = min((int)w.y0 + w.h, Y1);
+            const int rw = x1 - x0, rh = y1 - y0;
+            if (rw <= 0 || rh <= 0) continue;
+            const float* __restrict__ src = sl + (size_t)s * SLAB_STRIDE;
+            const float inv = 1.f / (float)rw;
+            for (int i = threadIdx.x; i < rw * rh; i += kBlock) {
+                const int r = (int)(((float)i + 0.5f) * inv), c = i - r * rw;
+                const int y = y0 + r, x = x0 + c;
+                sAcc[(y - Y0) * TW + (x - X0)] += src[(y - w.y0) * w.w + (x - w.x0)];   // distinct elements within one slab
+            }
+            __syncthreads();   // the next slab may touch the same elements from other threads
+        }
     }
     float* __restrict__ g = grad + (size_t)(b * 2 + k) * H * W;
     for (int i = threadIdx.x; i < TH * TW; i += kBlock) {

@@ -41,7 +41,7 @@ def test_workspace_query_is_pure_host():
     lib = _native.lib()
     a = lib.cd_consistency_loss_workspace_bytes(4, 384, 224)
     b = lib.cd_consistency_loss_workspace_bytes(8, 384, 224)
-    assert 0 < a < b < (1 << 24)
+    assert 0 < a < b < (1 << 28)   # B=8: ~17 MB (slabs of the evaluate-once gradient kernel dominate)
     assert lib.cd_consistency_loss_workspace_bytes(0, 384, 224) == 0
 
 
