@@ -206,7 +206,7 @@ def main():
         in_step_ms = float(np.mean(ms_step)) if len(ms_step) else None
         if in_step_ms:
             ach = LOSS_BYTES_PER_PAIR_PX * px * B / (in_step_ms * 1e-3) / 1e9
-            out["roofline_in_step"] = {"kernel": "loss_owner_kernel", "bound": "hbm", "achieved": round(ach, 1),
+            out["roofline_in_step"] = {"kernel": "loss_source_kernel + loss_gather4_kernel (one gradient launch)", "bound": "hbm", "achieved": round(ach, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                        "traffic": None, "launch_pairs": B, "avg_ms": round(in_step_ms, 5),
                                        "note": "13.8 MB per launch: cache resident, launch-latency bound"}
@@ -215,7 +215,7 @@ def main():
             ms = loss_microbench(lib, args.loss_batch, H, W, args.loss_iters, device)
             avg = float(np.mean(ms))
             ach = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch / (avg * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "loss_owner_kernel", "bound": "hbm", "achieved": round(ach, 1),
+            out["roofline"] = {"kernel": "loss_source_kernel + loss_gather4_kernel (one gradient launch)", "bound": "hbm", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": None, "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}

@@ -146,7 +146,7 @@ struct Workspace {
     void* wins;        // tile windows     (when the caller passes none)
     void* ovf;         // 256 B header + idx[cap] + val[cap]
     int ovf_cap;
-    float* slabs;      // v3: [B*2][ntiles][64*64] floats (only each tile's window is touched)
+    float* slabs;      // v3: [min(B,chunk)*2][ntiles][48*48] floats (only each tile's window is touched)
 };
 
 static inline int ovf_capacity(int B, int HW) {
@@ -278,6 +278,11 @@ int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out) {
     for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
     delete[] g_prof.start; delete[] g_prof.stop; delete[] g_prof.batch;
     g_prof = cd::Profiler();
+    return CD_OK;
+}
+
+int cd_debug_set_loss_chunk(int pairs) {
+    cd::set_slab_chunk_pairs(pairs);
     return CD_OK;
 }
 

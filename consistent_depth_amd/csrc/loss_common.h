@@ -81,6 +81,8 @@ int launch_overflow_apply(void* ovf_mem, int ovf_cap, float* grad, hipStream_t s
 
 // ---- v3 (loss_slab.hip): source pass + gather pass; slabs = slab_floats(B,H,W) floats of scratch
 size_t slab_floats(int B, int H, int W);
+int slab_chunk_pairs(int H, int W);     // pairs per source+gather launch pair (slabs sized to stay cache resident)
+void set_slab_chunk_pairs(int pairs);   // test/measurement hook; 0 restores the default
 int launch_slab(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb,
                 const void* cams, const void* wins, int mode, bool reproj, int B, int H, int W, float* partial,
                 float* grad, float* slabs, void* ovf_mem, int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t),

@@ -25,7 +25,10 @@ namespace cd {
 // v3 keeps TWO window-shaped arrays in LDS (depth + 64-bit accumulator), so its window cap is smaller than the
 // table's (64x64): table windows are centre-cropped to 48x48 on the fly, identically in both passes.
 constexpr int V3W = 48;
-constexpr int SLAB_STRIDE = V3W * V3W;      // floats reserved per (plane, tile) slab; only w*h are touched
+// Slab layout: row r of the window starts at image column xa0 = win.x0 & ~3 (so that float4-aligned target columns
+// are float4-aligned in the slab), fixed row stride SLAB_RS; the <= 3 pad columns either side of the window hold 0.
+constexpr int SLAB_RS = V3W + 4;
+constexpr int SLAB_STRIDE = V3W * SLAB_RS;  // floats reserved per (plane, tile) slab; only h rows of pw are touched
 
 __device__ __forceinline__ TileWin crop_win(TileWin w) {
     if (w.w > V3W) { w.x0 = (short)(w.x0 + (w.w - V3W) / 2); w.w = (short)V3W; }
@@ -39,12 +42,12 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     const float* __restrict__ mask_fwd, const float* __restrict__ mask_bwd, const PairCam* __restrict__ cams,
     const TileWin* __restrict__ wins, int H, int W, int tiles_x, int ntiles, float* __restrict__ partial,
     float* __restrict__ grad, float* __restrict__ slabs, Overflow* ovf, unsigned* __restrict__ oidx,
-    float* __restrict__ oval) {
+    float* __restrict__ oval, int b0) {
     __shared__ float sA[V3W * V3W];                     // depth of frame k over the window
     __shared__ unsigned long long sW[V3W * V3W];        // scatter accumulator over the same window (2^-40 fixed point)
     __shared__ float red[kBlock / kWave];
 
-    const int j = blockIdx.y, b = blockIdx.z, tile = blockIdx.x, k = 1 - j;
+    const int j = blockIdx.y, b = b0 + blockIdx.z, tile = blockIdx.x, k = 1 - j;   // slabs are per chunk: indexed by blockIdx.z
     const int HW = H * W;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int X0 = txi * TW, Y0 = tyi * TH;
@@ -57,6 +60,21 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     float* __restrict__ g_j = grad + (size_t)(b * 2 + j) * HW;
     const unsigned base_k = (unsigned)(b * 2 + k) * (unsigned)HW;
 
+    // ---- per-pixel inputs of this thread's 4 rows: issued first so their latency hides behind the window staging
+    constexpr int ROWS_PER_IT = kBlock / TW, ITERS = TH / ROWS_PER_IT;
+    const int lx = threadIdx.x & (TW - 1), ly0 = threadIdx.x / TW;
+    float in_v[ITERS], in_m[ITERS], in_fx[ITERS], in_fy[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int x = X0 + lx, y = Y0 + ly0 + it * ROWS_PER_IT;
+        const bool valid = x < W && y < H;
+        const int p = valid ? y * W + x : 0;
+        in_v[it] = v_j[p];
+        in_m[it] = valid ? mk_j[p] : 0.f;
+        in_fx[it] = fl_j[p];
+        in_fy[it] = fl_j[HW + p];
+    }
+
     // ---- stage the window, clear the accumulator
     const int wn = (int)win.w * (int)win.h;
     const float inv_ww = win.w > 0 ? 1.f / (float)win.w : 0.f;
@@ -68,8 +86,6 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     __syncthreads();
 
     // ---- evaluate every source pixel of the tile once
-    constexpr int ROWS_PER_IT = kBlock / TW, ITERS = TH / ROWS_PER_IT;
-    const int lx = threadIdx.x & (TW - 1), ly0 = threadIdx.x / TW;
     float acc_r = 0.f, acc_d = 0.f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -77,9 +93,9 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
         const int x = X0 + lx, y = Y0 + ly;
         const bool valid = x < W && y < H;
         const int p = valid ? y * W + x : 0;
-        const float d = to_depth<MODE>(v_j[p]);
-        const float m = valid ? mk_j[p] : 0.f;
-        const float fx = fl_j[p], fy = fl_j[HW + p];
+        const float d = to_depth<MODE>(in_v[it]);
+        const float m = in_m[it];
+        const float fx = in_fx[it], fy = in_fy[it];
         const float xf = (float)x, yf = (float)y;
         const float r0 = (xf - cj.cx_r) * cj.ifx_r, r1 = -(yf - cj.cy_r) * cj.ify_r;
         const float a0 = cj.M[0] * r0 + cj.M[1] * r1 - cj.M[2];
@@ -148,11 +164,21 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     }
     __syncthreads();
 
-    // ---- the window accumulator leaves as a float slab (compact rows of win.w)
-    float* __restrict__ slab = slabs + ((size_t)(b * 2 + j) * ntiles + tile) * SLAB_STRIDE;
-    for (int i = threadIdx.x; i < wn; i += kBlock) {
-        const int r = (int)(((float)i + 0.5f) * inv_ww), c = i - r * win.w;
-        slab[i] = from_fixed(sW[r * V3W + c]);
+    // ---- the window accumulator leaves as a float slab (float4 stores, target-aligned rows)
+    float* __restrict__ slab = slabs + ((size_t)(blockIdx.z * 2 + j) * ntiles + tile) * SLAB_STRIDE;
+    const int xa0 = win.x0 & ~3, lpad = win.x0 - xa0;
+    const int pw4 = (((win.x0 + win.w + 3) & ~3) - xa0) >> 2;
+    const int nq = pw4 * win.h;
+    const float inv_pw4 = pw4 > 0 ? 1.f / (float)pw4 : 0.f;
+    for (int i = threadIdx.x; i < nq; i += kBlock) {
+        const int r = (int)(((float)i + 0.5f) * inv_pw4), q = i - r * pw4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = q * 4 + e - lpad;
+            v[e] = (unsigned)c < (unsigned)win.w ? from_fixed(sW[r * V3W + c]) : 0.f;
+        }
+        *reinterpret_cast<float4*>(slab + r * SLAB_RS + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
     acc_r = block_sum(acc_r, red);
     acc_d = block_sum(acc_d, red);
@@ -163,21 +189,21 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     }
 }
 
-// pass B: grad[b, k, T] += sum over the source tiles s of plane j of slab_s restricted to T.
-// Which slabs overlap T is found in parallel (one thread per source tile -> bitmask in LDS); the overlapping
+// pass B, general form (any W, any number of tiles): grad[b, k, T] += sum over the source tiles s of plane j of
+// slab_s restricted to T.  Which slabs overlap T is found in parallel (one thread per source tile -> bitmask in LDS); the overlapping
 // ones are then visited in increasing s (fixed order -> bit-reproducible sums), each contributing a rectangle of
 // distinct elements of the LDS tile accumulator.
 __global__ __launch_bounds__(kBlock) void loss_gather_kernel(const TileWin* __restrict__ wins,
                                                              const float* __restrict__ slabs, int H, int W,
-                                                             int tiles_x, int ntiles, float* __restrict__ grad) {
+                                                             int tiles_x, int ntiles, float* __restrict__ grad, int b0) {
     __shared__ float sAcc[TH * TW];
     __shared__ unsigned sBits[MAXT_LDS / 32];
     __shared__ TileWin sWin[MAXT_LDS];
-    const int k = blockIdx.y, b = blockIdx.z, tile = blockIdx.x, j = 1 - k;
+    const int k = blockIdx.y, b = b0 + blockIdx.z, tile = blockIdx.x, j = 1 - k;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int X0 = txi * TW, Y0 = tyi * TH, X1 = min(X0 + TW, W), Y1 = min(Y0 + TH, H);
     const TileWin* __restrict__ wj = wins + (size_t)(b * 2 + j) * ntiles;
-    const float* __restrict__ sl = slabs + (size_t)(b * 2 + j) * ntiles * SLAB_STRIDE;
+    const float* __restrict__ sl = slabs + (size_t)(blockIdx.z * 2 + j) * ntiles * SLAB_STRIDE;
     for (int i = threadIdx.x; i < TH * TW; i += kBlock) sAcc[i] = 0.f;
     if (threadIdx.x < MAXT_LDS / 32) sBits[threadIdx.x] = 0u;
     __syncthreads();
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void loss_gather_kernel(const TileWin* __re
             for (int i = threadIdx.x; i < rw * rh; i += kBlock) {
                 const int r = (int)(((float)i + 0.5f) * inv), c = i - r * rw;
                 const int y = y0 + r, x = x0 + c;
-                sAcc[(y - Y0) * TW + (x - X0)] += src[(y - w.y0) * w.w + (x - w.x0)];   // distinct elements within one slab
+                sAcc[(y - Y0) * TW + (x - X0)] += src[(y - w.y0) * SLAB_RS + (x - (w.x0 & ~3))];   // distinct elements within one slab
             }
             __syncthreads();   // the next slab may touch the same elements from other threads
         }
@@ -219,20 +245,87 @@ __global__ __launch_bounds__(kBlock) void loss_gather_kernel(const TileWin* __re
     }
 }
 
+// pass B, float4 form (W % 4 == 0, <= MAXT_LDS tiles): one thread owns one float4 of the 32x32 target tile.  The
+// overlapping slabs are found in parallel (bitmask), compacted in increasing s into an LDS list, and every thread
+// adds its float4 of each listed slab that covers it: no barriers in the accumulation, fixed order of summation.
+__global__ __launch_bounds__(kBlock) void loss_gather4_kernel(const TileWin* __restrict__ wins,
+                                                              const float* __restrict__ slabs, int H, int W,
+                                                              int tiles_x, int ntiles, float* __restrict__ grad, int b0) {
+    static_assert(kBlock == TH * TW / 4, "one float4 per thread");
+    __shared__ unsigned sBits[MAXT_LDS / 32];
+    __shared__ int4 sEnt[MAXT_LDS];   // y0, h, xa0, padded width of the overlapping slabs, in increasing s
+    __shared__ int sOff[MAXT_LDS];
+    const int k = blockIdx.y, b = b0 + blockIdx.z, tile = blockIdx.x, j = 1 - k;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int X0 = txi * TW, Y0 = tyi * TH, X1 = min(X0 + TW, W), Y1 = min(Y0 + TH, H);
+    const TileWin* __restrict__ wj = wins + (size_t)(b * 2 + j) * ntiles;
+    const float* __restrict__ sl = slabs + (size_t)(blockIdx.z * 2 + j) * ntiles * SLAB_STRIDE;
+    if (threadIdx.x < MAXT_LDS / 32) sBits[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int s = threadIdx.x; s < ntiles; s += kBlock) {
+        const TileWin w = crop_win(wj[s]);
+        const int xa0 = w.x0 & ~3, xa1 = (w.x0 + w.w + 3) & ~3;
+        if (min(xa1, X1) > max(xa0, X0) && min((int)w.y0 + w.h, Y1) > max((int)w.y0, Y0)) atomicOr(&sBits[s >> 5], 1u << (s & 31));
+    }
+    __syncthreads();
+    const int nwords = (ntiles + 31) >> 5;
+    for (int s = threadIdx.x; s < ntiles; s += kBlock) {
+        const unsigned word = sBits[s >> 5];
+        if (word >> (s & 31) & 1u) {
+            int pos = __popc(word & ((1u << (s & 31)) - 1u));
+            for (int wd = 0; wd < (s >> 5); ++wd) pos += __popc(sBits[wd]);
+            const TileWin w = crop_win(wj[s]);
+            const int xa0 = w.x0 & ~3;
+            sEnt[pos] = make_int4(w.y0, w.h, xa0, ((w.x0 + w.w + 3) & ~3) - xa0);
+            sOff[pos] = s * SLAB_STRIDE;
+        }
+    }
+    int count = 0;
+    for (int wd = 0; wd < nwords; ++wd) count += __popc(sBits[wd]);
+    __syncthreads();
+    const int y = Y0 + (threadIdx.x >> 3), x = X0 + (threadIdx.x & 7) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = 0; e < count; ++e) {
+        const int4 en = sEnt[e];
+        const int r = y - en.x, c = x - en.z;
+        if ((unsigned)r < (unsigned)en.y && (unsigned)c < (unsigned)en.w) {
+            const float4 v = *reinterpret_cast<const float4*>(sl + sOff[e] + r * SLAB_RS + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    if (y < H && x < W) {
+        float4* g = reinterpret_cast<float4*>(grad + (size_t)(b * 2 + k) * H * W + (size_t)y * W + x);
+        float4 o = *g;
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *g = o;
+    }
+}
+
 // ---------------------------------------------------------------- host side
-size_t slab_floats(int B, int H, int W) { return (size_t)B * 2 * owner_ntiles(H, W) * SLAB_STRIDE; }
+static int g_slab_chunk_override = 0;   // pairs per chunk; 0 = size the chunk's slabs to kSlabChunkBytes
+constexpr size_t kSlabChunkBytes = 216u << 20;   // 128 pairs at 384x224; chunks are balanced (B=256 -> 2 x 128)
+void set_slab_chunk_pairs(int pairs) { g_slab_chunk_override = pairs > 0 ? pairs : 0; }
+int slab_chunk_pairs(int H, int W) {
+    if (g_slab_chunk_override > 0) return g_slab_chunk_override;
+    const size_t per_pair = (size_t)2 * owner_ntiles(H, W) * SLAB_STRIDE * sizeof(float);
+    const size_t ch = kSlabChunkBytes / per_pair;
+    return ch < 1 ? 1 : (int)ch;
+}
+size_t slab_floats(int B, int H, int W) {
+    return (size_t)min(B, slab_chunk_pairs(H, W)) * 2 * owner_ntiles(H, W) * SLAB_STRIDE;
+}
 
 template <int MODE>
 static void launch_source_mode(bool reproj, dim3 grid, hipStream_t s, const float* depth, const float* ff,
                                const float* fb, const float* mf, const float* mb, const PairCam* cams,
                                const TileWin* wins, int H, int W, int tx, int nt, float* partial, float* grad,
-                               float* slabs, Overflow* ovf, unsigned* oidx, float* oval) {
+                               float* slabs, Overflow* ovf, unsigned* oidx, float* oval, int b0) {
     if (reproj)
         hipLaunchKernelGGL((loss_source_kernel<MODE, true>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins, H, W,
-                           tx, nt, partial, grad, slabs, ovf, oidx, oval);
+                           tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
     else
         hipLaunchKernelGGL((loss_source_kernel<MODE, false>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins, H, W,
-                           tx, nt, partial, grad, slabs, ovf, oidx, oval);
+                           tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
 }
 
 // Enqueues: overflow header reset, [before_main] source pass, gather pass [after_main], overflow apply.
@@ -246,15 +339,23 @@ int launch_slab(const float* depth, const float* ff, const float* fb, const floa
     float* oval = (float*)(oidx + ovf_cap);
     if (hipMemsetAsync(ovf, 0, sizeof(Overflow), s) != hipSuccess) return CD_ERR_LAUNCH;
     if (hipMemsetD32Async((hipDeviceptr_t)&ovf->cap, ovf_cap, 1, s) != hipSuccess) return CD_ERR_LAUNCH;
-    const dim3 grid(nt, 2, B);
     if (before_main) before_main(s);
-    if (mode == CD_DEPTH_EXP)
-        launch_source_mode<CD_DEPTH_EXP>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval);
-    else if (mode == CD_DEPTH_RECIPROCAL)
-        launch_source_mode<CD_DEPTH_RECIPROCAL>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval);
-    else
-        launch_source_mode<CD_DEPTH_IDENTITY>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval);
-    hipLaunchKernelGGL(loss_gather_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, grad);
+    // Pairs are processed in balanced chunks (pass A then pass B per chunk) so the slab scratch is bounded for any B.
+    // (Measured: chunk size does not change the rate as long as each launch has >= ~10k workgroups.)
+    const int ch_max = slab_chunk_pairs(H, W), nch = (B + ch_max - 1) / ch_max, ch = (B + nch - 1) / nch;
+    for (int b0 = 0; b0 < B; b0 += ch) {
+        const dim3 grid(nt, 2, min(ch, B - b0));
+        if (mode == CD_DEPTH_EXP)
+            launch_source_mode<CD_DEPTH_EXP>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+        else if (mode == CD_DEPTH_RECIPROCAL)
+            launch_source_mode<CD_DEPTH_RECIPROCAL>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+        else
+            launch_source_mode<CD_DEPTH_IDENTITY>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+        if (W % 4 == 0 && nt <= MAXT_LDS && reinterpret_cast<uintptr_t>(grad) % 16 == 0)
+            hipLaunchKernelGGL(loss_gather4_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, grad, b0);
+        else
+            hipLaunchKernelGGL(loss_gather_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, grad, b0);
+    }
     if (after_main) after_main(s);
     if (hipGetLastError() != hipSuccess) return CD_ERR_LAUNCH;
     launch_overflow_apply(ovf_mem, ovf_cap, grad, s);

@@ -123,6 +123,9 @@ int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out);
 int cd_debug_set_overflow_capacity(int cap);
 /* Test / A-B hook: gradient-kernel formulation, 3 = evaluate once + slab reduce (default), 2 = owner-computes. */
 int cd_debug_set_loss_variant(int variant);
+/* pairs per source+gather launch pair of the evaluate-once gradient kernel (0 = default: slabs of one chunk sized
+ * to stay resident in the Infinity Cache).  Changes cd_consistency_loss_workspace_bytes(); set it before the query. */
+int cd_debug_set_loss_chunk(int pairs);
 
 /* utils/geometry.py:201-208 `sample`: bilinear, border padding, align_corners=False on an
  * align_corners=True style normalisation.  data [B,C,H,W], uv [B,2,H,W] px -> out [B,C,H,W]. */

@@ -249,3 +249,22 @@ def test_rejects_cpu_tensors(torch_cuda):
     with pytest.raises(RuntimeError, match="HIP device"):
         CL.consistency_loss(t(b["depth"]), [t(f) for f in b["flows"]], [t(m) for m in b["masks"]],
                             t(b["intrinsics"]), t(b["extrinsics"]), 1.0, 0.1)
+
+
+def test_chunked_launches_are_bit_identical(torch_cuda):
+    """The evaluate-once kernel processes pairs in chunks (bounded slab scratch); pairs are independent and
+    the order of summation inside a pair is fixed, so chunking must not change a single bit."""
+    from consistent_depth_amd import _native, synthetic
+    lib = _native.lib()
+    batch = synthetic.make_scene_batch(7, 96, 128, seed=3)
+    try:
+        assert lib.cd_debug_set_loss_chunk(7) == 0
+        one = _run(torch_cuda, batch, 1.0, 0.1)
+        assert lib.cd_debug_set_loss_chunk(3) == 0          # chunks of 3, 3, 1
+        three = _run(torch_cuda, batch, 1.0, 0.1)
+    finally:
+        lib.cd_debug_set_loss_chunk(0)
+    assert one[0] == three[0]
+    np.testing.assert_array_equal(one[1], three[1])
+    np.testing.assert_array_equal(one[2], three[2])
+    np.testing.assert_array_equal(one[3], three[3])

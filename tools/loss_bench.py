@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--mode", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=0, help="pairs per source+gather launch pair (0 = default)")
     ap.add_argument("--variant", type=int, default=3, help="3 = evaluate-once + slab reduce, 2 = owner-computes")
     ap.add_argument("--noise-px", type=float, default=0.25)
     ap.add_argument("--inconsistent", action="store_true", help="adversarial generator: unrelated depth per frame")
@@ -33,6 +34,7 @@ def main():
     from consistent_depth_amd.loss import consistency_loss as CL
     lib = _native.lib()
     assert lib.cd_debug_set_loss_variant(args.variant) == 0
+    assert lib.cd_debug_set_loss_chunk(args.chunk) == 0
     dev = torch.device("cuda", 0)
     H, W = args.height, args.width
     gen = synthetic.make_pair_batch if args.inconsistent else synthetic.make_scene_batch
