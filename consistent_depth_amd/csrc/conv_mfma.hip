@@ -28,6 +28,9 @@ namespace cd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CV_TX = 32;  // output tile width (2 M-tiles)
+#ifndef CD_CONV_PIPE_MAX_REGS
+#define CD_CONV_PIPE_MAX_REGS 72   // prefetch registers (data + offsets) a block may spend on the software pipeline
+#endif
 
 template <int KS, int TY_> struct ConvCfg {
     static constexpr int TY = TY_;                          // output rows per block (4 waves x TY/4 rows): 4, 8 or 16
@@ -69,32 +72,37 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int C
 }
 
 // ---------------------------------------------------------------- the convolution
+// CO_T = 16-wide output-channel tiles per block.  The packed filter rows are cobp_pack floats wide (the layout
+// is chosen once per filter, pick_co_tiles); a block may take only a CO_T*16-column slice of them
+// (blockIdx.y = group * nsub + sub), which gives the small deep-level images enough workgroups.
 template <int KS, int CO_T, int TYP>
 __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
-    const float* __restrict__ wpk, const float* __restrict__ bias,
+    const float* __restrict__ wpk, int cobp_pack, int nsub, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     float* __restrict__ y, int y_ctot, int y_coff, int Cout,
-    double* __restrict__ stats, int accumulate, int H, int W, int tiles_x) {
+    double* __restrict__ stats, int accumulate, int H, int W, int tiles_x, int pipe) {
     using Cfg = ConvCfg<KS, TYP>;
     constexpr int TY = Cfg::TY, CI = Cfg::CI_CHUNK, RS = Cfg::RS, PS = Cfg::PS, ROWS = Cfg::ROWS;
     constexpr int P = (KS - 1) / 2, TAPS = KS * KS;
     constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
     constexpr int RPW = TY / 4;          // output rows per wave
     constexpr int MT = RPW * 2;          // M-tiles per wave
-    constexpr int W_ELEMS = TAPS * CI * COBP;
+    constexpr int ROW4 = COB / 4;        // float4 per staged filter row
+    constexpr int W_ROWS = TAPS * CI;    // filter rows (tap, ci) per chunk
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;                  // [CI][PS]
     float* s_w = smem + CI * PS;         // [TAPS][CI][COBP]
 
-    const int tile = blockIdx.x, grp = blockIdx.y, n = blockIdx.z;
+    const int tile = blockIdx.x, grp = blockIdx.y / nsub, sub = blockIdx.y - grp * nsub, n = blockIdx.z;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int X0 = tx * CV_TX, Y0 = ty * TY;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t HW = (size_t)H * W;
     const float* xin = x + ((size_t)n * x_ctot + x_coff) * HW;
     const int n_chunks = (Cin + CI - 1) / CI;
+    const float* wbase = wpk + (size_t)grp * n_chunks * W_ROWS * cobp_pack + sub * COB;
 
     f32x4 acc[MT][CO_T];
 #pragma unroll
@@ -105,93 +113,166 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     const int a_lane = (lane >> 4) * PS + (lane & 15);      // A fragment: channel k = lane>>4, pixel i = lane&15
     const int b_lane = (lane >> 4) * COBP + (lane & 15);    // B fragment: channel k, out-channel j
 
-    // 1x1 (pure GEMM, little math per staged byte): software pipeline -- the next chunk's global loads are in
-    // flight in registers while the MFMAs of the current chunk run
-    constexpr int PF_IN = (KS == 1) ? (CI * ROWS * (RS / 4) + kBlock - 1) / kBlock : 1;
-    constexpr int PF_W = (KS == 1) ? (W_ELEMS / 4 + kBlock - 1) / kBlock : 1;
-    float4 pf_in[PF_IN], pf_w[PF_W];
-    const bool pipelined = (KS == 1) && ((W & 3) == 0);
-    auto pf_load = [&](int chunk) {
-#pragma unroll
-        for (int q = 0; q < PF_IN; ++q) {
-            const int i = threadIdx.x + q * kBlock;
-            const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
-            const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
-            const int ci = chunk * CI + cc, gy = Y0 + r, gx = X0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < CI * ROWS * (RS / 4) && ci < Cin && gy < H && gx < W) {
-                v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
-                if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
-                if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
-            pf_in[q] = v;
+    // Software pipeline: the next chunk's global loads (input tile and filter slice) are in flight in registers
+    // while the MFMAs of the current chunk run; the producer's BN-apply + ReLU is applied when the registers are
+    // written to LDS (scale/shift staged once in LDS).  Per-thread element offsets are 32-bit and precomputed; the
+    // chunk base pointers are wave-uniform.  Used when the registers fit (PIPE_OK) and the launch asks for it.
+    constexpr bool VEC_IN = (KS == 1);   // no halo: tile rows are 32 contiguous pixels -> 16-byte loads (needs W % 4 == 0)
+    constexpr int IN_ELEMS = VEC_IN ? CI * ROWS * (RS / 4) : CI * ROWS * RS;
+    constexpr int PF_IN = (IN_ELEMS + kBlock - 1) / kBlock;
+    constexpr int PF_W = (W_ROWS * ROW4 + kBlock - 1) / kBlock;
+    constexpr bool PIPE_OK = (PF_IN * (VEC_IN ? 5 : 2) + PF_W * 5) <= CD_CONV_PIPE_MAX_REGS;
+    const bool vec_in = VEC_IN && ((W & 3) == 0);
+    const bool pipelined = PIPE_OK && pipe && (!VEC_IN || vec_in) && (size_t)CI * HW < (1u << 30);
+    float* s_aff = s_w + W_ROWS * COBP;  // [2][n_chunks * CI] scale, shift of the input channels (pipelined path)
+
+    // ---- generic (non-pipelined) staging helpers
+    auto in_load4 = [&](int chunk, int i) -> float4 {
+        const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
+        const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
+        const int ci = chunk * CI + cc, gy = Y0 + r, gx = X0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci < Cin && gy < H && gx < W) {
+            v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
+            if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
+            if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         }
-        const float* wsrc = wpk + ((size_t)grp * n_chunks + chunk) * W_ELEMS;
+        return v;
+    };
+    auto in_load1 = [&](int chunk, int i, int pad) -> float {
+        const int cc = i / (ROWS * RS), rem = i - cc * (ROWS * RS);
+        const int r = rem / RS, c = rem - r * RS;
+        const int ci = chunk * CI + cc, gy = Y0 - pad + r, gx = X0 - pad + c;
+        float v = 0.f;
+        if (ci < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            v = xin[(size_t)ci * HW + (size_t)gy * W + gx];
+            if (in_scale) v = __fmaf_rn(v, in_scale[ci], in_shift[ci]);  // same fma as the BN backward's mask
+            if (in_relu) v = fmaxf(v, 0.f);
+        }
+        return v;
+    };
+    auto in_lds4 = [&](int i) -> int {
+        const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
+        const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
+        return cc * PS + r * RS + c;
+    };
+    auto in_lds1 = [&](int i) -> int {
+        const int cc = i / (ROWS * RS);
+        return cc * PS + (i - cc * (ROWS * RS));
+    };
+    auto w_src = [&](int i) -> int { const int row = i / ROW4; return row * cobp_pack + (i - row * ROW4) * 4; };
+    auto w_lds = [&](int i) -> int { const int row = i / ROW4; return row * COBP + (i - row * ROW4) * 4; };
+
+    // ---- pipelined path state
+    int in_off[PIPE_OK ? PF_IN : 1], w_off[PIPE_OK ? PF_W : 1];   // element offsets from the chunk base; -1 = zero padding
+    float4 pf_in4[(PIPE_OK && VEC_IN) ? PF_IN : 1];
+    float pf_in1[(PIPE_OK && !VEC_IN) ? PF_IN : 1];
+    float4 pf_w[PIPE_OK ? PF_W : 1];
+    if constexpr (PIPE_OK) {
+        if (pipelined) {
 #pragma unroll
-        for (int q = 0; q < PF_W; ++q) {
-            const int i = (threadIdx.x + q * kBlock) * 4;
-            pf_w[q] = i < W_ELEMS ? *reinterpret_cast<const float4*>(wsrc + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < PF_IN; ++q) {
+                const int i = threadIdx.x + q * kBlock;
+                int off = -1;
+                if (i < IN_ELEMS) {
+                    if constexpr (VEC_IN) {
+                        const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
+                        const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
+                        const int gy = Y0 + r, gx = X0 + c;
+                        if (gy < H && gx < W) off = cc * (int)HW + gy * W + gx;
+                    } else {
+                        const int cc = i / (ROWS * RS), rem = i - cc * (ROWS * RS);
+                        const int r = rem / RS, c = rem - r * RS;
+                        const int gy = Y0 - P + r, gx = X0 - P + c;
+                        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) off = cc * (int)HW + gy * W + gx;
+                    }
+                }
+                in_off[q] = off;
+            }
+#pragma unroll
+            for (int q = 0; q < PF_W; ++q) {
+                const int i = threadIdx.x + q * kBlock;
+                w_off[q] = i < W_ROWS * ROW4 ? w_src(i) : -1;
+            }
+            if (in_scale)
+                for (int i = threadIdx.x; i < n_chunks * CI; i += kBlock) {
+                    s_aff[i] = i < Cin ? in_scale[i] : 0.f;
+                    s_aff[n_chunks * CI + i] = i < Cin ? in_shift[i] : 0.f;
+                }
+        }
+    }
+    auto pf_load = [&](int chunk) {
+        if constexpr (PIPE_OK) {
+            const float* xc = xin + (size_t)chunk * CI * HW;                       // uniform
+            const float* wc = wbase + (size_t)chunk * W_ROWS * cobp_pack;        // uniform
+            const int ci_left = Cin - chunk * CI;                                 // channels of this chunk that exist
+#pragma unroll
+            for (int q = 0; q < PF_IN; ++q) {
+                const int i = threadIdx.x + q * kBlock;
+                const int cc = VEC_IN ? i / (ROWS * (RS / 4)) : i / (ROWS * RS);
+                const bool ok = in_off[q] >= 0 && cc < ci_left;
+                if constexpr (VEC_IN) pf_in4[q] = ok ? *reinterpret_cast<const float4*>(xc + in_off[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else pf_in1[q] = ok ? xc[in_off[q]] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < PF_W; ++q)
+                pf_w[q] = w_off[q] >= 0 ? *reinterpret_cast<const float4*>(wc + w_off[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto pf_store = [&]() {
+    auto pf_store = [&](int chunk) {
+        if constexpr (PIPE_OK) {
+            const int ci_left = Cin - chunk * CI;
 #pragma unroll
-        for (int q = 0; q < PF_IN; ++q) {
-            const int i = threadIdx.x + q * kBlock;
-            if (i < CI * ROWS * (RS / 4)) {
-                const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
-                const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
-                *reinterpret_cast<float4*>(s_in + cc * PS + r * RS + c) = pf_in[q];
+            for (int q = 0; q < PF_IN; ++q) {
+                const int i = threadIdx.x + q * kBlock;
+                if (i < IN_ELEMS) {
+                    const int cc = VEC_IN ? i / (ROWS * (RS / 4)) : i / (ROWS * RS);
+                    const bool live = in_off[q] >= 0 && cc < ci_left;   // zero padding stays zero
+                    float sc = 1.f, sh = 0.f;
+                    if (in_scale) { sc = s_aff[chunk * CI + cc]; sh = s_aff[n_chunks * CI + chunk * CI + cc]; }
+                    if constexpr (VEC_IN) {
+                        float4 v = pf_in4[q];
+                        if (live) {
+                            if (in_scale) { v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
+                            if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        }
+                        *reinterpret_cast<float4*>(s_in + in_lds4(i)) = v;
+                    } else {
+                        float v = pf_in1[q];
+                        if (live) {
+                            if (in_scale) v = __fmaf_rn(v, sc, sh);
+                            if (in_relu) v = fmaxf(v, 0.f);
+                        }
+                        s_in[in_lds1(i)] = v;
+                    }
+                }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < PF_W; ++q) {
-            const int i = (threadIdx.x + q * kBlock) * 4;
-            if (i < W_ELEMS) *reinterpret_cast<float4*>(s_w + i) = pf_w[q];
+            for (int q = 0; q < PF_W; ++q) {
+                const int i = threadIdx.x + q * kBlock;
+                if (i < W_ROWS * ROW4) *reinterpret_cast<float4*>(s_w + w_lds(i)) = pf_w[q];
+            }
         }
     };
     if (pipelined) pf_load(0);
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        __syncthreads();  // previous round's fragments are consumed
+        __syncthreads();  // previous round's fragments are consumed (and, first round, s_aff is written)
         if (pipelined) {
-            pf_store();
+            pf_store(chunk);
             if (chunk + 1 < n_chunks) pf_load(chunk + 1);
-            __syncthreads();
         } else {
-        // ---- stage the input tile (zero padding, fused BN-apply + ReLU of the producer)
-        if (KS == 1 && (W & 3) == 0) {
-            // 1x1: no halo, tile rows are 32 contiguous pixels -> 16-byte loads
-            for (int i = threadIdx.x; i < CI * ROWS * (RS / 4); i += kBlock) {
-                const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
-                const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
-                const int ci = chunk * CI + cc, gy = Y0 + r, gx = X0 + c;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci < Cin && gy < H && gx < W) {
-                    v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
-                    if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
-                    if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                }
-                *reinterpret_cast<float4*>(s_in + cc * PS + r * RS + c) = v;
+            // ---- stage the input tile (zero padding, fused BN-apply + ReLU of the producer) and the filter slice
+            if (vec_in) {
+                for (int i = threadIdx.x; i < IN_ELEMS; i += kBlock) *reinterpret_cast<float4*>(s_in + in_lds4(i)) = in_load4(chunk, i);
+            } else {
+                for (int i = threadIdx.x; i < CI * ROWS * RS; i += kBlock) s_in[in_lds1(i)] = in_load1(chunk, i, P);
             }
-        } else
-        for (int i = threadIdx.x; i < CI * ROWS * RS; i += kBlock) {
-            const int cc = i / (ROWS * RS), rem = i - cc * (ROWS * RS);
-            const int r = rem / RS, c = rem - r * RS;
-            const int ci = chunk * CI + cc, gy = Y0 - P + r, gx = X0 - P + c;
-            float v = 0.f;
-            if (ci < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                v = xin[(size_t)ci * HW + (size_t)gy * W + gx];
-                if (in_scale) v = __fmaf_rn(v, in_scale[ci], in_shift[ci]);  // same fma as the BN backward's mask
-                if (in_relu) v = fmaxf(v, 0.f);
-            }
-            s_in[cc * PS + r * RS + c] = v;
+            const float* wc = wbase + (size_t)chunk * W_ROWS * cobp_pack;
+            for (int i = threadIdx.x; i < W_ROWS * ROW4; i += kBlock)
+                *reinterpret_cast<float4*>(s_w + w_lds(i)) = *reinterpret_cast<const float4*>(wc + w_src(i));
         }
-        // ---- stage this chunk's packed weights (one contiguous block)
-        const float* wsrc = wpk + ((size_t)grp * n_chunks + chunk) * W_ELEMS;
-        for (int i = threadIdx.x * 4; i < W_ELEMS; i += kBlock * 4)
-            *reinterpret_cast<float4*>(s_w + i) = *reinterpret_cast<const float4*>(wsrc + i);
         __syncthreads();
-        }
 
         // ---- MFMA over (channel quad, tap)
 #pragma unroll
@@ -218,10 +299,11 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
 
     // ---- epilogue: bias, store, batch statistics of the raw output
     const int co_l = lane & 15, px4 = (lane >> 4) * 4;
+    const int co_base = grp * (nsub * COB) + sub * COB;
     float* yout = y + ((size_t)n * y_ctot + y_coff) * HW;
 #pragma unroll
     for (int t = 0; t < CO_T; ++t) {
-        const int co = grp * COB + t * 16 + co_l;
+        const int co = co_base + t * 16 + co_l;
         const float bv = (bias != nullptr && co < Cout) ? bias[co] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -262,23 +344,29 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     }
 }
 
+// pack_cot = co tiles per packed group (the filter's layout), CO_T = co tiles per block (<= pack_cot, divides it)
 template <int KS, int CO_T, int TYP>
-static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wpk, const float* bias,
+static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wpk, int pack_cot, const float* bias,
                          const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff,
-                         int Cout, double* stats, int accumulate, int N, int H, int W, hipStream_t s) {
+                         int Cout, double* stats, int accumulate, int N, int H, int W, int pipe, hipStream_t s) {
     using Cfg = ConvCfg<KS, TYP>;
     constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
     const int tiles_x = (W + CV_TX - 1) / CV_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
-    const int groups = (Cout + COB - 1) / COB;
-    const size_t lds = sizeof(float) * ((size_t)Cfg::CI_CHUNK * Cfg::PS + (size_t)KS * KS * Cfg::CI_CHUNK * COBP);
+    const int pack_cob = pack_cot * 16, groups = (Cout + pack_cob - 1) / pack_cob, nsub = pack_cot / CO_T;
+    const int n_chunks = (Cin + Cfg::CI_CHUNK - 1) / Cfg::CI_CHUNK;
+    const size_t lds = sizeof(float) * ((size_t)Cfg::CI_CHUNK * Cfg::PS + (size_t)KS * KS * Cfg::CI_CHUNK * COBP + 2 * (size_t)n_chunks * Cfg::CI_CHUNK);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<KS, CO_T, TYP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T, TYP>), dim3(tiles_x * tiles_y, groups, N), dim3(kBlock), lds, s, x, x_ctot,
-                       x_coff, Cin, wpk, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, H, W, tiles_x);
+    if (lds > 160 * 1024 || nsub < 1 || nsub * CO_T != pack_cot) return CD_ERR_UNSUPPORTED;
+    // sub-slices whose first channel is already past Cout have nothing to do: trim the last group's tail
+    const int live = (Cout + COB - 1) / COB;   // live (group, sub) slices over all groups, in channel order
+    const int gy = groups * nsub < live ? groups * nsub : live;
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T, TYP>), dim3(tiles_x * tiles_y, gy, N), dim3(kBlock), lds, s, x, x_ctot,
+                       x_coff, Cin, wpk, co_stride_padded(pack_cob), nsub, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff,
+                       Cout, stats, accumulate, H, W, tiles_x, pipe);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -289,6 +377,26 @@ __host__ __device__ static inline int pick_co_tiles(int ks, int cout) {
     int t = need < cap ? need : cap;
     if (t == 3) t = 4;
     return t < 1 ? 1 : t;
+}
+
+// (tile rows, co tiles per block) for one launch when the caller does not say (cd_conv2d_fwd_cfg lets a caller that
+// has timed the candidates choose -- the hourglass engine does, once per distinct shape).  Rules read off
+// tools/conv_sweep.py on the hourglass shapes (profiles/conv_sweep_r01.txt): large images want tall tiles and wide
+// channel slices (operand reuse); from 96x56 down there are too few tiles to fill 256 CUs, so a block takes
+// a single 16-channel slice and a short tile.
+static inline void pick_conv_tile(int ks, int pack_cot, int N, int H, int W, int* ty_out, int* cot_out) {
+    const long long px = (long long)N * H * W;
+    const long long L1 = 8LL * 192 * 112, L2 = 8LL * 96 * 56, L3 = 8LL * 48 * 28;
+    int ty, cot;
+    if (ks == 1) {
+        cot = px > L1 ? pack_cot : (px > L3 ? (pack_cot < 2 ? pack_cot : 2) : 1);
+        ty = px > L3 ? 8 : 4;
+    } else {
+        cot = px > L2 ? (pack_cot < 2 ? pack_cot : 2) : 1;
+        ty = px > L2 ? ((ks == 7) ? 8 : 16) : (px > L3 ? 8 : 4);
+    }
+    *ty_out = ty;
+    *cot_out = cot;
 }
 
 // All filters of a network in ONE launch: blockIdx.y selects the descriptor, blockIdx.x grid-strides the elements
@@ -328,13 +436,24 @@ __global__ void pack_weights_table_kernel(const PackDesc* __restrict__ table) {
 
 }  // namespace cd
 
-namespace cd { static int g_force_conv_ty = 0; }
+namespace cd { static int g_force_conv_ty = 0, g_force_conv_cot = 0, g_conv_pipe = 1; }
 
 extern "C" {
 
 int cd_debug_force_conv_tile_rows(int ty) {
     if (!(ty == 0 || ty == 4 || ty == 8 || ty == 16)) return CD_ERR_INVALID_ARG;
     cd::g_force_conv_ty = ty;
+    return CD_OK;
+}
+
+int cd_debug_force_conv_co_tiles(int cot) {
+    if (!(cot == 0 || cot == 1 || cot == 2 || cot == 4)) return CD_ERR_INVALID_ARG;
+    cd::g_force_conv_cot = cot;
+    return CD_OK;
+}
+
+int cd_debug_set_conv_pipeline(int on) {
+    cd::g_conv_pipe = on ? 1 : 0;
     return CD_OK;
 }
 
@@ -368,21 +487,24 @@ int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream) {
     return CD_OK;
 }
 
-int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w, const float* bias,
+int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w, const float* bias,
                   const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout,
-                  double* stats, int accumulate, int N, int H, int W, int ks, void* stream) {
+                  double* stats, int accumulate, int N, int H, int W, int ks, int tile_rows, int co_tiles, void* stream) {
     if (!x || !packed_w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD_ERR_INVALID_ARG;
     if (x_coff < 0 || x_coff + Cin > x_ctot || y_coff < 0 || y_coff + Cout > y_ctot) return CD_ERR_INVALID_ARG;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return CD_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int cot = cd::pick_co_tiles(ks, Cout);
-    // tile height: the tallest tile that still yields enough blocks to fill 256 CUs (the deep hourglass levels
-    // are only 96x56 ... 24x14 pixels)
-    const int groups = (Cout + cot * 16 - 1) / (cot * 16), tiles_x = (W + cd::CV_TX - 1) / cd::CV_TX;
-    int ty = ks >= 7 ? 16 : 8;
-    while (ty > 4 && (long long)tiles_x * ((H + ty - 1) / ty) * groups * N < 640) ty >>= 1;
+    const int pack_cot = cd::pick_co_tiles(ks, Cout);
+    if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16)) return CD_ERR_INVALID_ARG;
+    if (!(co_tiles == 0 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4)) return CD_ERR_INVALID_ARG;
+    int ty, cot;
+    cd::pick_conv_tile(ks, pack_cot, N, H, W, &ty, &cot);
+    if (tile_rows) ty = tile_rows;
+    if (co_tiles) cot = co_tiles < pack_cot ? co_tiles : pack_cot;
     if (cd::g_force_conv_ty) ty = cd::g_force_conv_ty;
-#define CD_CONV(K, T, Y) return cd::launch_conv_t<K, T, Y>(x, x_ctot, x_coff, Cin, packed_w, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
+    if (cd::g_force_conv_cot && cd::g_force_conv_cot <= pack_cot) cot = cd::g_force_conv_cot;
+    const int pipe = cd::g_conv_pipe;
+#define CD_CONV(K, T, Y) return cd::launch_conv_t<K, T, Y>(x, x_ctot, x_coff, Cin, packed_w, pack_cot, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, pipe, s)
 #define CD_CONV_T(K, T)                     \
     {                                       \
         if (ty == 16) CD_CONV(K, T, 16);    \
@@ -402,5 +524,14 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
 #undef CD_CONV
     return CD_ERR_UNSUPPORTED;
 }
+
+int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w, const float* bias,
+                  const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout,
+                  double* stats, int accumulate, int N, int H, int W, int ks, void* stream) {
+    return cd_conv2d_fwd_cfg(x, x_ctot, x_coff, Cin, packed_w, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats,
+                             accumulate, N, H, W, ks, 0, 0, stream);
+}
+
+int cd_conv2d_packed_co_tiles(int Cout, int ks) { return cd::pick_co_tiles(ks, Cout); }
 
 }  // extern "C"

@@ -74,12 +74,18 @@ class ConvUnit:
                        scale=bn_mod.weight if affine else None, shift=bn_mod.bias if affine else None, needs_grad=False)
         self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
         self.pk, self.pkT = eng.packed(conv_mod)
+        # launch shapes, timed once per distinct convolution shape (ops/conv.py::tuned_config)
+        N, _, H, W = dst_buf.shape
+        self.cfg_f = C.tuned_config(self.ks, self.cin, self.cout, N, H, W, dst_buf.device, affine_in=src.scale is not None,
+                                    relu_in=src.relu, stats=bn_mod is not None, x_ctot=src.buf.shape[1], y_ctot=dst_buf.shape[1])
+        self.cfg_d = C.tuned_config(self.ks, self.cout, self.cin, N, H, W, dst_buf.device, accumulate=True,
+                                    x_ctot=dst_buf.shape[1], y_ctot=src.buf.shape[1])
 
     def forward(self, training):
         s = self.src
         C.conv2d(s.buf, self.pk, self.cin, self.cout, self.ks, bias=self.conv.bias, x_coff=s.coff, out=self.dst_buf,
                  y_coff=self.dst_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu,
-                 stats=self.stats.view(-1) if (self.bn is not None and training) else None)
+                 stats=self.stats.view(-1) if (self.bn is not None and training) else None, cfg=self.cfg_f)
         if self.bn is not None:
             if training:
                 L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS, self.bn.running_mean,
@@ -107,7 +113,7 @@ class ConvUnit:
                        dy_coff=g_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
         if s.gbuf is not None:
             C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
-                     accumulate=s.grad_mode())
+                     accumulate=s.grad_mode(), cfg=self.cfg_d)
 
 
 class _Member:
@@ -132,6 +138,11 @@ class PointwiseGroup:
         self._filt, self._filtT = filt, filtT
         self._bias = torch.empty(self.ctot, device=P.device)
         self._bias_versions = None
+        N, _, H, W = P.shape
+        self.cfg_f = C.tuned_config(1, self.cin, self.ctot, N, H, W, P.device, affine_in=src.scale is not None, relu_in=src.relu,
+                                    stats=True, x_ctot=src.buf.shape[1], y_ctot=P.shape[1])
+        self.cfg_d = C.tuned_config(1, self.ctot, self.cin, N, H, W, P.device, accumulate=True, x_ctot=Pg.shape[1],
+                                    y_ctot=src.buf.shape[1])
 
     def _fused_bias(self):
         v = tuple((m.conv.bias.data_ptr(), m.conv.bias._version) for m in self.members)
@@ -143,7 +154,8 @@ class PointwiseGroup:
     def forward(self, training):
         s, pk = self.src, self.eng._pack.view(self._filt)
         C.conv2d(s.buf, pk, self.cin, self.ctot, 1, bias=self._fused_bias(), x_coff=s.coff, out=self.P, y_coff=0,
-                 in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, stats=self.stats.view(-1) if training else None)
+                 in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, stats=self.stats.view(-1) if training else None,
+                 cfg=self.cfg_f)
         cnt = float(self.P.shape[0] * self.P.shape[2] * self.P.shape[3])
         for m in self.members:
             if training:
@@ -165,7 +177,7 @@ class PointwiseGroup:
             _grad_of(m.conv.weight).copy_(self._dw[m.coff:m.coff + m.cout])
         if s.gbuf is not None:
             C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
-                     accumulate=s.grad_mode())
+                     accumulate=s.grad_mode(), cfg=self.cfg_d)
 
 
 def _grad_of(p: torch.nn.Parameter) -> torch.Tensor:

@@ -3,6 +3,8 @@ Tensors are NCHW fp32 on the HIP device; `(tensor, channel offset)` pairs addres
 of concat buffers in place."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _native
@@ -25,8 +27,9 @@ def pack_weights(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
 
 
 def conv2d(x, packed_w, Cin, Cout, ks, bias=None, x_coff=0, out=None, y_coff=0, in_scale=None, in_shift=None,
-           in_relu=False, stats=None, accumulate=False):
-    """out[:, y_coff:y_coff+Cout] = conv(act(x[:, x_coff:x_coff+Cin])) + bias.  Returns `out`."""
+           in_relu=False, stats=None, accumulate=False, cfg=None):
+    """out[:, y_coff:y_coff+Cout] = conv(act(x[:, x_coff:x_coff+Cin])) + bias.  Returns `out`.
+    cfg = (tile_rows, co_tiles) launch shape (see `tuned_config`); None = the library's heuristic."""
     N, x_ctot, H, W = x.shape
     if out is None:
         out = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
@@ -34,12 +37,66 @@ def conv2d(x, packed_w, Cin, Cout, ks, bias=None, x_coff=0, out=None, y_coff=0, 
     opt = lambda t, name: _native.dev_ptr(t, name) if t is not None else None  # noqa: E731
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.is_cuda and stats.is_contiguous() and stats.numel() == 2 * y_ctot
-    rc = _native.lib().cd_conv2d_fwd(
+    ty, cot = cfg if cfg is not None else (0, 0)
+    rc = _native.lib().cd_conv2d_fwd_cfg(
         _native.dev_ptr(x, "x"), x_ctot, x_coff, Cin, _native.dev_ptr(packed_w, "packed_w"), opt(bias, "bias"),
         opt(in_scale, "in_scale"), opt(in_shift, "in_shift"), int(in_relu), _native.dev_ptr(out, "out"), y_ctot, y_coff,
-        Cout, stats.data_ptr() if stats is not None else None, int(accumulate), N, H, W, ks, _native.stream_ptr(x.device))
-    _native.check(rc, "cd_conv2d_fwd")
+        Cout, stats.data_ptr() if stats is not None else None, int(accumulate), N, H, W, ks, ty, cot,
+        _native.stream_ptr(x.device))
+    _native.check(rc, "cd_conv2d_fwd_cfg")
     return out
+
+
+_TUNED = {}
+
+
+def autotune_enabled() -> bool:
+    return os.environ.get("CD_AMD_CONV_AUTOTUNE", "1") != "0"
+
+
+def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=False, stats=False, accumulate=False,
+                 x_ctot=None, y_ctot=None, iters=3):
+    """(tile_rows, co_tiles) of the fastest launch shape for this convolution, measured once per distinct
+    (shape, fusion flags) on scratch tensors with HIP events and cached for the life of the process -- the
+    result of the convolution does not depend on the choice.  Returns None (library heuristic) when disabled."""
+    if not autotune_enabled():
+        return None
+    x_ctot, y_ctot = x_ctot or Cin, y_ctot or Cout
+    key = (ks, Cin, Cout, N, H, W, bool(affine_in), bool(relu_in), bool(stats), bool(accumulate), x_ctot, y_ctot)
+    if key in _TUNED:
+        return _TUNED[key]
+    dev = torch.device(device)
+    x = torch.randn(N, x_ctot, H, W, device=dev)
+    out = torch.zeros(N, y_ctot, H, W, device=dev)
+    pk = torch.randn(_native.lib().cd_conv2d_packed_weight_floats(Cout, Cin, ks, 0), device=dev) * 0.05
+    sc = torch.rand(Cin, device=dev) + 0.5 if affine_in else None
+    sh = torch.randn(Cin, device=dev) * 0.1 if affine_in else None
+    st = torch.zeros(2 * y_ctot, dtype=torch.float64, device=dev) if stats else None
+    max_cot = _native.lib().cd_conv2d_packed_co_tiles(Cout, ks)
+    best, best_t = None, float("inf")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for ty in (4, 8, 16):
+        for cot in (1, 2, 4):
+            if cot > max_cot:
+                continue
+
+            def run():
+                conv2d(x, pk, Cin, Cout, ks, out=out, in_scale=sc, in_shift=sh, in_relu=relu_in, stats=st,
+                       accumulate=accumulate, cfg=(ty, cot))
+            try:
+                run()
+            except RuntimeError:      # launch shape not available for this filter (LDS budget)
+                continue
+            e0.record()
+            for _ in range(iters):
+                run()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = (ty, cot), t
+    _TUNED[key] = best
+    return best
 
 
 def wgrad_workspace_floats(Cout, Cin, ks) -> int:

@@ -87,3 +87,54 @@ def test_dgrad_is_conv_with_transposed_filter(Cin, Cout, ks):
     pk = conv.pack_weights(w.float().cuda(), transposed=True)
     dx = conv.conv2d(dy.float().cuda(), pk, Cout, Cin, ks)
     assert (dx.cpu().double() - x.grad).abs().max().item() < 2e-5 * x.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [(2, 40, 56, 20, 36, 7), (2, 24, 64, 12, 20, 5), (2, 64, 48, 17, 33, 3),
+                                               (2, 100, 64, 16, 40, 1), (1, 36, 30, 24, 36, 1), (1, 20, 16, 24, 40, 11)])
+def test_launch_shapes_are_bit_identical(N, Cin, Cout, H, W, ks, pipe):
+    """Every (tile rows, co tiles per workgroup) launch shape, with and without the register-prefetch pipeline, with
+    the fused input transform, the statistics epilogue and gradient accumulation, produces the same bits (the order
+    of accumulation over (channel chunk, tap) is fixed) -- the licence for timing-based autotuning."""
+    import torch
+    from consistent_depth_amd import _native
+    from consistent_depth_amd.ops import conv
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(ks * 77 + Cin)
+    x = torch.randn(N, Cin + 5, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), torch.randn(Cin, generator=g).cuda()
+    base = torch.randn(N, Cout + 3, H, W, generator=g).cuda()
+    pk = conv.pack_weights(w)
+    max_cot = lib.cd_conv2d_packed_co_tiles(Cout, ks)
+    ref = _ref(torch.relu(x[:, 2:2 + Cin].cpu() * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)), w.cpu(), b.cpu(), ks)
+    outs = []
+    try:
+        lib.cd_debug_set_conv_pipeline(pipe)
+        for ty in (4, 8, 16):
+            for cot in (1, 2, 4):
+                if cot > max_cot:
+                    continue
+                out = base.clone()
+                stats = torch.zeros(2 * (Cout + 3), dtype=torch.float64, device="cuda")
+                conv.conv2d(x, pk, Cin, Cout, ks, bias=b, x_coff=2, out=out, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True,
+                            stats=stats, accumulate=True, cfg=(ty, cot))
+                outs.append(((ty, cot), out, stats))
+    finally:
+        lib.cd_debug_set_conv_pipeline(1)
+    (_, o0, s0) = outs[0]
+    got = (o0[:, 1:1 + Cout] - base[:, 1:1 + Cout]).cpu().double()
+    assert (got - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(o0[:, :1], base[:, :1]) and torch.equal(o0[:, 1 + Cout:], base[:, 1 + Cout:])
+    for cfg, o, s in outs[1:]:
+        assert torch.equal(o, o0), cfg
+        torch.testing.assert_close(s, s0, rtol=1e-12, atol=1e-9)
+
+
+def test_autotuner_returns_a_valid_cached_launch_shape():
+    from consistent_depth_amd.ops import conv
+    cfg = conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True)
+    assert cfg is not None and cfg[0] in (4, 8, 16) and cfg[1] in (1, 2, 4)
+    assert conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True) is cfg or \
+        conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True) == cfg

@@ -1,17 +1,37 @@
 #!/usr/bin/env python3
-"""Top kernels by total time from a rocprofv3 kernel trace (rocpd sqlite) of bench.py."""
+"""Top kernels by total time from a rocprofv3 kernel trace (rocpd sqlite) of bench.py.
+
+    python tools/prof_step_summary.py gpurun_out/prof_<tag> [steps] [--by-grid]
+
+With --by-grid the rows are (kernel, grid, workgroup) so that every layer shape shows up separately.
+"""
 import glob
 import os
 import sqlite3
 import sys
 
 root = sys.argv[1]
+by_grid = "--by-grid" in sys.argv
+nums = [a for a in sys.argv[2:] if a.isdigit()]
+steps = int(nums[0]) if nums else None
 db = sorted(glob.glob(os.path.join(root, "trace", "**", "*.db"), recursive=True))[0]
 c = sqlite3.connect(db)
-rows = c.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc").fetchall()
+grp = "name, grid_x, grid_y, grid_z, workgroup_x" if by_grid else "name"
+sel = "name, count(*), sum(duration), avg(duration)" + (", grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count" if by_grid else "")
+rows = c.execute(f"select {sel} from kernels group by {grp} order by sum(duration) desc").fetchall()
 total = sum(r[2] for r in rows)
 t0, t1 = c.execute("select min(start), max(end) from kernels").fetchone()
-print(f"kernel time total {total / 1e6:.2f} ms over {sum(r[1] for r in rows)} launches; trace span {(t1 - t0) / 1e6:.2f} ms")
-for name, n, tot, avg in rows[:28]:
-    short = name.split("(")[0].replace("void ", "")[-78:]
-    print(f"  {short:78s} n={n:6d} total_ms={tot / 1e6:9.3f} ({100 * tot / total:5.1f}%) avg_us={avg / 1e3:9.2f}")
+print(f"kernel time total {total / 1e6:.2f} ms over {sum(r[1] for r in rows)} launches; trace span {(t1 - t0) / 1e6:.2f} ms"
+      + (f"; per step (/{steps}): {total / 1e6 / steps:.2f} ms" if steps else ""))
+for r in rows[:(70 if by_grid else 28)]:
+    name, n, tot, avg = r[:4]
+    short = name.split("(")[0].replace("void ", "").replace("cd::", "")
+    if "<" in name.split("(")[0]:
+        short = name[:name.index("(")].replace("void ", "").replace("cd::", "")
+    short = short[-60:]
+    extra = ""
+    if by_grid:
+        gx, gy, gz, wx, lds, vg = r[4:]
+        extra = f" blocks=({gx // max(wx, 1)},{gy},{gz}) wg={wx} lds={lds} vgpr={vg}"
+    per = f" per_step_ms={tot / 1e6 / steps:7.3f}" if steps else ""
+    print(f"  {short:60s} n={n:6d} total_ms={tot / 1e6:9.3f} ({100 * tot / total:5.1f}%) avg_us={avg / 1e3:9.2f}{per}{extra}")
