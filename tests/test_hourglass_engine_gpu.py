@@ -61,9 +61,16 @@ def test_engine_matches_autograd(N, H, W):
     med = sorted(e for e, _, _ in errs)[len(errs) // 2]
     med32 = sorted(e for _, e, _ in errs)[len(errs) // 2]
     print(f"  median engine {med:.2e}  median torch-fp32 {med32:.2e}  (N={N}, {H}x{W})")
-    # the engine must be in the same noise class as fp32 autograd: within 4x of it per parameter (+ floor)
+    # The engine must be in the same noise class as fp32 autograd.  At random init this network is chaotic in the
+    # ReLU masks (train-mode BN, ~100 layers): a forward round-off of 1e-6 flips a few masks and moves single
+    # parameter gradients by up to ~1e-3, for autograd and the engine alike but not on the same parameters.  So:
+    # nearly every parameter within 4x of autograd's own error, none beyond 4x / 3e-3 (a wrong tap, scale or mask
+    # convention shows up as >= 1e-1), and the medians within 2x.
+    within = [e < max(4 * e32, 2e-4) for e, e32, _ in errs]
+    assert sum(within) >= 0.95 * len(within), [(n, e, e32) for (e, e32, n), ok in zip(errs, within) if not ok][:8]
     for e, e32, name in errs:
-        assert e < max(4 * e32, 2e-4), (name, e, e32)
+        assert e < max(4 * e32, 3e-3), (name, e, e32)
+    assert med < 2 * med32 + 1e-4, (med, med32)
     # BatchNorm running statistics follow nn.BatchNorm2d
     sd_ref, sd = ref.state_dict(), net.state_dict()
     for k in sd_ref:
