@@ -12,7 +12,8 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
+BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 
 _lib = None
 

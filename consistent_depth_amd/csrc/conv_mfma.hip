@@ -301,13 +301,14 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     const int co_l = lane & 15, px4 = (lane >> 4) * 4;
     const int co_base = grp * (nsub * COB) + sub * COB;
     float* yout = y + ((size_t)n * y_ctot + y_coff) * HW;
+    // statistics partials in double: the sums must not depend on how the launch shape groups the pixels
+    // (fp32 partials differ at 1e-7 between tile shapes, which a deep train-mode-BN network amplifies)
+    double s1[CO_T], s2[CO_T];
 #pragma unroll
     for (int t = 0; t < CO_T; ++t) {
         const int co = co_base + t * 16 + co_l;
         const float bv = (bias != nullptr && co < Cout) ? bias[co] : 0.f;
-        // statistics partials in double: the sums must not depend on how the launch shape groups the pixels
-        // (fp32 partials differ at 1e-7 between tile shapes, which a deep train-mode-BN network amplifies)
-        double s1 = 0.0, s2 = 0.0;
+        s1[t] = 0.0; s2[t] = 0.0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int gy = Y0 + wid * RPW + (m >> 1), gx = X0 + (m & 1) * 16 + px4;
@@ -323,8 +324,8 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
                     *reinterpret_cast<float4*>(dst) = make_float4(v.x, v.y, v.z, v.w);
                     if (stats != nullptr) {
                         const double a = v.x, b = v.y, c = v.z, d = v.w;
-                        s1 += (a + b) + (c + d);
-                        s2 += (a * a + b * b) + (c * c + d * d);
+                        s1[t] += (a + b) + (c + d);
+                        s2[t] += (a * a + b * b) + (c * c + d * d);
                     }
                 } else {
                     float e[4] = {v.x, v.y, v.z, v.w};
@@ -332,18 +333,35 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
                     for (int q = 0; q < 4; ++q)
                         if (gx + q < W) {
                             if (accumulate) e[q] += dst[q];
-                            dst[q] = e[q]; s1 += (double)e[q]; s2 += (double)e[q] * (double)e[q];
+                            dst[q] = e[q]; s1[t] += (double)e[q]; s2[t] += (double)e[q] * (double)e[q];
                         }
                 }
             }
         }
-        if (stats != nullptr) {  // block-uniform
-            // lanes l, l+16, l+32, l+48 hold the same channel
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 16 && co < Cout) {
-                atomicAdd(&stats[2 * (y_coff + co)], s1);
-                atomicAdd(&stats[2 * (y_coff + co) + 1], s2);
+    }
+    if (stats != nullptr) {  // block-uniform
+        // Same-address fp64 atomics serialise in the memory system (~50 ns each, measured), so: reduce over the lanes
+        // and the 4 waves of the block first (LDS), then ONE atomic pair per channel per block, spread over
+        // CD_BN_STAT_SLOTS copies of the statistics that the BatchNorm kernels sum.
+        __syncthreads();   // the MFMA operands in LDS are dead: reuse the front of it
+        double* red = reinterpret_cast<double*>(smem);   // [4 waves][COB][2]
+#pragma unroll
+        for (int t = 0; t < CO_T; ++t) {
+            double a = s1[t], b = s2[t];   // lanes l, l+16, l+32, l+48 hold the same channel
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            if (lane < 16) { red[(wid * COB + t * 16 + co_l) * 2] = a; red[(wid * COB + t * 16 + co_l) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        if (threadIdx.x < COB) {
+            const int co = co_base + threadIdx.x;
+            if (co < Cout) {
+                const double a = (red[threadIdx.x * 2] + red[(COB + threadIdx.x) * 2]) + (red[(2 * COB + threadIdx.x) * 2] + red[(3 * COB + threadIdx.x) * 2]);
+                const double b = (red[threadIdx.x * 2 + 1] + red[(COB + threadIdx.x) * 2 + 1]) + (red[(2 * COB + threadIdx.x) * 2 + 1] + red[(3 * COB + threadIdx.x) * 2 + 1]);
+                const int slot = (blockIdx.x + 5 * blockIdx.z) & (CD_BN_STAT_SLOTS - 1);
+                double* st = stats + ((size_t)slot * y_ctot + y_coff + co) * 2;
+                atomicAdd(st, a);
+                atomicAdd(st + 1, b);
             }
         }
     }

@@ -17,7 +17,8 @@ __device__ __forceinline__ float act(float v, const float* sc, const float* sh, 
 }
 
 // ---------------------------------------------------------------- BatchNorm (train) forward
-// stats[c] = (sum, sumsq) of the raw conv output over N*H*W (accumulated by the conv epilogue).
+// stats[slot][c] = partial (sum, sumsq) of the raw conv output over N*H*W (accumulated by the conv epilogue into
+// CD_BN_STAT_SLOTS copies to keep same-address atomics apart; summed here in slot order).
 // In place: x <- (x - mean) * rsqrt(var + eps); saves (mean, invstd); updates the running stats like
 // nn.BatchNorm2d(momentum): running_var uses the unbiased variance.
 __global__ __launch_bounds__(kBlock) void bn_normalize_kernel(float* __restrict__ x, int ctot, int coff,
@@ -26,8 +27,13 @@ __global__ __launch_bounds__(kBlock) void bn_normalize_kernel(float* __restrict_
                                                               float* __restrict__ running_var, float momentum,
                                                               float* __restrict__ mean_invstd, int HW) {
     const int c = blockIdx.y, n = blockIdx.z;
-    const double mean_d = stats[2 * (coff + c)] / count;
-    double var_d = stats[2 * (coff + c) + 1] / count - mean_d * mean_d;
+    double sum = 0.0, sumsq = 0.0;
+    for (int s = 0; s < CD_BN_STAT_SLOTS; ++s) {   // fixed order
+        sum += stats[((size_t)s * ctot + coff + c) * 2];
+        sumsq += stats[((size_t)s * ctot + coff + c) * 2 + 1];
+    }
+    const double mean_d = sum / count;
+    double var_d = sumsq / count - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var_d + (double)eps));
     if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
@@ -56,14 +62,19 @@ __global__ __launch_bounds__(kBlock) void bn_normalize_kernel(float* __restrict_
 //   scale = gamma * invstd,  shift = beta - gamma * mean * invstd     (gamma = 1, beta = 0 when not affine)
 // so that consumers evaluate relu(raw * scale + shift) while loading the RAW conv output; also saves
 // (mean, invstd) for the backward and updates the running statistics.  One thread per channel.
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int coff, int C, double count, float eps,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int ctot, int coff, int C, double count, float eps,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                    float* __restrict__ mean_invstd, float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean_d = stats[2 * (coff + c)] / count;
-    double var_d = stats[2 * (coff + c) + 1] / count - mean_d * mean_d;
+    double sum = 0.0, sumsq = 0.0;
+    for (int s = 0; s < CD_BN_STAT_SLOTS; ++s) {
+        sum += stats[((size_t)s * ctot + coff + c) * 2];
+        sumsq += stats[((size_t)s * ctot + coff + c) * 2 + 1];
+    }
+    const double mean_d = sum / count;
+    double var_d = sumsq / count - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var_d + (double)eps));
     mean_invstd[2 * (coff + c)] = mean;
@@ -295,7 +306,7 @@ int cd_bn_finalize(const double* stats, int ctot, int coff, int C, double count,
                    float* scale, float* shift, void* stream) {
     CD_ARGCHK(stats && mean_invstd && scale && shift && C > 0 && coff >= 0 && coff + C <= ctot && count > 0);
     CD_ARGCHK((running_mean == nullptr) == (running_var == nullptr) && (gamma == nullptr) == (beta == nullptr));
-    hipLaunchKernelGGL(cd::bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, coff, C, count, eps,
+    hipLaunchKernelGGL(cd::bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, ctot, coff, C, count, eps,
                        gamma, beta, running_mean, running_var, momentum, mean_invstd, scale, shift);
     CD_CHECK_LAUNCH();
     return CD_OK;

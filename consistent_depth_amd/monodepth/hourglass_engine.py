@@ -93,8 +93,8 @@ class ConvUnit:
             else:  # eval: normalise with the running statistics (synthesised sums; nothing is updated)
                 cnt = float(self.dst_buf.shape[0] * self.dst_buf.shape[2] * self.dst_buf.shape[3])
                 rm, rv = self.bn.running_mean.double(), self.bn.running_var.double()
-                self.stats[self.dst_coff:self.dst_coff + self.cout, 0] = rm * cnt
-                self.stats[self.dst_coff:self.dst_coff + self.cout, 1] = (rv + rm * rm) * cnt
+                self.stats[0, self.dst_coff:self.dst_coff + self.cout, 0] = rm * cnt   # slot 0; the others stay zero
+                self.stats[0, self.dst_coff:self.dst_coff + self.cout, 1] = (rv + rm * rm) * cnt
                 L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS)
 
     def backward(self, gbuf, g_coff):
@@ -163,8 +163,8 @@ class PointwiseGroup:
                                BN_MOMENTUM)
             else:
                 rm, rv = m.bn.running_mean.double(), m.bn.running_var.double()
-                self.stats[m.coff:m.coff + m.cout, 0] = rm * cnt
-                self.stats[m.coff:m.coff + m.cout, 1] = (rv + rm * rm) * cnt
+                self.stats[0, m.coff:m.coff + m.cout, 0] = rm * cnt
+                self.stats[0, m.coff:m.coff + m.cout, 1] = (rv + rm * rm) * cnt
                 L.bn_normalize(self.P, m.coff, m.cout, self.stats, self.mi, BN_EPS)
 
     def backward(self):
@@ -280,12 +280,12 @@ class HourglassEngine:
         return torch.empty(N, Ch, H, W, dtype=torch.float32, device=self.device)
 
     def _stats(self, plan, channels):
-        """(channels, 2) fp64 view of the plan's statistics arena (zeroed by ONE memset per forward)."""
-        a = plan["stats_used"]
-        if a + channels > plan["stats_arena"].shape[0]:
+        """(STAT_SLOTS, channels, 2) fp64 view of the plan's statistics arena (zeroed by ONE memset per forward)."""
+        a, n = plan["stats_used"], L.STAT_SLOTS * channels
+        if a + n > plan["stats_arena"].shape[0]:
             raise RuntimeError("statistics arena too small")
-        plan["stats_used"] = a + channels
-        return plan["stats_arena"][a:a + channels]
+        plan["stats_used"] = a + n
+        return plan["stats_arena"][a:a + n].view(L.STAT_SLOTS, channels, 2)
 
     def _inception(self, plan, steps, mod: HG.Inception, x: Act, N, H, W) -> Act:
         c_in, cfg = HG.INCEPTION[mod.kind]
@@ -358,7 +358,7 @@ class HourglassEngine:
         net = self.net
         Act.registry = []
         plan = {"steps": [], "convs": [], "stats_used": 0,
-                "stats_arena": torch.zeros(16384, 2, dtype=torch.float64, device=self.device)}
+                "stats_arena": torch.zeros(16384 * L.STAT_SLOTS, 2, dtype=torch.float64, device=self.device)}
         plan["x"] = self._new(N, 3, H, W)
         x_in = Act(plan["x"], 0, 3, needs_grad=False)
         stem_buf = self._new(N, 128, H, W)

@@ -36,7 +36,8 @@ def conv2d(x, packed_w, Cin, Cout, ks, bias=None, x_coff=0, out=None, y_coff=0, 
     y_ctot = out.shape[1]
     opt = lambda t, name: _native.dev_ptr(t, name) if t is not None else None  # noqa: E731
     if stats is not None:
-        assert stats.dtype == torch.float64 and stats.is_cuda and stats.is_contiguous() and stats.numel() == 2 * y_ctot
+        assert stats.dtype == torch.float64 and stats.is_cuda and stats.is_contiguous() and \
+            stats.numel() == _native.BN_STAT_SLOTS * 2 * y_ctot, "stats must be (BN_STAT_SLOTS, y_ctot, 2) fp64"
     ty, cot = cfg if cfg is not None else (0, 0)
     rc = _native.lib().cd_conv2d_fwd_cfg(
         _native.dev_ptr(x, "x"), x_ctot, x_coff, Cin, _native.dev_ptr(packed_w, "packed_w"), opt(bias, "bias"),
@@ -71,7 +72,7 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
     pk = torch.randn(_native.lib().cd_conv2d_packed_weight_floats(Cout, Cin, ks, 0), device=dev) * 0.05
     sc = torch.rand(Cin, device=dev) + 0.5 if affine_in else None
     sh = torch.randn(Cin, device=dev) * 0.1 if affine_in else None
-    st = torch.zeros(2 * y_ctot, dtype=torch.float64, device=dev) if stats else None
+    st = torch.zeros(_native.BN_STAT_SLOTS, y_ctot, 2, dtype=torch.float64, device=dev) if stats else None
     max_cot = _native.lib().cd_conv2d_packed_co_tiles(Cout, ks)
     best, best_t = None, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

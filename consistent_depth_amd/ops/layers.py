@@ -17,8 +17,17 @@ def _s(t):
     return _native.stream_ptr(t.device)
 
 
+STAT_SLOTS = _native.BN_STAT_SLOTS
+
+
+def new_stats(ctot, device) -> torch.Tensor:
+    """Zeroed batch-statistics buffer (STAT_SLOTS, ctot, 2) fp64 for the conv epilogue / BatchNorm entry points."""
+    return torch.zeros(STAT_SLOTS, ctot, 2, dtype=torch.float64, device=device)
+
+
 def bn_normalize(x, coff, C, stats, mean_invstd, eps=1e-5, running_mean=None, running_var=None, momentum=0.1):
     N, ctot, H, W = x.shape
+    assert stats.shape == (STAT_SLOTS, ctot, 2) and stats.is_contiguous(), "stats must be (STAT_SLOTS, ctot, 2)"
     rc = _native.lib().cd_bn_normalize(_p(x), ctot, coff, C, stats.data_ptr(), float(eps), _o(running_mean), _o(running_var),
                                        float(momentum), _p(mean_invstd), N, H, W, _s(x))
     _native.check(rc, "cd_bn_normalize")
@@ -26,8 +35,9 @@ def bn_normalize(x, coff, C, stats, mean_invstd, eps=1e-5, running_mean=None, ru
 
 def bn_finalize(stats, coff, C, count, mean_invstd, scale, shift, eps=1e-5, gamma=None, beta=None, running_mean=None,
                 running_var=None, momentum=0.1):
-    """stats (ctot,2) fp64 -> scale/shift (ctot,) for relu(raw*scale+shift) on load; no pass over the activation."""
-    rc = _native.lib().cd_bn_finalize(stats.data_ptr(), stats.shape[0], coff, C, float(count), float(eps), _o(gamma), _o(beta),
+    """stats (STAT_SLOTS,ctot,2) fp64 -> scale/shift (ctot,) for relu(raw*scale+shift) on load; no pass over the activation."""
+    assert stats.shape[0] == STAT_SLOTS and stats.is_contiguous()
+    rc = _native.lib().cd_bn_finalize(stats.data_ptr(), stats.shape[1], coff, C, float(count), float(eps), _o(gamma), _o(beta),
                                       _o(running_mean), _o(running_var), float(momentum), _p(mean_invstd), _p(scale), _p(shift),
                                       _native.stream_ptr(scale.device))
     _native.check(rc, "cd_bn_finalize")

@@ -46,6 +46,13 @@ typedef enum cd_depth_mode {
 
 /* ABI version, bumped on any signature change. */
 int cd_abi_version(void);
+
+/* Batch-statistics buffers (the `stats` arguments below) hold CD_BN_STAT_SLOTS partial copies:
+ *   double stats[CD_BN_STAT_SLOTS][ctot][2]   -- (sum, sum of squares) per channel of the concat buffer.
+ * The convolution epilogue adds each workgroup's contribution into one of the copies (same-address fp64 atomics
+ * serialise in the memory system; spreading them keeps the epilogue off the critical path), the BatchNorm entry points
+ * sum the copies in slot order.  A caller that synthesises statistics (eval mode) writes slot 0 and zeroes the rest. */
+#define CD_BN_STAT_SLOTS 16
 /* Human-readable build string ("gfx950 hipcc x.y ..."); static storage. */
 const char* cd_build_info(void);
 
@@ -163,7 +170,7 @@ int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream);
  * padding (ks-1)/2, ks in {1,3,5,7,11}, on the fp32 matrix cores (exact fp32).
  *   act(v) = relu?(v * in_scale[c] + in_shift[c])   when in_scale/in_shift are given (the producer's
  *            BatchNorm-apply [+ReLU] fused into the load), relu only when in_relu and no scale, else v;
- *   stats (optional, [y_ctot][2] doubles, caller-zeroed): per-channel sum and sum of squares of the
+ *   stats (optional, [CD_BN_STAT_SLOTS][y_ctot][2] doubles, caller-zeroed): per-channel sum and sum of squares of the
  *            raw output are ADDED -- the batch statistics of the following train-mode BatchNorm;
  *   accumulate != 0: y += result instead of y = result (gradient fan-in of the dgrad convolutions). */
 int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w,
@@ -199,7 +206,7 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
                     int Cout, float* dw, int accumulate, float* workspace, int N, int H, int W, int ks,
                     void* stream);
 
-/* BatchNorm2d in training mode, forward.  stats[ctot][2] = per-channel (sum, sum of squares) of the raw
+/* BatchNorm2d in training mode, forward.  stats[CD_BN_STAT_SLOTS][ctot][2] = per-channel (sum, sum of squares) of the raw
  * tensor over N*H*W (what cd_conv2d_fwd accumulates).  In place: x <- (x - mean) * rsqrt(var + eps)
  * (x_hat, PRE-ReLU: consumers apply relu / the affine part while loading); writes
  * mean_invstd[ctot][2] (mean, 1/std) for the backward and updates running_mean/var[C] (momentum, unbiased

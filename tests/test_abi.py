@@ -34,6 +34,10 @@ def test_abi_version_and_build_info():
     lib = _native.lib()
     assert lib.cd_abi_version() == _native.ABI_VERSION
     assert b"gfx950" in lib.cd_build_info()
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "consistent_depth_amd.h")).read()
+    assert int(re.search(r"#define CD_BN_STAT_SLOTS (\d+)", hdr).group(1)) == _native.BN_STAT_SLOTS
 
 
 def test_workspace_query_is_pure_host():

@@ -46,9 +46,10 @@ def test_bn_normalize_and_backward_match_torch():
         a.backward(dA)
         buf = torch.zeros(N, ctot, H, W).cuda()
         buf[:, coff:coff + C] = raw.float().cuda()
-        stats = torch.zeros(ctot, 2, dtype=torch.float64).cuda()
-        stats[coff:coff + C, 0] = raw.sum((0, 2, 3)).cuda()
-        stats[coff:coff + C, 1] = (raw ** 2).sum((0, 2, 3)).cuda()
+        stats = layers.new_stats(ctot, "cuda")          # (STAT_SLOTS, ctot, 2): split the sums over three of the copies
+        for slot, part in ((0, raw[:1]), (5, raw[1:2]), (layers.STAT_SLOTS - 1, raw[2:])):
+            stats[slot, coff:coff + C, 0] = part.sum((0, 2, 3)).cuda()
+            stats[slot, coff:coff + C, 1] = (part ** 2).sum((0, 2, 3)).cuda()
         mi = torch.zeros(ctot, 2).cuda()
         rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
         layers.bn_normalize(buf, coff, C, stats, mi, running_mean=rm, running_var=rv)

@@ -70,7 +70,7 @@ def main():
         pk = conv.pack_weights(w)
         out = torch.empty(N, Cout, H, W, device="cuda")
         sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
-        stats = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda")
+        stats = torch.zeros(16, Cout, 2, dtype=torch.float64, device="cuda")   # (CD_BN_STAT_SLOTS, Cout, 2)
         fused = kind == "f" and Cin > 3     # forward convs read BN-normalised inputs and produce batch statistics
         flops = 2.0 * N * H * W * Cin * ks * ks * Cout
 
