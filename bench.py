@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--pool", type=int, default=6, help="distinct synthetic batches cycled through")
     ap.add_argument("--loss-batch", type=int, default=256, help="pairs per launch of the roofline micro-benchmark")
     ap.add_argument("--loss-iters", type=int, default=20)
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("CD_AMD_STEP_GRAPH", "1")),
+                    help="1: replay the step from a HIP graph after the eager warm-up steps (GraphedFineTuneStep); 0: eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss-microbench", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -134,7 +136,7 @@ def loss_microbench(lib, B, H, W, iters, device):
 def main():
     args = parse()
     from consistent_depth_amd import _native, parallel
-    from consistent_depth_amd.engine import FineTuneStep
+    from consistent_depth_amd.engine import FineTuneStep, GraphedFineTuneStep
     from consistent_depth_amd.monodepth.depth_model_registry import get_depth_model
     import torch.distributed as dist
 
@@ -155,7 +157,8 @@ def main():
     log(f"rank {rank}/{world} building mc model, conv backend {args.backend}")
     model = get_depth_model("mc")(backend=args.backend, seed=0)
     model.train()
-    step = FineTuneStep(model, params, world=world)
+    eager_step = FineTuneStep(model, params, world=world)
+    step = GraphedFineTuneStep(eager_step, eager_steps=max(1, min(2, args.warmup - 1))) if args.graph else eager_step
     pool = make_pool(args.pool, B, H, W, seed=rank + 1, device=device)
 
     def run(n, offset=0):
@@ -173,21 +176,35 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    assert lib.cd_profile_begin(args.steps + 8) == 0
+    graphed = bool(args.graph) and getattr(step, "graphed", None) is True
+    if args.graph and not graphed:
+        log(f"HIP graph capture not active ({getattr(step, 'capture_error', None) or 'needs >= 3 warm-up steps'}); eager steps")
+    if not graphed:   # event records of the in-step loss profiler are not captured into graphs: eager only
+        assert lib.cd_profile_begin(args.steps + 8) == 0
     t0 = time.perf_counter()
     last_loss = run(args.steps, offset=args.warmup)
+    t_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (no sync inside the loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ms_step, _ = profile_collect(lib, args.steps + 8)
+    if graphed:       # the same kernel timed in 3 eager steps after the timed region
+        assert lib.cd_profile_begin(16) == 0
+        for i in range(3):
+            images, meta, _, _ = pool[i % len(pool)]
+            eager_step(images, meta)
+        torch.cuda.synchronize()
+        ms_step, _ = profile_collect(lib, 16)
+    else:
+        ms_step, _ = profile_collect(lib, args.steps + 8)
     if world > 1:
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     pairs_per_s = B * world * args.steps / elapsed
-    log(f"timed region: {args.steps} steps in {elapsed:.3f}s -> {pairs_per_s:.2f} pairs/s")
+    log(f"timed region: {args.steps} steps in {elapsed:.3f}s -> {pairs_per_s:.2f} pairs/s "
+        f"(host enqueue {1e3 * t_enqueue / args.steps:.1f} ms/step)")
 
     out = {
         "metric": "frame-pairs/sec fine-tuning @384x224 BS4; warp+loss HBM GB/s vs peak",
@@ -198,6 +215,7 @@ def main():
                                f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{2 if args.backend == 'hip' else 1}]: "
                                + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"),
                    "conv_backend": args.backend, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "hip_graph": graphed, "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),
                    "last_loss": float(last_loss.item())},
     }
 

@@ -74,14 +74,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int C
 // ---------------------------------------------------------------- the convolution
 // CO_T = 16-wide output-channel tiles per block.  The packed filter rows are cobp_pack floats wide (the layout
 // is chosen once per filter, pick_co_tiles); a block may take only a CO_T*16-column slice of them
-// (blockIdx.y = group * nsub + sub), which gives the small deep-level images enough workgroups.
+// (which gives the small deep-level images enough workgroups) or, for 1x1, span several groups (input read once).
 template <int KS, int CO_T, int TYP>
 __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
-    const float* __restrict__ wpk, int cobp_pack, int nsub, const float* __restrict__ bias,
+    const float* __restrict__ wpk, int cobp_pack, int pack_cot, int pack_tiles, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     float* __restrict__ y, int y_ctot, int y_coff, int Cout,
-    double* __restrict__ stats, int accumulate, int H, int W, int tiles_x, int pipe) {
+    double* __restrict__ stats, int accumulate, int H, int W, int tiles_x, int tiles_img, int tiles_total, int chunk,
+    int slices, int pipe) {
     using Cfg = ConvCfg<KS, TYP>;
     constexpr int TY = Cfg::TY, CI = Cfg::CI_CHUNK, RS = Cfg::RS, PS = Cfg::PS, ROWS = Cfg::ROWS;
     constexpr int P = (KS - 1) / 2, TAPS = KS * KS;
@@ -95,14 +96,24 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     float* s_in = smem;                  // [CI][PS]
     float* s_w = smem + CI * PS;         // [TAPS][CI][COBP]
 
-    const int tile = blockIdx.x, grp = blockIdx.y / nsub, sub = blockIdx.y - grp * nsub, n = blockIdx.z;
+    // XCD-aware block -> (image tile, channel slice) mapping.  Workgroups are dealt round-robin to the 8 XCDs (own L2
+    // each): XCD x takes the contiguous run of tiles [x * chunk, (x+1) * chunk), and the slices of one tile are
+    // consecutive in its dispatch order -- so the workgroups that read the same input tile (all channel slices) or
+    // overlapping halos (neighbouring tiles) share an L2 and run close in time.
+    const int xcd = blockIdx.x & 7, kx_ = blockIdx.x >> 3;
+    const int tg = kx_ / slices, slice = kx_ - tg * slices;
+    const int t_lin = xcd * chunk + tg;
+    if (tg >= chunk || t_lin >= tiles_total) return;   // block-uniform
+    const int n = t_lin / tiles_img, tile = t_lin - n * tiles_img;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int X0 = tx * CV_TX, Y0 = ty * TY;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t HW = (size_t)H * W;
     const float* xin = x + ((size_t)n * x_ctot + x_coff) * HW;
     const int n_chunks = (Cin + CI - 1) / CI;
-    const float* wbase = wpk + (size_t)grp * n_chunks * W_ROWS * cobp_pack + sub * COB;
+    // this block's CO_T channel tiles are the global tiles slice * CO_T + t; tile g lives in packed group g / pack_cot
+    // at column (g % pack_cot) * 16 -- a block may take part of a packed group or span several
+    const int grp_stride = n_chunks * W_ROWS * cobp_pack;
 
     f32x4 acc[MT][CO_T];
 #pragma unroll
@@ -160,7 +171,13 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
         const int cc = i / (ROWS * RS);
         return cc * PS + (i - cc * (ROWS * RS));
     };
-    auto w_src = [&](int i) -> int { const int row = i / ROW4; return row * cobp_pack + (i - row * ROW4) * 4; };
+    auto w_src = [&](int i) -> int {   // offset of the float4 from the chunk's base in packed group 0; -1 = zero fill
+        const int row = i / ROW4, c4 = i - row * ROW4;
+        const int g = slice * CO_T + (c4 >> 2);
+        if (g >= pack_tiles) return -1;
+        const int pg = g / pack_cot;
+        return pg * grp_stride + row * cobp_pack + (g - pg * pack_cot) * 16 + (c4 & 3) * 4;
+    };
     auto w_lds = [&](int i) -> int { const int row = i / ROW4; return row * COBP + (i - row * ROW4) * 4; };
 
     // ---- pipelined path state
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     auto pf_load = [&](int chunk) {
         if constexpr (PIPE_OK) {
             const float* xc = xin + (size_t)chunk * CI * HW;                       // uniform
-            const float* wc = wbase + (size_t)chunk * W_ROWS * cobp_pack;        // uniform
+            const float* wc = wpk + (size_t)chunk * W_ROWS * cobp_pack;          // uniform
             const int ci_left = Cin - chunk * CI;                                 // channels of this chunk that exist
 #pragma unroll
             for (int q = 0; q < PF_IN; ++q) {
@@ -268,9 +285,11 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
             } else {
                 for (int i = threadIdx.x; i < CI * ROWS * RS; i += kBlock) s_in[in_lds1(i)] = in_load1(chunk, i, P);
             }
-            const float* wc = wbase + (size_t)chunk * W_ROWS * cobp_pack;
-            for (int i = threadIdx.x; i < W_ROWS * ROW4; i += kBlock)
-                *reinterpret_cast<float4*>(s_w + w_lds(i)) = *reinterpret_cast<const float4*>(wc + w_src(i));
+            const float* wc = wpk + (size_t)chunk * W_ROWS * cobp_pack;
+            for (int i = threadIdx.x; i < W_ROWS * ROW4; i += kBlock) {
+                const int off = w_src(i);
+                *reinterpret_cast<float4*>(s_w + w_lds(i)) = off >= 0 ? *reinterpret_cast<const float4*>(wc + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         __syncthreads();
 
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
 
     // ---- epilogue: bias, store, batch statistics of the raw output
     const int co_l = lane & 15, px4 = (lane >> 4) * 4;
-    const int co_base = grp * (nsub * COB) + sub * COB;
+    const int co_base = slice * COB;
     float* yout = y + ((size_t)n * y_ctot + y_coff) * HW;
     // statistics partials in double: the sums must not depend on how the launch shape groups the pixels
     // (fp32 partials differ at 1e-7 between tile shapes, which a deep train-mode-BN network amplifies)
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
             if (co < Cout) {
                 const double a = (red[threadIdx.x * 2] + red[(COB + threadIdx.x) * 2]) + (red[(2 * COB + threadIdx.x) * 2] + red[(3 * COB + threadIdx.x) * 2]);
                 const double b = (red[threadIdx.x * 2 + 1] + red[(COB + threadIdx.x) * 2 + 1]) + (red[(2 * COB + threadIdx.x) * 2 + 1] + red[(3 * COB + threadIdx.x) * 2 + 1]);
-                const int slot = (blockIdx.x + 5 * blockIdx.z) & (CD_BN_STAT_SLOTS - 1);
+                const int slot = t_lin & (CD_BN_STAT_SLOTS - 1);
                 double* st = stats + ((size_t)slot * y_ctot + y_coff + co) * 2;
                 atomicAdd(st, a);
                 atomicAdd(st + 1, b);
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     }
 }
 
-// pack_cot = co tiles per packed group (the filter's layout), CO_T = co tiles per block (<= pack_cot, divides it)
+// pack_cot = co tiles per packed group (the filter's layout), CO_T = co tiles per block (any of 1, 2, 4, 8, 16)
 template <int KS, int CO_T, int TYP>
 static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wpk, int pack_cot, const float* bias,
                          const float* in_scale, const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff,
@@ -375,7 +394,7 @@ static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const 
     using Cfg = ConvCfg<KS, TYP>;
     constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
     const int tiles_x = (W + CV_TX - 1) / CV_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
-    const int pack_cob = pack_cot * 16, groups = (Cout + pack_cob - 1) / pack_cob, nsub = pack_cot / CO_T;
+    const int pack_cob = pack_cot * 16, groups = (Cout + pack_cob - 1) / pack_cob;
     const int n_chunks = (Cin + Cfg::CI_CHUNK - 1) / Cfg::CI_CHUNK;
     const size_t lds = sizeof(float) * ((size_t)Cfg::CI_CHUNK * Cfg::PS + (size_t)KS * KS * Cfg::CI_CHUNK * COBP + 2 * (size_t)n_chunks * Cfg::CI_CHUNK);
     static bool attr_set = false;
@@ -383,13 +402,12 @@ static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const 
         (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<KS, CO_T, TYP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (lds > 160 * 1024 || nsub < 1 || nsub * CO_T != pack_cot) return CD_ERR_UNSUPPORTED;
-    // sub-slices whose first channel is already past Cout have nothing to do: trim the last group's tail
-    const int live = (Cout + COB - 1) / COB;   // live (group, sub) slices over all groups, in channel order
-    const int gy = groups * nsub < live ? groups * nsub : live;
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T, TYP>), dim3(tiles_x * tiles_y, gy, N), dim3(kBlock), lds, s, x, x_ctot,
-                       x_coff, Cin, wpk, co_stride_padded(pack_cob), nsub, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff,
-                       Cout, stats, accumulate, H, W, tiles_x, pipe);
+    if (lds > 160 * 1024 || lds < sizeof(double) * 8 * COB) return CD_ERR_UNSUPPORTED;   // (the statistics reduction reuses 8*COB doubles)
+    const int slices = (Cout + COB - 1) / COB;   // channel slices with at least one live channel
+    const int tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * N, chunk = (tiles_total + 7) / 8;
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, CO_T, TYP>), dim3((unsigned)chunk * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
+                       x_coff, Cin, wpk, co_stride_padded(pack_cob), pack_cot, groups * pack_cot, bias, in_scale, in_shift, in_relu, y,
+                       y_ctot, y_coff, Cout, stats, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk, slices, pipe);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -407,17 +425,27 @@ __host__ __device__ static inline int pick_co_tiles(int ks, int cout) {
 // tools/conv_sweep.py on the hourglass shapes (profiles/conv_sweep_r01.txt): large images want tall tiles and wide
 // channel slices (operand reuse); from 96x56 down there are too few tiles to fill 256 CUs, so a block takes
 // a single 16-channel slice and a short tile.
-static inline void pick_conv_tile(int ks, int pack_cot, int N, int H, int W, int* ty_out, int* cot_out) {
+// widest channel slice a workgroup may take: the packed group for k > 1; for 1x1 (a pure GEMM whose input would
+// otherwise be re-read once per 64-channel group) up to 8 or 16 tiles, i.e. ALL output channels up to 256
+static inline int max_co_tiles(int ks, int Cout) {
+    const int pack_cot = pick_co_tiles(ks, Cout);
+    if (ks != 1) return pack_cot;
+    const int need = (Cout + 15) / 16;
+    return need > 8 ? 16 : (need > 4 ? 8 : pack_cot);
+}
+
+static inline void pick_conv_tile(int ks, int pack_cot, int Cout, int N, int H, int W, int* ty_out, int* cot_out) {
     const long long px = (long long)N * H * W;
     const long long L1 = 8LL * 192 * 112, L2 = 8LL * 96 * 56, L3 = 8LL * 48 * 28;
     int ty, cot;
     if (ks == 1) {
-        cot = px > L1 ? pack_cot : (px > L3 ? (pack_cot < 2 ? pack_cot : 2) : 1);
+        cot = px > L2 ? max_co_tiles(ks, Cout) : (px > L3 ? (pack_cot < 2 ? pack_cot : 2) : 1);
         ty = px > L3 ? 8 : 4;
     } else {
         cot = px > L2 ? (pack_cot < 2 ? pack_cot : 2) : 1;
         ty = px > L2 ? ((ks == 7) ? 8 : 16) : (px > L3 ? 8 : 4);
     }
+    (void)L1;
     *ty_out = ty;
     *cot_out = cot;
 }
@@ -470,7 +498,7 @@ int cd_debug_force_conv_tile_rows(int ty) {
 }
 
 int cd_debug_force_conv_co_tiles(int cot) {
-    if (!(cot == 0 || cot == 1 || cot == 2 || cot == 4)) return CD_ERR_INVALID_ARG;
+    if (!(cot == 0 || cot == 1 || cot == 2 || cot == 4 || cot == 8 || cot == 16)) return CD_ERR_INVALID_ARG;
     cd::g_force_conv_cot = cot;
     return CD_OK;
 }
@@ -519,13 +547,16 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     hipStream_t s = (hipStream_t)stream;
     const int pack_cot = cd::pick_co_tiles(ks, Cout);
     if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16)) return CD_ERR_INVALID_ARG;
-    if (!(co_tiles == 0 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4)) return CD_ERR_INVALID_ARG;
+    if (!(co_tiles == 0 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4 || co_tiles == 8 || co_tiles == 16)) return CD_ERR_INVALID_ARG;
     int ty, cot;
-    cd::pick_conv_tile(ks, pack_cot, N, H, W, &ty, &cot);
+    cd::pick_conv_tile(ks, pack_cot, Cout, N, H, W, &ty, &cot);
+    const int max_cot = cd::max_co_tiles(ks, Cout);
     if (tile_rows) ty = tile_rows;
-    if (co_tiles) cot = co_tiles < pack_cot ? co_tiles : pack_cot;
+    if (co_tiles) cot = co_tiles < max_cot ? co_tiles : max_cot;
     if (cd::g_force_conv_ty) ty = cd::g_force_conv_ty;
-    if (cd::g_force_conv_cot && cd::g_force_conv_cot <= pack_cot) cot = cd::g_force_conv_cot;
+    if (cd::g_force_conv_cot && cd::g_force_conv_cot <= max_cot) cot = cd::g_force_conv_cot;
+    if (cot == 16 && ty > 4) ty = 4;    // accumulator budget: 16 channel tiles x (TY/4 x 2) pixel tiles x 4 registers
+    if (cot == 8 && ty > 8) ty = 8;
     // conv_fwd_kernel<7, 1, 16> is miscompiled by this toolchain (hipcc 7.2 / gfx950): the register allocator
     // rotates the 8 accumulator tiles through AGPRs around the tap loop and the last element of the last tile comes
     // back wrong (tests/test_conv_gpu.py::test_launch_shapes_are_bit_identical catches it; every other
@@ -547,6 +578,8 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     }
     CD_CONV_K(1) CD_CONV_K(3) CD_CONV_K(5) CD_CONV_K(7)
     if (ks == 11 && cot == 1) CD_CONV_T(11, 1)
+    if (ks == 1 && cot == 8) { if (ty == 8) CD_CONV(1, 8, 8); CD_CONV(1, 8, 4); }
+    if (ks == 1 && cot == 16) CD_CONV(1, 16, 4);
 #undef CD_CONV_K
 #undef CD_CONV_T
 #undef CD_CONV
@@ -560,6 +593,6 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                              accumulate, N, H, W, ks, 0, 0, stream);
 }
 
-int cd_conv2d_packed_co_tiles(int Cout, int ks) { return cd::pick_co_tiles(ks, Cout); }
+int cd_conv2d_packed_co_tiles(int Cout, int ks) { return cd::max_co_tiles(ks, Cout); }
 
 }  // extern "C"

@@ -35,7 +35,7 @@ import numpy as np
 import torch
 
 from . import optimizer, parallel
-from .engine import FineTuneStep
+from .engine import FineTuneStep, GraphedFineTuneStep
 from .loaders.pair_store import PairStore
 from .loaders.video_dataset import VideoFrameDataset
 from .loss.loss_params import LossParams
@@ -121,6 +121,8 @@ class DepthFineTuner:
             self.store = PairStore.from_directory(self.base_dir, pjoin(self.range_dir, "metadata_scaled.npz"))
         store = self.store
         step = FineTuneStep(self.model, p, world=self.world)
+        if os.environ.get("CD_AMD_STEP_GRAPH", "1") != "0":   # replay the step from a HIP graph after 2 eager steps
+            step = GraphedFineTuneStep(step)
         self._step = step
         if self.rank == 0:
             os.makedirs(pjoin(self.out_dir, "eval"), exist_ok=True)

@@ -50,6 +50,23 @@ class FineTuneStep:
         self.opt.step(grad_scale=1.0 / self.world, guard_loss=guard)
         return loss.detach(), parts
 
+    # -- the step split at the data-parallel exchange (GraphedFineTuneStep captures the two halves)
+    def _grads(self, images, metadata):
+        raw = self.model.estimate_raw(images)
+        self.opt.zero_grad()
+        loss, parts = self.criterion(raw, metadata, parameters=self._plist)
+        loss.backward()
+        guard = loss.detach()
+        if self.world > 1:
+            self.opt.loss_slot.copy_(guard.reshape(1))
+        return guard, parts
+
+    def _update(self, guard):
+        if self.world > 1:
+            parallel.allreduce_sum_(self.opt.reduce_buffer)
+            guard = self.opt.loss_slot
+        self.opt.step(grad_scale=1.0 / self.world, guard_loss=guard)
+
     @torch.no_grad()
     def evaluate(self, images, metadata):
         """Validation forward: model stays in whatever mode it is in (the reference keeps
@@ -57,3 +74,94 @@ class FineTuneStep:
         raw = self.model.estimate_raw(images)
         loss, parts = self.criterion(raw, metadata, parameters=self._plist)
         return raw, loss, parts
+
+
+def _flatten(metadata, prefix=()):
+    """(path, tensor) pairs of a nested metadata dict / list, in a fixed order."""
+    out = []
+    if isinstance(metadata, dict):
+        for k in sorted(metadata):
+            out += _flatten(metadata[k], prefix + (k,))
+    elif isinstance(metadata, (list, tuple)):
+        for i, v in enumerate(metadata):
+            out += _flatten(v, prefix + (i,))
+    elif torch.is_tensor(metadata):
+        out.append((prefix, metadata))
+    return out
+
+
+def _clone_tree(metadata):
+    if isinstance(metadata, dict):
+        return {k: _clone_tree(v) for k, v in metadata.items()}
+    if isinstance(metadata, (list, tuple)):
+        return type(metadata)(_clone_tree(v) for v in metadata)
+    if torch.is_tensor(metadata):
+        return metadata.detach().clone().contiguous()
+    return metadata
+
+
+class GraphedFineTuneStep:
+    """A FineTuneStep replayed from a HIP graph.
+
+    One step is ~1300 kernel launches (157 convolutions x {forward, input gradient, weight gradient}, BatchNorm,
+    pooling, loss, Adam) issued from Python; at ~20 us of host time each the host, not the MI355X, bounds the step.
+    The first `eager_steps` calls per input signature run the plain FineTuneStep (they build the engine plan, time
+    the convolution launch shapes, size the workspaces); the next call captures the whole step -- zero-grad, CNN
+    forward, fused loss, CNN backward and (single GPU) the guarded Adam update, including the engine's side streams
+    -- into one graph with static input buffers, and every later call copies its batch into those buffers and
+    replays.  The training trajectory is that of the eager step (capturing executes nothing).  With world > 1 the
+    graph ends before the gradient all-reduce; the collective and the one Adam launch stay eager.
+
+    If capture fails (a torch / HIP runtime without stream capture) the step stays eager and `self.graphed` is False.
+    """
+
+    def __init__(self, step: FineTuneStep, eager_steps: int = 2):
+        self.step, self.eager_steps = step, eager_steps
+        self._seen, self._graphs = {}, {}
+        self.graphed = None      # None: nothing captured yet; True / False after the first attempt
+        self.capture_error = None
+
+    @staticmethod
+    def _signature(images, metadata):
+        return (tuple(images.shape),) + tuple((path, tuple(t.shape), t.dtype) for path, t in _flatten(metadata))
+
+    def _capture(self, images, metadata):
+        st_images, st_meta = images.detach().clone().contiguous(), _clone_tree(metadata)
+        dev = images.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                guard, parts = self.step._grads(st_images, st_meta)
+                if self.step.world == 1:
+                    self.step._update(guard)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return {"graph": graph, "images": st_images, "meta": st_meta, "flat": [t for _, t in _flatten(st_meta)],
+                "guard": guard, "parts": parts}
+
+    def __call__(self, images, metadata):
+        key = self._signature(images, metadata)
+        n = self._seen.get(key, 0)
+        self._seen[key] = n + 1
+        if self.graphed is False or n < self.eager_steps:
+            return self.step(images, metadata)
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                g = self._capture(images, metadata)
+            except Exception as e:   # noqa: BLE001 -- stay on the (equally native) eager path
+                self.graphed, self.capture_error = False, f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize()
+                return self.step(images, metadata)
+            self._graphs[key], self.graphed = g, True
+        g["images"].copy_(images)
+        for dst, (_, src) in zip(g["flat"], _flatten(metadata)):
+            dst.copy_(src)
+        g["graph"].replay()
+        if self.step.world > 1:
+            self.step._update(g["guard"])
+        return g["guard"].clone(), {k: v.clone() for k, v in g["parts"].items()}
+
+    def evaluate(self, images, metadata):
+        return self.step.evaluate(images, metadata)

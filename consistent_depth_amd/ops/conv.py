@@ -77,8 +77,8 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
     best, best_t = None, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for ty in (4, 8, 16):
-        for cot in (1, 2, 4):
-            if cot > max_cot:
+        for cot in (1, 2, 4, 8, 16):
+            if cot > max_cot or (cot == 16 and ty > 4) or (cot == 8 and ty > 8):
                 continue
 
             def run():

@@ -178,21 +178,22 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                   float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                   int N, int H, int W, int ks, void* stream);
 /* The same with the launch shape chosen by the caller: tile_rows in {4, 8, 16} output rows per workgroup and
- * co_tiles in {1, 2, 4} 16-wide output-channel slices per workgroup (clamped to cd_conv2d_packed_co_tiles);
+ * co_tiles in {1, 2, 4, 8, 16} 16-wide output-channel slices per workgroup (clamped to cd_conv2d_packed_co_tiles; 8 and
+ * 16 exist for 1x1 filters only, with at most 8 / 4 tile rows: one workgroup then computes up to 256 channels);
  * 0 = built-in heuristic.  The result does not depend on the choice (the order of accumulation is fixed), only the
  * speed does: a caller with many launches of few shapes times the candidates once (the hourglass engine does). */
 int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w,
                       const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                       float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                       int N, int H, int W, int ks, int tile_rows, int co_tiles, void* stream);
-/* 16-wide output-channel tiles per packed filter group for (Cout, ks): the upper bound of co_tiles. */
+/* The upper bound of co_tiles for (Cout, ks). */
 int cd_conv2d_packed_co_tiles(int Cout, int ks);
 
 /* Test hook: force the output-tile height (4, 8, 16; 0 = automatic) of cd_conv2d_fwd so every
  * template instantiation can be parity-tested at small sizes. */
 int cd_debug_force_conv_tile_rows(int ty);
-/* Force the number of 16-wide output-channel tiles a conv workgroup computes (1, 2 or 4; ignored when larger than the
- * filter's packed group; 0 = heuristic), and switch the register-prefetch software pipeline (default on). */
+/* Force the number of 16-wide output-channel tiles a conv workgroup computes (1, 2, 4, 8, 16; ignored when larger than
+ * cd_conv2d_packed_co_tiles; 0 = heuristic), and switch the register-prefetch software pipeline (default on). */
 int cd_debug_force_conv_co_tiles(int co_tiles);
 int cd_debug_set_conv_pipeline(int on);
 

@@ -92,7 +92,8 @@ def test_dgrad_is_conv_with_transposed_filter(Cin, Cout, ks):
 
 @pytest.mark.parametrize("pipe", [1, 0])
 @pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [(2, 40, 56, 20, 36, 7), (2, 24, 64, 12, 20, 5), (2, 64, 48, 17, 33, 3),
-                                               (2, 100, 64, 16, 40, 1), (1, 36, 30, 24, 36, 1), (1, 20, 16, 24, 40, 11)])
+                                               (2, 100, 64, 16, 40, 1), (1, 36, 30, 24, 36, 1), (1, 20, 16, 24, 40, 11),
+                                               (2, 70, 208, 12, 40, 1), (1, 128, 112, 16, 36, 1), (2, 33, 256, 9, 35, 1)])
 def test_launch_shapes_are_bit_identical(N, Cin, Cout, H, W, ks, pipe):
     """Every (tile rows, co tiles per workgroup) launch shape, with and without the register-prefetch pipeline, with
     the fused input transform, the statistics epilogue and gradient accumulation, produces the same bits (the order
@@ -114,8 +115,8 @@ def test_launch_shapes_are_bit_identical(N, Cin, Cout, H, W, ks, pipe):
     try:
         lib.cd_debug_set_conv_pipeline(pipe)
         for ty in (4, 8, 16):
-            for cot in (1, 2, 4):
-                if cot > max_cot:
+            for cot in (1, 2, 4, 8, 16):
+                if cot > max_cot or (cot == 16 and ty > 4) or (cot == 8 and ty > 8):
                     continue
                 out = base.clone()
                 stats = layers.new_stats(Cout + 3, "cuda")

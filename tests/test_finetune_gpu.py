@@ -47,10 +47,10 @@ def _cpu_run(state, batches, dtype):
     return np.array(losses), torch.exp(pred).reshape(B, 2, H, W).double().numpy()
 
 
-def _gpu_run(backend, batches):
+def _gpu_run(backend, batches, graph=False):
     import argparse
     import torch
-    from consistent_depth_amd.engine import FineTuneStep
+    from consistent_depth_amd.engine import FineTuneStep, GraphedFineTuneStep
     from consistent_depth_amd.monodepth.mannequin_challenge_model import MannequinChallengeModel
     params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0, learning_rate=4e-4,
                                 optimizer="Adam")
@@ -58,6 +58,8 @@ def _gpu_run(backend, batches):
     state = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
     model.train()
     step = FineTuneStep(model, params, world=1)
+    if graph:
+        step = GraphedFineTuneStep(step, eager_steps=1)
     t = lambda a: torch.tensor(a, device="cuda")  # noqa: E731
     losses = []
     for images, b in batches[:STEPS]:
@@ -67,6 +69,8 @@ def _gpu_run(backend, batches):
         losses.append(loss.item())
     with torch.no_grad():
         depth = model.forward(t(batches[-1][0]))
+    if graph:
+        assert step.graphed is True, step.capture_error
     return state, np.array(losses), depth.double().cpu().numpy()
 
 
@@ -93,3 +97,19 @@ def test_short_finetune_matches_cpu_reference(backend):
     assert np.isfinite(loss_gpu).all() and loss_gpu[-1] != loss_gpu[0]
     assert loss_gpu[-1] < loss_gpu[0]
     assert d_gpu < 3 * d_ref32 + 1e-3 and l_gpu < 5 * l_ref32 + 1e-3
+
+
+def test_hip_graph_replay_follows_the_eager_trajectory():
+    """GraphedFineTuneStep (1 eager step, then capture + replay of the whole step: CNN forward, loss, CNN backward, Adam
+    with its device-side step counter and NaN guard) must train like the eager step.  Not bit-identical: the weight
+    gradients are reduced with fp32 atomics in both, and the network amplifies that (parity)."""
+    batches = _batches()
+    _, loss_e, depth_e = _gpu_run("hip", batches)
+    _, loss_e2, depth_e2 = _gpu_run("hip", batches)
+    _, loss_g, depth_g = _gpu_run("hip", batches, graph=True)
+    run_to_run = _rel_l1(depth_e2, depth_e)
+    print(f"\nlosses eager {loss_e}\nlosses graph {loss_g}\ndepth rel-L1 graph vs eager {_rel_l1(depth_g, depth_e):.2e}  "
+          f"eager vs eager {run_to_run:.2e}")
+    assert loss_g[0] == pytest.approx(loss_e[0], rel=1e-5)          # first step: same eager code
+    np.testing.assert_allclose(loss_g, loss_e, rtol=5 * max(_rel_l1(loss_e2, loss_e), 1e-4))
+    assert _rel_l1(depth_g, depth_e) < 5 * run_to_run + 1e-3

@@ -93,13 +93,11 @@ def main():
 
         lib.cd_debug_force_conv_tile_rows(0); lib.cd_debug_force_conv_co_tiles(0); lib.cd_debug_set_conv_pipeline(1)
         t_h = timeit()
-        pack_cot = 1 if ks == 11 else min(4, max(1, (Cout + 15) // 16))
-        if pack_cot == 3:
-            pack_cot = 4
+        pack_cot = lib.cd_conv2d_packed_co_tiles(Cout, ks)
         res = {}
         for ty in (4, 8, 16):
-            for cot in (1, 2, 4):
-                if cot > pack_cot:
+            for cot in (1, 2, 4, 8, 16):
+                if cot > pack_cot or (cot == 16 and ty > 4) or (cot == 8 and ty > 8):
                     continue
                 for pipe in ((1,) if args.no_pipe_axis else (1, 0)):
                     lib.cd_debug_force_conv_tile_rows(ty); lib.cd_debug_force_conv_co_tiles(cot); lib.cd_debug_set_conv_pipeline(pipe)
