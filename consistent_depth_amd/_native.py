@@ -44,6 +44,7 @@ SIGNATURES = {
     "cd_debug_force_conv_tile_rows": (c_i, [c_i]),
     "cd_debug_force_conv_co_tiles": (c_i, [c_i]),
     "cd_debug_set_conv_pipeline": (c_i, [c_i]),
+    "cd_debug_set_wgrad_mode": (c_i, [c_i]),
     "cd_conv2d_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),
     "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_bn_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),

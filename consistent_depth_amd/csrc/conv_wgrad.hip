@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
-    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y) {
+    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y, int dbg) {
     using Cfg = WgCfg<KS>;
     using Sp = WgSplit<KS, CO_T, CI_T>;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, TPW = Sp::TPW, NW_T = Sp::NW_T, NW_A = Sp::NW_A, NW_C = Sp::NW_C;
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
         __syncthreads();
         }
         // ---- MFMA: all rows x all 4-pixel groups x this wave's (taps, co tiles, ci tiles)
+        if (!(dbg & 2))
 #pragma unroll 1
         for (int r = 0; r < WG_TY; ++r) {
 #pragma unroll 2
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
     }
 
     // ---- flush: packed [cog][cig][tap][COB][CIB]
+    if (dbg & 1) return;   // measurement hook (cd_debug_set_wgrad_mode): skip the flush
     const size_t base = ((size_t)cog * gridDim.y + cig) * TAPS * COB * CIB;
     const int ci_l = lane & 15, co4 = (lane >> 4) * 4;
 #pragma unroll
@@ -270,6 +272,8 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, int Cout, 
         dw[i] = accumulate ? dw[i] + v : v;
     }
 }
+
+static int g_wgrad_dbg = 0;   // measurement hook: bit 0 skip the atomic flush, bit 1 skip the MFMAs (results are then wrong)
 
 struct WgPlan { int co_t, ci_t; };
 
@@ -306,13 +310,18 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
     }
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((conv_wgrad_kernel<KS, CO_T, CI_T>), dim3(splits, cigs, cogs), dim3(kBlock), lds, s, x, x_ctot, x_coff,
-                       Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y);
+                       Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y, g_wgrad_dbg);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
 }  // namespace cd
 
 extern "C" {
+
+int cd_debug_set_wgrad_mode(int bits) {
+    cd::g_wgrad_dbg = bits;
+    return CD_OK;
+}
 
 size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;

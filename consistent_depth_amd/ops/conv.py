@@ -49,10 +49,45 @@ def conv2d(x, packed_w, Cin, Cout, ks, bias=None, x_coff=0, out=None, y_coff=0, 
 
 
 _TUNED = {}
+_TUNE_CACHE_LOADED = [False]
 
 
 def autotune_enabled() -> bool:
     return os.environ.get("CD_AMD_CONV_AUTOTUNE", "1") != "0"
+
+
+def _tune_cache_path():
+    return os.environ.get("CD_AMD_CONV_TUNE_CACHE") or None
+
+
+def _load_tune_cache():
+    """CD_AMD_CONV_TUNE_CACHE=<file>: measured launch shapes persist across processes (JSON, key -> [rows, tiles])."""
+    if _TUNE_CACHE_LOADED[0]:
+        return
+    _TUNE_CACHE_LOADED[0] = True
+    path = _tune_cache_path()
+    if path and os.path.exists(path):
+        import json
+        try:
+            with open(path) as f:
+                for k, v in json.load(f).items():
+                    _TUNED[tuple(json.loads(k))] = tuple(v) if v is not None else None
+        except (OSError, ValueError):
+            pass   # unreadable cache: measure again
+
+
+def _save_tune_cache():
+    path = _tune_cache_path()
+    if not path:
+        return
+    import json
+    tmp = f"{path}.{os.getpid()}.tmp"
+    try:
+        with open(tmp, "w") as f:
+            json.dump({json.dumps([int(x) if not isinstance(x, bool) else bool(x) for x in k]): v for k, v in _TUNED.items()}, f)
+        os.replace(tmp, path)
+    except OSError:
+        pass
 
 
 def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=False, stats=False, accumulate=False,
@@ -63,7 +98,8 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
     if not autotune_enabled():
         return None
     x_ctot, y_ctot = x_ctot or Cin, y_ctot or Cout
-    key = (ks, Cin, Cout, N, H, W, bool(affine_in), bool(relu_in), bool(stats), bool(accumulate), x_ctot, y_ctot)
+    _load_tune_cache()
+    key = (ks, Cin, Cout, N, H, W, int(bool(affine_in)), int(bool(relu_in)), int(bool(stats)), int(bool(accumulate)), x_ctot, y_ctot)
     if key in _TUNED:
         return _TUNED[key]
     dev = torch.device(device)
@@ -97,6 +133,7 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
             if t < best_t:
                 best, best_t = (ty, cot), t
     _TUNED[key] = best
+    _save_tune_cache()
     return best
 
 

@@ -196,6 +196,9 @@ int cd_debug_force_conv_tile_rows(int ty);
  * cd_conv2d_packed_co_tiles; 0 = heuristic), and switch the register-prefetch software pipeline (default on). */
 int cd_debug_force_conv_co_tiles(int co_tiles);
 int cd_debug_set_conv_pipeline(int on);
+/* Measurement hook for cd_conv2d_wgrad: bit 0 skips the flush of the partial sums, bit 1 the matrix instructions
+ * (the result is then wrong; 0 restores normal operation). */
+int cd_debug_set_wgrad_mode(int bits);
 
 /* Weight gradient dw[Cout][Cin][ks][ks] (=, or += when accumulate) of the same convolution:
  * sum over n,y,x of dy[n][co][y][x] * act(x)[n][ci][y+ky-P][x+kx-P]  (act as in cd_conv2d_fwd).
