@@ -438,9 +438,10 @@ static inline void pick_conv_tile(int ks, int pack_cot, int Cout, int N, int H, 
     const long long px = (long long)N * H * W;
     const long long L1 = 8LL * 192 * 112, L2 = 8LL * 96 * 56, L3 = 8LL * 48 * 28;
     int ty, cot;
-    if (ks == 1) {
-        cot = px > L2 ? max_co_tiles(ks, Cout) : (px > L3 ? (pack_cot < 2 ? pack_cot : 2) : 1);
-        ty = px > L3 ? 8 : 4;
+    if (ks == 1) {   // measured: 4-row tiles with the full packed group win nearly everywhere; the wide (8/16-tile) slices do not
+        cot = px > L3 ? pack_cot : (pack_cot < 2 ? pack_cot : 2);
+        ty = 4;
+        (void)Cout;
     } else {
         cot = px > L2 ? (pack_cot < 2 ? pack_cot : 2) : 1;
         ty = px > L2 ? ((ks == 7) ? 8 : 16) : (px > L3 ? 8 : 4);

@@ -39,8 +39,10 @@ template <int KS, int CO_T, int CI_T> struct WgSplit {
     static constexpr int APW = CO_T / NW_A, CPW = CI_T / NW_C;       // tiles per wave
 };
 
-template <int KS> struct WgCfg {
-    static constexpr int TY = (KS == 1) ? 4 : 8;                     // tile rows (1x1: smaller tile -> 2 blocks per CU)
+template <int KS, int CO_T = 1, int CI_T = 1> struct WgCfg {
+    // tile rows.  1x1: a smaller tile (2 blocks per CU); the wide 1x1 shapes (all of dY's and X's channels in one block,
+    // so both are read exactly once) keep (CO_T + CI_T) * 16 channel planes in LDS and take 2 rows
+    static constexpr int TY = (KS == 1) ? ((CO_T + CI_T > 16) ? 2 : 4) : 8;
     static constexpr int TAPS = KS * KS;
     static constexpr int RS = WG_TX + KS - 1, ROWS = TY + KS - 1;
     static constexpr int PS_IN_RAW = ROWS * RS;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
     float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y, int dbg) {
-    using Cfg = WgCfg<KS>;
+    using Cfg = WgCfg<KS, CO_T, CI_T>;
     using Sp = WgSplit<KS, CO_T, CI_T>;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, TPW = Sp::TPW, NW_T = Sp::NW_T, NW_A = Sp::NW_A, NW_C = Sp::NW_C;
     constexpr int APW = Sp::APW, CPW = Sp::CPW;
@@ -273,6 +275,127 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, int Cout, 
     }
 }
 
+// ---------------------------------------------------------------- few input channels (the RGB stem)
+// With Cin <= 4 the generic kernel would pad the input channels to a 16-wide N tile (5x wasted MFMAs at Cin = 3).
+// Here the N dimension packs (ci, kx) pairs instead -- Cin * KS <= 32 columns = 2 N tiles -- so ONE filter row ky
+// of all channels is 2 MFMAs per (co tile, 4 pixels) instead of KS:
+//   B[k = pixel][j = (ci, kx)] = act(X)[ci][y+ky][x0+k+kx]      (per-lane LDS offset ci * PSI + kx)
+//   D tile (co tile a, row ky, half nt): lane holds column q = nt*16 + (lane&15) -> (ci, kx) = (q / KS, q % KS).
+// A block owns 32 output channels; wave w keeps co tile (w & 1), column half (w >> 1), all KS rows: KS tiles.
+// Partial sums go to the same packed [cog][0][tap][32][16] buffer as conv_wgrad_kernel<KS, 2, 1>.
+template <int KS>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_fewcin_kernel(
+    const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
+    const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
+    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int P = (KS - 1) / 2, TAPS = KS * KS, TY = 8, CMAX = 4;
+    constexpr int RS = WG_TX + KS - 1, ROWS = TY + KS - 1;
+    constexpr int PSI = ROWS * RS + 8;                 // planes 8 floats apart (mod 32 it decorrelates the ci groups)
+    constexpr int PSD = TY * WG_TX + 2;
+    constexpr int COB = 32, CIB = 16;
+    static_assert(CMAX * KS <= 32, "two N tiles of (ci, kx) pairs");
+    __shared__ float s_dy[COB * PSD];
+    __shared__ float s_in[CMAX * PSI];
+
+    const int cog = blockIdx.z;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wa = wid & 1, nt = wid >> 1;
+    const size_t HW = (size_t)H * W;
+    const int items = N * tiles_x * tiles_y;
+    const int q = nt * 16 + (lane & 15);               // this lane's column: (ci, kx) pair
+    const bool q_live = q < Cin * KS;
+    const int q_ci = q_live ? q / KS : 0, q_kx = q_live ? q - q_ci * KS : 0;
+    const int a_lane = (wa * 16 + (lane & 15)) * PSD + (lane >> 4);
+    const int b_lane = q_ci * PSI + q_kx + (lane >> 4);
+
+    f32x4 acc[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int n = item / (tiles_x * tiles_y), tile = item - n * (tiles_x * tiles_y);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int X0 = tx * WG_TX, Y0 = ty * TY;
+        __syncthreads();
+        const float* dyn = dy + ((size_t)n * dy_ctot + dy_coff) * HW;
+        if ((W & 3) == 0) {
+            for (int i = threadIdx.x; i < COB * TY * (WG_TX / 4); i += kBlock) {
+                const int c = i / (TY * (WG_TX / 4)), rem = i - c * (TY * (WG_TX / 4));
+                const int r = rem / (WG_TX / 4), col = (rem - r * (WG_TX / 4)) * 4;
+                const int co = cog * COB + c, gy = Y0 + r, gx = X0 + col;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (co < Cout && gy < H && gx < W) v = *reinterpret_cast<const float4*>(dyn + (size_t)co * HW + (size_t)gy * W + gx);
+                float* d = s_dy + c * PSD + r * WG_TX + col;
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < COB * TY * WG_TX; i += kBlock) {
+                const int c = i / (TY * WG_TX), rem = i - c * (TY * WG_TX);
+                const int r = rem / WG_TX, col = rem - r * WG_TX;
+                const int co = cog * COB + c, gy = Y0 + r, gx = X0 + col;
+                float v = 0.f;
+                if (co < Cout && gy < H && gx < W) v = dyn[(size_t)co * HW + (size_t)gy * W + gx];
+                s_dy[c * PSD + r * WG_TX + col] = v;
+            }
+        }
+        const float* xn = x + ((size_t)n * x_ctot + x_coff) * HW;
+        for (int i = threadIdx.x; i < CMAX * ROWS * RS; i += kBlock) {
+            const int c = i / (ROWS * RS), rem = i - c * (ROWS * RS);
+            const int r = rem / RS, col = rem - r * RS;
+            const int gy = Y0 - P + r, gx = X0 - P + col;
+            float v = 0.f;
+            if (c < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                v = xn[(size_t)c * HW + (size_t)gy * W + gx];
+                if (in_scale) v = __fmaf_rn(v, in_scale[c], in_shift[c]);
+                if (in_relu) v = fmaxf(v, 0.f);
+            }
+            s_in[c * PSI + rem] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < TY; ++r) {
+#pragma unroll 2
+            for (int c4 = 0; c4 < WG_TX / 4; ++c4) {
+                const float af = s_dy[r * WG_TX + c4 * 4 + a_lane];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    const float bf = s_in[(r + ky) * RS + c4 * 4 + b_lane];
+                    acc[ky] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[ky], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!q_live) return;   // (after the last barrier) padding columns carry garbage by construction
+    const size_t base = (size_t)cog * TAPS * COB * CIB;
+    const int co4 = wa * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        float* dst = dw_packed + base + ((size_t)(ky * KS + q_kx) * COB + co4) * CIB + q_ci;
+        const f32x4 v = acc[ky];
+        atomic_add_f32(dst, v.x);
+        atomic_add_f32(dst + CIB, v.y);
+        atomic_add_f32(dst + 2 * CIB, v.z);
+        atomic_add_f32(dst + 3 * CIB, v.w);
+    }
+}
+
+template <int KS>
+static int launch_wgrad_fewcin(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift,
+                               int in_relu, const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H,
+                               int W, hipStream_t s) {
+    const int tiles_x = (W + WG_TX - 1) / WG_TX, tiles_y = (H + 7) / 8;
+    const int cogs = (Cout + 31) / 32, items = N * tiles_x * tiles_y;
+    int splits = (256 * 3 + cogs - 1) / cogs;
+    if (splits > items) splits = items;
+    hipLaunchKernelGGL((conv_wgrad_fewcin_kernel<KS>), dim3(splits, 1, cogs), dim3(kBlock), 0, s, x, x_ctot, x_coff, Cin, in_scale,
+                       in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+
+static int g_wgrad_wide = 1;  // cd_debug_set_wgrad_mode bit 2 switches the wide 1x1 plan off (A/B measurements, tests)
 static int g_wgrad_dbg = 0;   // measurement hook: bit 0 skip the atomic flush, bit 1 skip the MFMAs (results are then wrong)
 
 struct WgPlan { int co_t, ci_t; };
@@ -288,18 +411,39 @@ static inline WgPlan wgrad_plan(int ks, int cout, int cin) {
     return p;
 }
 
+// 1x1 with many channels and many pixels: ONE block holds all (or half) of dY's and X's channels of its pixels, so the
+// two tensors are read once instead of once per channel group of the other (measured: the narrow plan spends 56 % of its
+// time staging, 2.5 GB of re-reads at 128 -> 208 channels).  Shapes are the instantiated ones; dead tiles are zeros.
+static inline bool wgrad_wide_plan(int ks, int cout, int cin, int N, int H, int W, WgPlan* p) {
+    if (ks != 1) return false;
+    const int co_need = (cout + 15) / 16, ci_need = (cin + 15) / 16;
+    if (co_need <= 4 && ci_need <= 4) return false;
+    if ((long long)N * ((W + WG_TX - 1) / WG_TX) * ((H + 1) / 2) < 512) return false;   // too few pixel tiles for 256 blocks
+    if (co_need > 16 || ci_need > 16) return false;
+    // measured (profiles/wgrad_sweep_r01.txt): it pays when the narrow plan (64 x 64 channels per block) would read the
+    // tensors >= 6 times in total and the wide shape covers all channels in ONE block
+    const int narrow_groups = ((co_need + 3) / 4) * ((ci_need + 3) / 4);
+    if (narrow_groups < 6) return false;
+    const int co_t = co_need <= 8 ? 8 : (co_need <= 10 ? 10 : (co_need <= 14 ? 14 : 16));
+    const int ci_t = ci_need <= 8 ? 8 : 16;
+    if (co_t * ci_t > 160) return false;   // accumulator budget: <= 40 tiles per wave
+    p->co_t = co_t; p->ci_t = ci_t;
+    return true;
+}
+
 template <int KS, int CO_T, int CI_T>
 static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift,
                           int in_relu, const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H,
                           int W, hipStream_t s) {
-    using Cfg = WgCfg<KS>;
+    using Cfg = WgCfg<KS, CO_T, CI_T>;
     constexpr int COB = CO_T * 16, CIB = CI_T * 16;
     const int tiles_x = (W + WG_TX - 1) / WG_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
     const int cogs = (Cout + COB - 1) / COB, cigs = (Cin + CIB - 1) / CIB;
     const int items = N * tiles_x * tiles_y;
-    // enough blocks to fill the chip (~2 per CU: the LDS tiles allow 2 resident blocks), few enough that the
-    // atomic flush of the partial sums (one per block, all splits hit the same addresses) stays small
-    int splits = (256 * 2 + cogs * cigs - 1) / (cogs * cigs);
+    // enough blocks to fill the chip (~2 per CU: the LDS tiles allow 2 resident blocks; 1 for the wide 1x1 shapes), few
+    // enough that the atomic flush of the partial sums (one per block, all splits hit the same addresses) stays small
+    constexpr int per_cu = (CO_T + CI_T > 16) ? 1 : 2;
+    int splits = (256 * per_cu + cogs * cigs - 1) / (cogs * cigs);
     if (splits > items) splits = items;
     if (splits < 1) splits = 1;
     const size_t lds = sizeof(float) * ((size_t)COB * Cfg::PS_DY + (size_t)CIB * Cfg::PS_IN);
@@ -319,7 +463,8 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
 extern "C" {
 
 int cd_debug_set_wgrad_mode(int bits) {
-    cd::g_wgrad_dbg = bits;
+    cd::g_wgrad_dbg = bits & 11;   // bit 3: generic kernel for the few-input-channel (stem) case
+    cd::g_wgrad_wide = (bits & 4) ? 0 : 1;
     return CD_OK;
 }
 
@@ -327,7 +472,14 @@ size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
     const cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
     const int cob = p.co_t * 16, cib = p.ci_t * 16;
-    return (size_t)((Cout + cob - 1) / cob) * ((Cin + cib - 1) / cib) * ks * ks * cob * cib;
+    size_t n = (size_t)((Cout + cob - 1) / cob) * ((Cin + cib - 1) / cib) * ks * ks * cob * cib;
+    cd::WgPlan w;
+    if (cd::wgrad_wide_plan(ks, Cout, Cin, 1 << 20, 2, 32, &w)) {   // the wide 1x1 layout (chosen per launch by the image size)
+        const int wob = w.co_t * 16, wib = w.ci_t * 16;
+        const size_t m = (size_t)((Cout + wob - 1) / wob) * ((Cin + wib - 1) / wib) * wob * wib;
+        if (m > n) n = m;
+    }
+    return n;
 }
 
 int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift,
@@ -341,10 +493,13 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     hipStream_t s = (hipStream_t)stream;
     // accumulate bit 1 (value 2): the caller has already zeroed `workspace` (one memset over an arena of many)
     if (!(accumulate & 2) && hipMemsetAsync(workspace, 0, wsf * sizeof(float), s) != hipSuccess) return CD_ERR_LAUNCH;
-    const cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
+    cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
+    const bool wide = cd::g_wgrad_wide && cd::wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p);
     int rc = CD_ERR_UNSUPPORTED;
 #define CD_WG(K, A, C) rc = cd::launch_wgrad_t<K, A, C>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, s)
     if (ks == 11) CD_WG(11, 1, 1);
+    else if (ks == 7 && Cin <= 4 && p.co_t == 2 && !(cd::g_wgrad_dbg & 8))   // the RGB stem
+        rc = cd::launch_wgrad_fewcin<7>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, s);
     else if (ks == 7) { if (p.co_t == 2) CD_WG(7, 2, 1); else CD_WG(7, 1, 1); }
     else if (ks == 5) { if (p.co_t == 2) CD_WG(5, 2, 1); else CD_WG(5, 1, 1); }
     else if (ks == 3) {
@@ -352,6 +507,12 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
         else if (p.co_t == 2) CD_WG(3, 2, 1);
         else if (p.ci_t == 2) CD_WG(3, 1, 2);
         else CD_WG(3, 1, 1);
+    } else if (wide) {
+        if (p.co_t == 8 && p.ci_t == 16) CD_WG(1, 8, 16);
+        else if (p.co_t == 10 && p.ci_t == 8) CD_WG(1, 10, 8);
+        else if (p.co_t == 10 && p.ci_t == 16) CD_WG(1, 10, 16);
+        else if (p.co_t == 14 && p.ci_t == 8) CD_WG(1, 14, 8);
+        else if (p.co_t == 16 && p.ci_t == 8) CD_WG(1, 16, 8);
     } else {
         if (p.co_t == 4 && p.ci_t == 4) CD_WG(1, 4, 4);
         else if (p.co_t == 4 && p.ci_t == 2) CD_WG(1, 4, 2);

@@ -197,7 +197,9 @@ int cd_debug_force_conv_tile_rows(int ty);
 int cd_debug_force_conv_co_tiles(int co_tiles);
 int cd_debug_set_conv_pipeline(int on);
 /* Measurement hook for cd_conv2d_wgrad: bit 0 skips the flush of the partial sums, bit 1 the matrix instructions
- * (the result is then wrong; 0 restores normal operation). */
+ * (the result is then wrong); bit 2 switches the wide 1x1 plan off, bit 3 the few-input-channel (stem) kernel (correct
+ * results, for A/B timing and tests);
+ * 0 restores normal operation. */
 int cd_debug_set_wgrad_mode(int bits);
 
 /* Weight gradient dw[Cout][Cin][ks][ks] (=, or += when accumulate) of the same convolution:

@@ -28,6 +28,42 @@ def test_wgrad_matches_autograd(N, Cin, Cout, H, W, ks):
     assert (dw.cpu().double() - 2 * ref).abs().max().item() < 6e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [
+    (2, 128, 208, 130, 128),   # 14 x 8 channel tiles (13 live), odd number of 2-row tiles
+    (2, 256, 160, 128, 100),   # 10 x 16, W % 4 == 0 but not a multiple of the 32-pixel tile
+    (2, 128, 160, 128, 128),   # 10 x 8
+    (2, 256, 112, 128, 126),   # 8 x 16 (7 live), W % 4 != 0: unpipelined staging
+    (3, 120, 256, 96, 128),    # 16 x 8, Cin not a multiple of 16
+    (2, 128, 128, 128, 128),   # narrow plan in both modes (4 groups only)
+])
+def test_wide_1x1_wgrad_matches_autograd_and_the_narrow_plan(N, Cin, Cout, H, W):
+    """The wide 1x1 weight-gradient plan (all channels of dY and X of a pixel tile in one workgroup; chosen for large
+    images) against autograd in fp64 and against the narrow plan (cd_debug_set_wgrad_mode bit 2)."""
+    import torch
+    from consistent_depth_amd import _native
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin + 3, H, W, generator=g)
+    dy = torch.randn(N, Cout + 5, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    act = torch.relu(x[:, 2:2 + Cin].double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    ref = torch.einsum("nohw,nihw->oi", dy[:, 1:1 + Cout].double(), act).reshape(Cout, Cin, 1, 1)
+    ws = conv.wgrad_workspace(Cout, Cin, 1, "cuda")
+    out = {}
+    try:
+        for name, bits in (("wide", 0), ("narrow", 4)):
+            _native.lib().cd_debug_set_wgrad_mode(bits)
+            dw = torch.empty(Cout, Cin, 1, 1, device="cuda")
+            conv.conv2d_wgrad(x.cuda(), dy.cuda(), Cin, Cout, 1, dw, ws, x_coff=2, dy_coff=1, in_scale=sc.cuda(),
+                              in_shift=sh.cuda(), in_relu=True)
+            out[name] = dw.cpu().double()
+    finally:
+        _native.lib().cd_debug_set_wgrad_mode(0)
+    scale = ref.abs().max().item()
+    assert (out["wide"] - ref).abs().max().item() < 3e-5 * scale
+    assert (out["narrow"] - ref).abs().max().item() < 3e-5 * scale
+
+
 def test_bn_normalize_and_backward_match_torch():
     import torch
     from consistent_depth_amd.ops import conv, layers
