@@ -31,6 +31,10 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x2 (fp32), SURVEY.md 8d
+# HBM traffic of the gradient path per pair at 384x224 from rocprofv3 PMC (profiles/rocprofv3_loss_slab_b256_r01.txt:
+# FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE, source + gather pass; raw counters: 5.60e6).  Only valid
+# for the size it was measured at; null otherwise.
+LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = 8.96e6
 
 
 _T0 = time.perf_counter()
@@ -235,7 +239,9 @@ def main():
             ach = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch / (avg * 1e-3) / 1e9
             out["roofline"] = {"kernel": "loss_source_kernel + loss_gather4_kernel (one gradient launch)", "bound": "hbm", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": None, "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
+                               "traffic": (LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 * args.loss_batch if (H, W) == (384, 224) else None),
+                               "traffic_source": "profiles/rocprofv3_loss_slab_b256_r01.txt (PMC, separate passes; FETCH_SIZE x2 + WRITE_SIZE)",
+                               "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
         if world == 1 and not args.no_cpu_baseline:
             # the reference step restated on the host (oracle/cpu_step.py), in a bounded subprocess so a slow
