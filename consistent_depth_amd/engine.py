@@ -132,7 +132,8 @@ class GraphedFineTuneStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
+            # thread_local: other threads (RCCL's watchdog) may touch the runtime while this thread captures
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 guard, parts = self.step._grads(st_images, st_meta)
                 if self.step.world == 1:
                     self.step._update(guard)

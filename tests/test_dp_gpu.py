@@ -16,42 +16,49 @@ WORKER = r"""
 import argparse, json, os, sys, torch
 sys.path.insert(0, %(repo)r)
 from consistent_depth_amd import parallel, synthetic
-from consistent_depth_amd.engine import FineTuneStep
+from consistent_depth_amd.engine import FineTuneStep, GraphedFineTuneStep
 from consistent_depth_amd.monodepth.depth_model_registry import get_depth_model
 rank, local_rank, world = parallel.init()
 dev = parallel.local_device(local_rank); torch.cuda.set_device(dev)
 params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0, learning_rate=4e-4, optimizer="Adam")
 model = get_depth_model("mc")(seed=0); model.train()
-step = FineTuneStep(model, params, world=world)
+eager = FineTuneStep(model, params, world=world)
+GRAPH = %(graph)d
+step = GraphedFineTuneStep(eager, eager_steps=1) if GRAPH else eager
 t = lambda a: torch.tensor(a, device=dev)
 losses = []
-for it in range(2):
+for it in range(%(iters)d):
     b = synthetic.make_scene_batch(2, 64, 48, seed=10 * it + rank)          # every rank trains on its own pairs
     imgs = torch.rand(2, 2, 3, 64, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(100 * it + rank))
     meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
             "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
     loss, _ = step(imgs, meta)
     losses.append(loss.item())
-w = step.opt.flat_param
+w = eager.opt.flat_param
 ws = [torch.zeros_like(w) for _ in range(world)]
 torch.distributed.all_gather(ws, w)
 same = all(torch.equal(ws[0], x) for x in ws)
 if rank == 0:
-    print("RESULT " + json.dumps({"world": world, "same_weights": same, "losses": losses, "steps": int(step.opt.step_dev.item())}))
+    print("RESULT " + json.dumps({"world": world, "same_weights": same, "losses": losses, "steps": int(eager.opt.step_dev.item()),
+                                  "graphed": getattr(step, "graphed", None), "capture_error": getattr(step, "capture_error", None)}))
 torch.distributed.barrier(); torch.distributed.destroy_process_group()
 """
 
 
-def test_two_ranks_share_one_gpu_and_stay_in_sync(tmp_path):
+@pytest.mark.parametrize("graph", [0, 1], ids=["eager", "hip_graph"])
+def test_two_ranks_share_one_gpu_and_stay_in_sync(tmp_path, graph):
+    iters = 4 if graph else 2      # graph: 1 eager step, capture + 3 replays; the all-reduce and Adam stay outside the graph
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"repo": REPO})
+    script.write_text(WORKER % {"repo": REPO, "graph": graph, "iters": iters})
     env = dict(os.environ, CD_AMD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(29541 + graph), str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
     assert lines, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.loads(lines[-1][len("RESULT "):])
-    assert res["world"] == 2 and res["steps"] == 2
+    assert res["world"] == 2 and res["steps"] == iters
+    if graph:
+        assert res["graphed"] is True, res["capture_error"]
     assert res["same_weights"], "ranks diverged: the gradient all-reduce / guarded Adam are not in lock-step"
     assert all(l == l for l in res["losses"])
