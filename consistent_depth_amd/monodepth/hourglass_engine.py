@@ -109,8 +109,10 @@ class ConvUnit:
                           dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True)
         else:
             L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias))
-        C.conv2d_wgrad(s.buf, gbuf, self.cin, self.cout, self.ks, _grad_of(self.conv.weight), self.wgrad_ws, x_coff=s.coff,
-                       dy_coff=g_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
+        dw = _grad_of(self.conv.weight)
+        self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
+            s.buf, gbuf, self.cin, self.cout, self.ks, dw, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,
+            in_shift=s.shift, in_relu=s.relu, prezeroed=True))
         if s.gbuf is not None:
             C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
@@ -171,10 +173,14 @@ class PointwiseGroup:
         s = self.src
         L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True)
         # ONE weight-gradient GEMM for the four filters (X is read once), then split the rows
-        C.conv2d_wgrad(s.buf, self.Pg, self.cin, self.ctot, 1, self._dw, self.wgrad_ws, x_coff=s.coff, dy_coff=0,
-                       in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
-        for m in self.members:
-            _grad_of(m.conv.weight).copy_(self._dw[m.coff:m.coff + m.cout])
+        grads = [(_grad_of(m.conv.weight), m) for m in self.members]
+
+        def wgrad():
+            C.conv2d_wgrad(s.buf, self.Pg, self.cin, self.ctot, 1, self._dw, self.wgrad_ws, x_coff=s.coff, dy_coff=0,
+                           in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
+            for g, m in grads:
+                g.copy_(self._dw[m.coff:m.coff + m.cout])
+        self.eng.on_wgrad_stream(wgrad)
         if s.gbuf is not None:
             C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
@@ -221,11 +227,19 @@ class HourglassEngine:
                 self._pack_index[id(m)] = (self._pack.add(m.weight, False), self._pack.add(m.weight, True))
         self._pack.build()
         # streams: one per Channels level for its full-resolution side, and three branch streams per parent stream
-        mode = os.environ.get("CD_AMD_ENGINE_STREAMS", "level")   # none | branch | level | both (measured: 73 | 80 | 86 | 76 pairs/s)
+        mode = os.environ.get("CD_AMD_ENGINE_STREAMS", "level")   # none | branch | level | both (eager, round start: 73 | 80 | 86 | 76 pairs/s;
+        # with graph replay: none 100.6, level 109.6)
         self.use_branch_streams = mode in ("branch", "both")
         self.use_level_streams = mode in ("level", "both")
         self._level_streams = {lvl: torch.cuda.Stream(device=self.device) for lvl in (1, 2, 3, 4)}
         self._branch_streams = {}
+        # Weight gradients are off the critical path (only the optimiser needs them), so they could trail the
+        # input-gradient chain on their own stream.  Measured on MI355X: SLOWER (graph replay 109.4 -> 102.9 pairs/s, eager
+        # 107.5 -> 105.9): the wgrad kernels fill every CU on their own and only take cycles from the dgrad chain, and the
+        # forked graph doubles the host cost of a replay.  Opt-in for experiments: CD_AMD_ENGINE_WGRAD_STREAM=1.
+        self._wgrad_stream = torch.cuda.Stream(device=self.device) \
+            if mode != "none" and os.environ.get("CD_AMD_ENGINE_WGRAD_STREAM", "0") == "1" else None
+        self._wgrad_pending = False
 
     def packed(self, conv_mod):
         i, j = self._pack_index[id(conv_mod)]
@@ -254,6 +268,21 @@ class HourglassEngine:
             done = torch.cuda.Event()
             done.record(st)
             cur.wait_event(done)
+
+    def on_wgrad_stream(self, job):
+        """Run `job` (a weight-gradient launch sequence) on the wgrad stream, ordered after everything enqueued so far
+        on the current stream; `_backward` joins before returning."""
+        ws = self._wgrad_stream
+        if ws is None:
+            job()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        ws.wait_event(ready)
+        with torch.cuda.stream(ws):
+            job()
+        self._wgrad_pending = True
 
     def _on_side(self, level, job):
         """Run `job` on the level's side stream, forked from the current stream; returns the completion event
@@ -459,6 +488,9 @@ class HourglassEngine:
         for a in plan["acts"]:  # first gradient contribution overwrites, later ones accumulate
             a.grad_written = False
         self._run_backward(plan["steps"])
+        if self._wgrad_pending:   # join: the parameter gradients are complete when this returns (stream order)
+            torch.cuda.current_stream(self.device).wait_stream(self._wgrad_stream)
+            self._wgrad_pending = False
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (N,3,H,W) -> pred_d (N,1,H,W) (log depth), attached to autograd when grad is enabled."""
