@@ -35,9 +35,13 @@ constexpr int CV_TX = 32;  // output tile width (2 M-tiles)
 template <int KS, int TY_> struct ConvCfg {
     static constexpr int TY = TY_;                          // output rows per block (4 waves x TY/4 rows): 4, 8 or 16
     static constexpr int CI_CHUNK = (KS >= 7) ? 4 : (KS == 1 ? 32 : 8);  // input channels staged per round (1x1 = pure GEMM: long K chunks)
-    static constexpr int RS = CV_TX + KS - 1;              // LDS row stride (floats)
+    static constexpr int RS = CV_TX + KS - 1;              // logical tile row (floats): [X0 - P, X0 + 32 + P)
     static constexpr int ROWS = TY + KS - 1;
-    static constexpr int PLANE_RAW = ROWS * RS;
+    // physical LDS row: the 16-byte aligned superset [X0 - PADL, X0 + 32 + PADL), staged with 16-byte global loads;
+    // logical column c sits at c + COFF
+    static constexpr int PADL = (((KS - 1) / 2) + 3) & ~3;
+    static constexpr int RSP = CV_TX + 2 * PADL, COFF = PADL - (KS - 1) / 2;
+    static constexpr int PLANE_RAW = ROWS * RSP;
     // plane stride == 16 (mod 32): the 4 channels of an A fragment hit disjoint bank halves
     static constexpr int PS = PLANE_RAW + ((16 - (PLANE_RAW % 32)) + 32) % 32;
 };
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     int slices, int pipe) {
     using Cfg = ConvCfg<KS, TYP>;
     constexpr int TY = Cfg::TY, CI = Cfg::CI_CHUNK, RS = Cfg::RS, PS = Cfg::PS, ROWS = Cfg::ROWS;
+    constexpr int RSP = Cfg::RSP, COFF = Cfg::COFF, PADL = Cfg::PADL;
     constexpr int P = (KS - 1) / 2, TAPS = KS * KS;
     constexpr int COB = CO_T * 16, COBP = co_stride_padded(COB);
     constexpr int RPW = TY / 4;          // output rows per wave
@@ -128,22 +133,24 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
     // while the MFMAs of the current chunk run; the producer's BN-apply + ReLU is applied when the registers are
     // written to LDS (scale/shift staged once in LDS).  Per-thread element offsets are 32-bit and precomputed; the
     // chunk base pointers are wave-uniform.  Used when the registers fit (PIPE_OK) and the launch asks for it.
-    constexpr bool VEC_IN = (KS == 1);   // no halo: tile rows are 32 contiguous pixels -> 16-byte loads (needs W % 4 == 0)
-    constexpr int IN_ELEMS = VEC_IN ? CI * ROWS * (RS / 4) : CI * ROWS * RS;
+    // the input tile is staged as float4 of the aligned superset rows (needs W % 4 == 0: an aligned float4 is then inside
+    // or outside the image as a whole); otherwise scalar, unpipelined
+    constexpr bool VEC_IN = true;
+    constexpr int IN_ELEMS = CI * ROWS * (RSP / 4);
     constexpr int PF_IN = (IN_ELEMS + kBlock - 1) / kBlock;
     constexpr int PF_W = (W_ROWS * ROW4 + kBlock - 1) / kBlock;
-    constexpr bool PIPE_OK = (PF_IN * (VEC_IN ? 5 : 2) + PF_W * 5) <= CD_CONV_PIPE_MAX_REGS;
-    const bool vec_in = VEC_IN && ((W & 3) == 0);
-    const bool pipelined = PIPE_OK && pipe && (!VEC_IN || vec_in) && (size_t)CI * HW < (1u << 30);
+    constexpr bool PIPE_OK = (PF_IN * 5 + PF_W * 5) <= CD_CONV_PIPE_MAX_REGS;
+    const bool vec_in = (W & 3) == 0;
+    const bool pipelined = PIPE_OK && pipe && vec_in && (size_t)CI * HW < (1u << 30);
     float* s_aff = s_w + W_ROWS * COBP;  // [2][n_chunks * CI] scale, shift of the input channels (pipelined path)
 
     // ---- generic (non-pipelined) staging helpers
     auto in_load4 = [&](int chunk, int i) -> float4 {
-        const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
-        const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
-        const int ci = chunk * CI + cc, gy = Y0 + r, gx = X0 + c;
+        const int cc = i / (ROWS * (RSP / 4)), rem = i - cc * (ROWS * (RSP / 4));
+        const int r = rem / (RSP / 4), q4 = (rem - r * (RSP / 4)) * 4;
+        const int ci = chunk * CI + cc, gy = Y0 - P + r, gx = X0 - PADL + q4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ci < Cin && gy < H && gx < W) {
+        if (ci < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
             v = *reinterpret_cast<const float4*>(xin + (size_t)ci * HW + (size_t)gy * W + gx);
             if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
             if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -163,13 +170,14 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
         return v;
     };
     auto in_lds4 = [&](int i) -> int {
-        const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
-        const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
-        return cc * PS + r * RS + c;
+        const int cc = i / (ROWS * (RSP / 4)), rem = i - cc * (ROWS * (RSP / 4));
+        const int r = rem / (RSP / 4), q4 = (rem - r * (RSP / 4)) * 4;
+        return cc * PS + r * RSP + q4;
     };
     auto in_lds1 = [&](int i) -> int {
-        const int cc = i / (ROWS * RS);
-        return cc * PS + (i - cc * (ROWS * RS));
+        const int cc = i / (ROWS * RS), rem = i - cc * (ROWS * RS);
+        const int r = rem / RS;
+        return cc * PS + r * RSP + (rem - r * RS) + COFF;
     };
     auto w_src = [&](int i) -> int {   // offset of the float4 from the chunk's base in packed group 0; -1 = zero fill
         const int row = i / ROW4, c4 = i - row * ROW4;
@@ -192,17 +200,10 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
                 const int i = threadIdx.x + q * kBlock;
                 int off = -1;
                 if (i < IN_ELEMS) {
-                    if constexpr (VEC_IN) {
-                        const int cc = i / (ROWS * (RS / 4)), rem = i - cc * (ROWS * (RS / 4));
-                        const int r = rem / (RS / 4), c = (rem - r * (RS / 4)) * 4;
-                        const int gy = Y0 + r, gx = X0 + c;
-                        if (gy < H && gx < W) off = cc * (int)HW + gy * W + gx;
-                    } else {
-                        const int cc = i / (ROWS * RS), rem = i - cc * (ROWS * RS);
-                        const int r = rem / RS, c = rem - r * RS;
-                        const int gy = Y0 - P + r, gx = X0 - P + c;
-                        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) off = cc * (int)HW + gy * W + gx;
-                    }
+                    const int cc = i / (ROWS * (RSP / 4)), rem = i - cc * (ROWS * (RSP / 4));
+                    const int r = rem / (RSP / 4), q4 = (rem - r * (RSP / 4)) * 4;
+                    const int gy = Y0 - P + r, gx = X0 - PADL + q4;
+                    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) off = cc * (int)HW + gy * W + gx;
                 }
                 in_off[q] = off;
             }
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
 #pragma unroll
             for (int q = 0; q < PF_IN; ++q) {
                 const int i = threadIdx.x + q * kBlock;
-                const int cc = VEC_IN ? i / (ROWS * (RS / 4)) : i / (ROWS * RS);
+                const int cc = i / (ROWS * (RSP / 4));
                 const bool ok = in_off[q] >= 0 && cc < ci_left;
                 if constexpr (VEC_IN) pf_in4[q] = ok ? *reinterpret_cast<const float4*>(xc + in_off[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
                 else pf_in1[q] = ok ? xc[in_off[q]] : 0.f;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
             for (int q = 0; q < PF_IN; ++q) {
                 const int i = threadIdx.x + q * kBlock;
                 if (i < IN_ELEMS) {
-                    const int cc = VEC_IN ? i / (ROWS * (RS / 4)) : i / (ROWS * RS);
+                    const int cc = i / (ROWS * (RSP / 4));
                     const bool live = in_off[q] >= 0 && cc < ci_left;   // zero padding stays zero
                     float sc = 1.f, sh = 0.f;
                     if (in_scale) { sc = s_aff[chunk * CI + cc]; sh = s_aff[n_chunks * CI + chunk * CI + cc]; }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_kernel(
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const int row = wid * RPW + (m >> 1), ct = m & 1;
-                        const float af = s_in[c4 * 4 * PS + (row + ky) * RS + ct * 16 + kx + a_lane];
+                        const float af = s_in[c4 * 4 * PS + (row + ky) * RSP + ct * 16 + kx + COFF + a_lane];
 #pragma unroll
                         for (int t = 0; t < CO_T; ++t)
                             acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[t], acc[m][t], 0, 0, 0);

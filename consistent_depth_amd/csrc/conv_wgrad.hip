@@ -45,7 +45,11 @@ template <int KS, int CO_T = 1, int CI_T = 1> struct WgCfg {
     static constexpr int TY = (KS == 1) ? ((CO_T + CI_T > 16) ? 2 : 4) : 8;
     static constexpr int TAPS = KS * KS;
     static constexpr int RS = WG_TX + KS - 1, ROWS = TY + KS - 1;
-    static constexpr int PS_IN_RAW = ROWS * RS;
+    // physical row of the input tile in LDS: the 16-byte aligned superset [X0 - PADL, X0 + 32 + PADL) of the logical
+    // [X0 - P, X0 + 32 + P), so that rows are staged with 16-byte global loads; logical column c sits at c + COFF
+    static constexpr int PADL = (((KS - 1) / 2) + 3) & ~3;
+    static constexpr int RSP = WG_TX + 2 * PADL, COFF = PADL - (KS - 1) / 2;
+    static constexpr int PS_IN_RAW = ROWS * RSP;
     static constexpr int PS_IN = PS_IN_RAW + ((2 - (PS_IN_RAW % 32)) + 32) % 32;   // == 2 (mod 32)
     static constexpr int PS_DY = TY * WG_TX + 2;                                     // == 2 (mod 32)
 };
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, TPW = Sp::TPW, NW_T = Sp::NW_T, NW_A = Sp::NW_A, NW_C = Sp::NW_C;
     constexpr int APW = Sp::APW, CPW = Sp::CPW;
     constexpr int RS = Cfg::RS, ROWS = Cfg::ROWS, PSI = Cfg::PS_IN, PSD = Cfg::PS_DY, WG_TY = Cfg::TY;
+    constexpr int RSP = Cfg::RSP, COFF = Cfg::COFF, PADL = Cfg::PADL;
     constexpr int COB = CO_T * 16, CIB = CI_T * 16;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -198,6 +203,22 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
                 *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
                 *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
             }
+        } else if ((W & 3) == 0) {
+            // halo tile through 16-byte loads of the aligned superset (W % 4 == 0: an aligned float4 is inside or outside as a whole)
+            for (int i = threadIdx.x; i < CIB * ROWS * (RSP / 4); i += kBlock) {
+                const int c = i / (ROWS * (RSP / 4)), rem = i - c * (ROWS * (RSP / 4));
+                const int r = rem / (RSP / 4), q4 = (rem - r * (RSP / 4)) * 4;
+                const int ci = cig * CIB + c, gy = Y0 - P + r, gx = X0 - PADL + q4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < Cin && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                    v = *reinterpret_cast<const float4*>(xn + (size_t)ci * HW + (size_t)gy * W + gx);
+                    if (in_scale) { const float sc = in_scale[ci], sh = in_shift[ci]; v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh); }
+                    if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                float* d = s_in + c * PSI + r * RSP + q4;   // plane stride is 2 (mod 4): 8-byte aligned only
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+            }
         } else
         for (int i = threadIdx.x; i < CIB * ROWS * RS; i += kBlock) {
             const int c = i / (ROWS * RS), rem = i - c * (ROWS * RS);
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
                 if (in_scale) v = __fmaf_rn(v, in_scale[ci], in_shift[ci]);  // same fma as the BN backward's mask
                 if (in_relu) v = fmaxf(v, 0.f);
             }
-            s_in[c * PSI + r * RS + col] = v;
+            s_in[c * PSI + r * RSP + col + COFF] = v;
         }
         __syncthreads();
         }
@@ -229,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
                         const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
                         for (int c = 0; c < CPW; ++c) {
-                            const float bf = s_in[(c * NW_C + wc) * 16 * PSI + (r + ky) * RS + c4 * 4 + kx + b_lane];
+                            const float bf = s_in[(c * NW_C + wc) * 16 * PSI + (r + ky) * RSP + c4 * 4 + kx + COFF + b_lane];
 #pragma unroll
                             for (int a = 0; a < APW; ++a)
                                 acc[t][a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf, acc[t][a][c], 0, 0, 0);
