@@ -113,13 +113,22 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_reduce_kernel(const float*
     const float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
     float t1 = 0.f, t2 = 0.f;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
-        const float rv = xh[i];
+    auto term = [&](float rv, float dval) {
         const float pre = raw ? __fmaf_rn(rv, sc, sh) : g * rv + b;
         const float xv = raw ? (gamma ? (rv - xm) * xs : pre) : rv;
-        const float dv = pre > 0.f ? d[i] : 0.f;
+        const float dv = pre > 0.f ? dval : 0.f;
         t1 += dv;
         t2 += dv * xv;
+    };
+    if ((HW & 3) == 0) {   // 16-byte loads (plane starts are 16-byte aligned when HW % 4 == 0)
+        const float4* d4 = reinterpret_cast<const float4*>(d);
+        const float4* x4 = reinterpret_cast<const float4*>(xh);
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW / 4; i += gridDim.x * kBlock) {
+            const float4 rv = x4[i], dv = d4[i];
+            term(rv.x, dv.x); term(rv.y, dv.y); term(rv.z, dv.z); term(rv.w, dv.w);
+        }
+    } else {
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) term(xh[i], d[i]);
     }
     t1 = block_sum(t1, lds);
     t2 = block_sum(t2, lds);
@@ -152,12 +161,23 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
     }
     float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
-        const float rv = xh[i];
+    auto apply = [&](float rv, float dval) -> float {
         const float pre = raw ? __fmaf_rn(rv, sc, sh) : g * rv + b;
         const float xv = raw ? (gamma ? (rv - xm) * xs : pre) : rv;
-        const float dv = pre > 0.f ? d[i] : 0.f;
-        d[i] = k * (dv - m1 - xv * m2);
+        const float dv = pre > 0.f ? dval : 0.f;
+        return k * (dv - m1 - xv * m2);
+    };
+    if ((HW & 3) == 0) {
+        float4* d4 = reinterpret_cast<float4*>(d);
+        const float4* x4 = reinterpret_cast<const float4*>(xh);
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW / 4; i += gridDim.x * kBlock) {
+            const float4 rv = x4[i];
+            float4 dv = d4[i];
+            dv.x = apply(rv.x, dv.x); dv.y = apply(rv.y, dv.y); dv.z = apply(rv.z, dv.z); dv.w = apply(rv.w, dv.w);
+            d4[i] = dv;
+        }
+    } else {
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) d[i] = apply(xh[i], d[i]);
     }
 }
 
@@ -259,7 +279,17 @@ __global__ __launch_bounds__(kBlock) void add_slice_kernel(const float* __restri
     const int c = blockIdx.y, n = blockIdx.z;
     const float* s = src + ((size_t)n * s_ctot + s_coff + c) * HW;
     float* d = dst + ((size_t)n * d_ctot + d_coff + c) * HW;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) d[i] = accumulate ? d[i] + s[i] : s[i];
+    if ((HW & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        float4* d4 = reinterpret_cast<float4*>(d);
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW / 4; i += gridDim.x * kBlock) {
+            float4 v = s4[i];
+            if (accumulate) { const float4 o = d4[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            d4[i] = v;
+        }
+    } else {
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) d[i] = accumulate ? d[i] + s[i] : s[i];
+    }
 }
 
 // out[c] (+)= sum over n, y, x of src[n][coff+c]   (bias gradient of a conv that is NOT followed by BatchNorm).
