@@ -111,7 +111,11 @@ def test_hip_graph_replay_follows_the_eager_trajectory():
     print(f"\nlosses eager {loss_e}\nlosses graph {loss_g}\ndepth rel-L1 graph vs eager {_rel_l1(depth_g, depth_e):.2e}  "
           f"eager vs eager {run_to_run:.2e}")
     assert loss_g[0] == pytest.approx(loss_e[0], rel=1e-5)          # first step: same eager code
-    # later steps: within the run-to-run spread of the eager path (atomics -> chaotic amplification, ~1e-4..1e-3 in
-    # the loss and a few 1e-2 in the depth after 4 Adam steps at random init), with head room for an unlucky draw
-    np.testing.assert_allclose(loss_g, loss_e, rtol=max(10 * _rel_l1(loss_e2, loss_e), 3e-3))
-    assert _rel_l1(depth_g, depth_e) < 3 * run_to_run + 2e-2
+    # Step 2 sees the weights after ONE update: only the atomics' round-off separates the runs (observed 2e-7).  Later
+    # steps diverge chaotically (sign-like Adam on noise-level gradients, observed up to 7e-4 in the loss and 4e-2 in the
+    # depth between two EAGER runs), so they get loose bounds -- a replay bug (stale inputs, missing update) moves the
+    # losses by >10 % because the batches differ (12.6, 12.3, 9.0, 6.3).
+    assert loss_g[1] == pytest.approx(loss_e[1], rel=1e-3)
+    np.testing.assert_allclose(loss_g[2:], loss_e[2:], rtol=5e-2)
+    assert loss_g[-1] < loss_g[0]
+    assert _rel_l1(depth_g, depth_e) < 3 * run_to_run + 5e-2
