@@ -1,0 +1,98 @@
+"""CPU: host-side logic added around the HIP path -- the launch-shape tuning cache and the graph step's input
+bookkeeping.  No GPU, no compute calls."""
+import json
+
+import pytest
+import torch
+
+
+def test_tuning_cache_round_trips_through_a_file(tmp_path, monkeypatch):
+    from consistent_depth_amd.ops import conv
+    path = tmp_path / "tune.json"
+    monkeypatch.setenv("CD_AMD_CONV_TUNE_CACHE", str(path))
+    saved, loaded = dict(conv._TUNED), conv._TUNE_CACHE_LOADED[0]
+    try:
+        conv._TUNED.clear()
+        key = (7, 32, 64, 8, 96, 56, 1, 1, 1, 0, 224, 224)
+        conv._TUNED[key] = (8, 1)
+        conv._TUNED[(1, 128, 208, 8, 384, 224, 0, 1, 1, 0, 128, 432)] = None      # "no valid shape" is cached too
+        conv._save_tune_cache()
+        assert sorted(map(str, json.load(open(path)).values())) == ["None", "[8, 1]"]
+        conv._TUNED.clear()
+        conv._TUNE_CACHE_LOADED[0] = False
+        conv._load_tune_cache()
+        assert conv._TUNED[key] == (8, 1)
+        assert conv._TUNED[(1, 128, 208, 8, 384, 224, 0, 1, 1, 0, 128, 432)] is None
+        # a corrupt file is ignored (shapes are simply measured again)
+        path.write_text("{not json")
+        conv._TUNED.clear()
+        conv._TUNE_CACHE_LOADED[0] = False
+        conv._load_tune_cache()
+        assert conv._TUNED == {}
+    finally:
+        conv._TUNED.clear()
+        conv._TUNED.update(saved)
+        conv._TUNE_CACHE_LOADED[0] = loaded
+
+
+def test_autotune_switch(monkeypatch):
+    from consistent_depth_amd.ops import conv
+    monkeypatch.setenv("CD_AMD_CONV_AUTOTUNE", "0")
+    assert not conv.autotune_enabled()
+    assert conv.tuned_config(3, 32, 64, 2, 24, 32, "cpu") is None      # disabled: library heuristic, nothing is launched
+    monkeypatch.delenv("CD_AMD_CONV_AUTOTUNE")
+    assert conv.autotune_enabled()
+
+
+def _meta(B=2, H=8, W=12, with_cache=False):
+    g = {"flows": [torch.zeros(B, 2, H, W), torch.ones(B, 2, H, W)], "masks": [torch.ones(B, 1, H, W), torch.ones(B, 1, H, W)]}
+    if with_cache:
+        g["mask_sums"] = torch.full((B, 2), float(H * W))
+    return {"intrinsics": torch.zeros(B, 2, 4), "extrinsics": torch.zeros(B, 2, 3, 4), "geometry_consistency": g}
+
+
+def test_graph_step_input_bookkeeping():
+    from consistent_depth_amd import engine
+    m = _meta()
+    flat = engine._flatten(m)
+    assert [p for p, _ in flat] == [("extrinsics",), ("geometry_consistency", "flows", 0), ("geometry_consistency", "flows", 1),
+                                   ("geometry_consistency", "masks", 0), ("geometry_consistency", "masks", 1), ("intrinsics",)]
+    clone = engine._clone_tree(m)
+    for (pa, a), (pb, b) in zip(flat, engine._flatten(clone)):
+        assert pa == pb and torch.equal(a, b) and a.data_ptr() != b.data_ptr()
+    sig = engine.GraphedFineTuneStep._signature
+    img = torch.zeros(2, 2, 3, 8, 12)
+    assert sig(img, m) == sig(img.clone(), _meta())
+    assert sig(img, m) != sig(img, _meta(with_cache=True))            # optional cached constants change the graph
+    assert sig(img, m) != sig(torch.zeros(3, 2, 3, 8, 12), _meta(B=3))  # so does the batch size
+
+
+def test_graph_step_runs_eagerly_first_and_falls_back_when_capture_is_unavailable():
+    """Without a device there is nothing to capture: the wrapper must hand the first calls to the eager step and, when
+    capture raises, stay eager for good (same kernels) instead of failing."""
+    from consistent_depth_amd import engine
+
+    class _Step:
+        world = 1
+        calls = 0
+
+        def __call__(self, images, metadata):
+            self.calls += 1
+            return torch.tensor(float(self.calls)), {}
+
+        def _grads(self, images, metadata):
+            raise RuntimeError("no device")
+
+    st = _Step()
+    g = engine.GraphedFineTuneStep(st, eager_steps=2)
+    img, m = torch.zeros(1, 2, 3, 8, 12), _meta(B=1)
+    g._capture = lambda images, metadata: (_ for _ in ()).throw(RuntimeError("stream capture unsupported"))
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        for expected in (1.0, 2.0, 3.0, 4.0):
+            loss, _ = g(img, m)
+            assert loss.item() == expected
+    finally:
+        torch.cuda.synchronize = real_sync
+    assert g.graphed is False and "capture unsupported" in g.capture_error
