@@ -47,6 +47,8 @@ SIGNATURES = {
     "cd_debug_set_wgrad_mode": (c_i, [c_i]),
     "cd_conv2d_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),
     "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cd_conv2d_wgrad_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
+    "cd_conv2d_wgrad_unpack_table": (c_i, [c_p, c_i, c_p]),
     "cd_bn_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "cd_bn_finalize": (c_i, [c_p, c_i, c_i, c_i, ctypes.c_double, c_f, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     "cd_bn_relu_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -419,6 +419,27 @@ static int launch_wgrad_fewcin(const float* x, int x_ctot, int x_coff, int Cin, 
 static int g_wgrad_wide = 1;  // cd_debug_set_wgrad_mode bit 2 switches the wide 1x1 plan off (A/B measurements, tests)
 static int g_wgrad_dbg = 0;   // measurement hook: bit 0 skip the atomic flush, bit 1 skip the MFMAs (results are then wrong)
 
+// The same for MANY gradients in one launch (blockIdx.y = descriptor): a network's backward leaves every partial-sum
+// buffer packed (cd_conv2d_wgrad accumulate bit 2) and unpacks them all at the end; one descriptor may take only the
+// output-channel rows [row0, row0 + rows) of a packed gradient (a fused convolution whose rows belong to several
+// nn.Conv2d weights).
+struct UnpackDesc {
+    const float* packed; float* dw;
+    int Cin, ks, cob, cib, ci_groups, row0, rows, accumulate;
+};
+static_assert(sizeof(UnpackDesc) == 48, "cd_unpack_desc layout");
+
+__global__ void unpack_wgrad_table_kernel(const UnpackDesc* __restrict__ table) {
+    const UnpackDesc d = table[blockIdx.y];
+    const int taps = d.ks * d.ks, total = d.rows * d.Cin * taps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int tap = i % taps, ci = (i / taps) % d.Cin, co = d.row0 + i / (taps * d.Cin);
+        const int cog = co / d.cob, cig = ci / d.cib;
+        const float v = d.packed[(((size_t)cog * d.ci_groups + cig) * taps + tap) * d.cob * d.cib + (size_t)(co - cog * d.cob) * d.cib + (ci - cig * d.cib)];
+        d.dw[i] = d.accumulate ? d.dw[i] + v : v;
+    }
+}
+
 struct WgPlan { int co_t, ci_t; };
 
 static inline WgPlan wgrad_plan(int ks, int cout, int cin) {
@@ -503,10 +524,25 @@ size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     return n;
 }
 
+int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib) {
+    if (!cob || !cib || cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) == 0 || N <= 0 || H <= 0 || W <= 0) return CD_ERR_INVALID_ARG;
+    cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
+    if (cd::g_wgrad_wide) (void)cd::wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p);
+    *cob = p.co_t * 16;
+    *cib = p.ci_t * 16;
+    return CD_OK;
+}
+
+int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream) {
+    if (!table_dev || n <= 0 || n > 65535) return CD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cd::unpack_wgrad_table_kernel, dim3(8, n), dim3(256), 0, (hipStream_t)stream, (const cd::UnpackDesc*)table_dev);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
 int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift,
                     int in_relu, const float* dy, int dy_ctot, int dy_coff, int Cout, float* dw, int accumulate,
                     float* workspace, int N, int H, int W, int ks, void* stream) {
-    if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD_ERR_INVALID_ARG;
+    if (!x || !dy || (!dw && !(accumulate & 4)) || !workspace || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD_ERR_INVALID_ARG;
     if (x_coff < 0 || x_coff + Cin > x_ctot || dy_coff < 0 || dy_coff + Cout > dy_ctot) return CD_ERR_INVALID_ARG;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return CD_ERR_INVALID_ARG;
     const size_t wsf = cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks);
@@ -547,6 +583,7 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     }
 #undef CD_WG
     if (rc != CD_OK) return rc;
+    if (accumulate & 4) return CD_OK;   // stays packed: cd_conv2d_wgrad_unpack_table finishes it
     const int cob = p.co_t * 16, cib = p.ci_t * 16;
     const int total = Cout * Cin * ks * ks;
     hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,

@@ -109,9 +109,9 @@ class ConvUnit:
                           dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True)
         else:
             L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias))
-        dw = _grad_of(self.conv.weight)
+        # the partial sums stay packed in the arena; plan["unpack"] writes every weight gradient at the end of the backward
         self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
-            s.buf, gbuf, self.cin, self.cout, self.ks, dw, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,
+            s.buf, gbuf, self.cin, self.cout, self.ks, None, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,
             in_shift=s.shift, in_relu=s.relu, prezeroed=True))
         if s.gbuf is not None:
             C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
@@ -136,7 +136,6 @@ class PointwiseGroup:
         self.cin = members[0].cin
         self.cout, self.ks = self.ctot, 1          # the group is ONE unit for the arenas (wgrad workspace, BN sums)
         self.wgrad_ws = self.sums = None
-        self._dw = torch.empty(self.ctot, self.cin, 1, 1, device=P.device)   # fused weight gradient [m1;m2;m3;b0]
         self._filt, self._filtT = filt, filtT
         self._bias = torch.empty(self.ctot, device=P.device)
         self._bias_versions = None
@@ -173,14 +172,9 @@ class PointwiseGroup:
         s = self.src
         L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True)
         # ONE weight-gradient GEMM for the four filters (X is read once), then split the rows
-        grads = [(_grad_of(m.conv.weight), m) for m in self.members]
-
-        def wgrad():
-            C.conv2d_wgrad(s.buf, self.Pg, self.cin, self.ctot, 1, self._dw, self.wgrad_ws, x_coff=s.coff, dy_coff=0,
-                           in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, prezeroed=True)
-            for g, m in grads:
-                g.copy_(self._dw[m.coff:m.coff + m.cout])
-        self.eng.on_wgrad_stream(wgrad)
+        self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
+            s.buf, self.Pg, self.cin, self.ctot, 1, None, self.wgrad_ws, x_coff=s.coff, dy_coff=0, in_scale=s.scale,
+            in_shift=s.shift, in_relu=s.relu, prezeroed=True))
         if s.gbuf is not None:
             C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
@@ -413,11 +407,20 @@ class HourglassEngine:
         plan["wgrad_arena"] = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
         plan["sums_arena"] = torch.zeros(sum(2 * u.cout for u in units), dtype=torch.float64, device=self.device)
         o = so = 0
+        unpack = plan["unpack"] = C.UnpackTable(self.device)
+        N, _, H, W = plan["x"].shape
         for u, n in zip(units, sizes):
             u.wgrad_ws = plan["wgrad_arena"][o:o + n]
             u.sums = plan["sums_arena"][so:so + 2 * u.cout]
             o += n
             so += 2 * u.cout
+            h, w = (u.P.shape[2:] if isinstance(u, PointwiseGroup) else u.dst_buf.shape[2:])
+            layout = C.wgrad_plan(u.cout, u.cin, u.ks, N, h, w)
+            if isinstance(u, PointwiseGroup):   # the fused gradient's rows belong to the members' weights
+                for m in u.members:
+                    unpack.add(u.wgrad_ws, (lambda m=m: _grad_of(m.conv.weight)), u.cin, 1, layout, row0=m.coff)
+            else:
+                unpack.add(u.wgrad_ws, (lambda u=u: _grad_of(u.conv.weight)), u.cin, u.ks, layout)
 
     def plan(self, N, H, W):
         key = (N, H, W)
@@ -491,6 +494,7 @@ class HourglassEngine:
         if self._wgrad_pending:   # join: the parameter gradients are complete when this returns (stream order)
             torch.cuda.current_stream(self.device).wait_stream(self._wgrad_stream)
             self._wgrad_pending = False
+        plan["unpack"].run()      # every weight gradient (157 tensors) in one launch
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (N,3,H,W) -> pred_d (N,1,H,W) (log depth), attached to autograd when grad is enabled."""

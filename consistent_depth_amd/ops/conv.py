@@ -147,15 +147,63 @@ def wgrad_workspace(Cout, Cin, ks, device) -> torch.Tensor:
 
 def conv2d_wgrad(x, dy, Cin, Cout, ks, dw, workspace, x_coff=0, dy_coff=0, in_scale=None, in_shift=None,
                  in_relu=False, accumulate=False, prezeroed=False):
-    """dw (Cout,Cin,ks,ks) (+)= sum dy[:, dy_coff:+Cout] * act(x[:, x_coff:+Cin]) shifted by the taps."""
+    """dw (Cout,Cin,ks,ks) (+)= sum dy[:, dy_coff:+Cout] * act(x[:, x_coff:+Cin]) shifted by the taps.
+    dw=None: deferred form -- the result stays packed in `workspace` for an UnpackTable."""
     N, x_ctot, H, W = x.shape
     opt = lambda t, name: _native.dev_ptr(t, name) if t is not None else None  # noqa: E731
+    flags = int(accumulate) | (2 if prezeroed else 0) | (4 if dw is None else 0)
     rc = _native.lib().cd_conv2d_wgrad(
         _native.dev_ptr(x, "x"), x_ctot, x_coff, Cin, opt(in_scale, "in_scale"), opt(in_shift, "in_shift"), int(in_relu),
-        _native.dev_ptr(dy, "dy"), dy.shape[1], dy_coff, Cout, _native.dev_ptr(dw, "dw"), int(accumulate) | (2 if prezeroed else 0),
+        _native.dev_ptr(dy, "dy"), dy.shape[1], dy_coff, Cout, opt(dw, "dw"), flags,
         _native.dev_ptr(workspace, "workspace"), N, H, W, ks, _native.stream_ptr(x.device))
     _native.check(rc, "cd_conv2d_wgrad")
     return dw
+
+
+def wgrad_plan(Cout, Cin, ks, N, H, W):
+    """(cob, cib): channel block sizes of the packed layout cd_conv2d_wgrad uses for these arguments."""
+    import ctypes
+    cob, cib = ctypes.c_int(0), ctypes.c_int(0)
+    _native.check(_native.lib().cd_conv2d_wgrad_plan(Cout, Cin, ks, N, H, W, ctypes.byref(cob), ctypes.byref(cib)),
+                  "cd_conv2d_wgrad_plan")
+    return cob.value, cib.value
+
+
+class UnpackTable:
+    """Deferred weight gradients of a whole network written by ONE launch (cd_conv2d_wgrad_unpack_table).
+
+    add(workspace, grad, Cin, ks, plan, row0=0) registers a destination gradient tensor (rows = grad.shape[0]) fed from the
+    output-channel rows [row0, row0+rows) of a packed workspace; run() launches, rebuilding the device table first if a
+    gradient tensor moved (FlatAdam re-homes .grad; zero_grad(set_to_none) would reallocate)."""
+
+    _DT = [("packed", "<u8"), ("dw", "<u8"), ("Cin", "<i4"), ("ks", "<i4"), ("cob", "<i4"), ("cib", "<i4"), ("cig", "<i4"),
+           ("row0", "<i4"), ("rows", "<i4"), ("acc", "<i4")]
+
+    def __init__(self, device):
+        self.device, self._entries, self._table, self._ptrs = device, [], None, None
+
+    def add(self, workspace, grad_of, Cin, ks, plan, row0=0):
+        """grad_of: callable returning the CURRENT gradient tensor (evaluated at every run)."""
+        self._entries.append((workspace, grad_of, Cin, ks, plan, row0))
+
+    def _refresh(self, grads):
+        import numpy as np
+        tab = np.zeros(len(self._entries), np.dtype(self._DT))
+        for j, ((ws, _, Cin, ks, (cob, cib), row0), g) in enumerate(zip(self._entries, grads)):
+            if not (g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda and g.shape[1] == Cin and g.shape[2] == ks):
+                raise RuntimeError("weight gradients must be contiguous fp32 (rows, Cin, k, k) on the HIP device")
+            tab[j] = (ws.data_ptr(), g.data_ptr(), Cin, ks, cob, cib, (Cin + cib - 1) // cib, row0, g.shape[0], 0)
+        self._ptrs = [g.data_ptr() for g in grads]
+        self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+
+    def run(self):
+        if not self._entries:
+            return
+        grads = [e[1]() for e in self._entries]
+        if self._ptrs is None or any(g.data_ptr() != q for g, q in zip(grads, self._ptrs)):
+            self._refresh(grads)
+        rc = _native.lib().cd_conv2d_wgrad_unpack_table(self._table.data_ptr(), len(self._entries), _native.stream_ptr(self.device))
+        _native.check(rc, "cd_conv2d_wgrad_unpack_table")
 
 
 class PackTable:

@@ -211,6 +211,18 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
                     const float* in_shift, int in_relu, const float* dy, int dy_ctot, int dy_coff,
                     int Cout, float* dw, int accumulate, float* workspace, int N, int H, int W, int ks,
                     void* stream);
+/* Deferred form: with bit 2 of `accumulate` (value 4) cd_conv2d_wgrad leaves the result in `workspace` in the packed
+ * layout [co group][ci group][tap][cob][cib] that cd_conv2d_wgrad_plan reports for the same arguments (dw may be NULL),
+ * and ONE cd_conv2d_wgrad_unpack_table launch later writes any number of gradients -- one descriptor per destination
+ * tensor dw[rows][Cin][ks][ks] taking the output-channel rows [row0, row0+rows) of a packed buffer (a fused
+ * convolution's rows belong to several nn.Conv2d weights).  Device-resident table of cd_unpack_desc (48 bytes each). */
+typedef struct cd_unpack_desc {
+    const float* packed;
+    float* dw;
+    int Cin, ks, cob, cib, ci_groups, row0, rows, accumulate;
+} cd_unpack_desc;
+int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib);
+int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream);
 
 /* BatchNorm2d in training mode, forward.  stats[CD_BN_STAT_SLOTS][ctot][2] = per-channel (sum, sum of squares) of the raw
  * tensor over N*H*W (what cd_conv2d_fwd accumulates).  In place: x <- (x - mean) * rsqrt(var + eps)
