@@ -28,6 +28,73 @@ __global__ __launch_bounds__(kBlock) void sample_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- flow-consistency masks
+// Replaces /root/reference/utils/consistency.py:32-67 (called from flow.py:199-228): for direction k of a pair
+//   inside_k = 0 <= x+u <= W-1 and 0 <= y+v <= H-1
+//   mask_k   = inside_k  and  |flow_k - (-flow_{1-k} warped by flow_k)|^2 < flow_thresh^2
+//                        and  sum_c (color_k - color_{1-k} warped by flow_k)^2 < C * color_thresh^2
+// The warp is the reference's OTHER sampler (consistency.py:8-23): grid = 2*uv/(W,H) - 1 evaluated in fp64 and cast to
+// fp32, then grid_sample(border, align_corners=False): ix = ((g+1)*W - 1)/2 clipped to [0, W-1] -- i.e. u - 0.5, not
+// geometry.sample's u*W/(W-1) - 0.5.  Every rounding step of the reference is reproduced (explicit _rn intrinsics, no
+// contraction), so the masks are bit-identical to the oracle.  One thread = one pixel of one direction; the four taps
+// are shared by the flow and the colour test.
+struct TapsB { int x0, y0, x1, y1; float wnw, wne, wsw, wse; bool in_x1, in_y1; };
+
+__device__ __forceinline__ TapsB taps_border_grid(double idx_x, double idx_y, int W, int H) {
+    const float gx = (float)__dsub_rn(__ddiv_rn(__dmul_rn(2.0, idx_x), (double)W), 1.0);
+    const float gy = (float)__dsub_rn(__ddiv_rn(__dmul_rn(2.0, idx_y), (double)H), 1.0);
+    float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), 1.f), 0.5f);
+    float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), 1.f), 0.5f);
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const float x0f = floorf(ix), y0f = floorf(iy), x1f = __fadd_rn(x0f, 1.f), y1f = __fadd_rn(y0f, 1.f);
+    TapsB t;
+    t.x0 = (int)x0f; t.y0 = (int)y0f; t.x1 = t.x0 + 1; t.y1 = t.y0 + 1;
+    t.in_x1 = t.x1 <= W - 1; t.in_y1 = t.y1 <= H - 1;
+    t.wnw = __fmul_rn(__fsub_rn(x1f, ix), __fsub_rn(y1f, iy));
+    t.wne = __fmul_rn(__fsub_rn(ix, x0f), __fsub_rn(y1f, iy));
+    t.wsw = __fmul_rn(__fsub_rn(x1f, ix), __fsub_rn(iy, y0f));
+    t.wse = __fmul_rn(__fsub_rn(ix, x0f), __fsub_rn(iy, y0f));
+    return t;
+}
+
+__device__ __forceinline__ float tap_sum(const float* __restrict__ src, int W, const TapsB& t) {
+    // ((nw + ne) + sw) + se, each term rounded, taps outside the image contribute nothing
+    float o = __fmul_rn(src[t.y0 * W + t.x0], t.wnw);
+    o = __fadd_rn(o, t.in_x1 ? __fmul_rn(src[t.y0 * W + t.x1], t.wne) : 0.f);
+    o = __fadd_rn(o, t.in_y1 ? __fmul_rn(src[t.y1 * W + t.x0], t.wsw) : 0.f);
+    o = __fadd_rn(o, (t.in_x1 && t.in_y1) ? __fmul_rn(src[t.y1 * W + t.x1], t.wse) : 0.f);
+    return o;
+}
+
+__global__ __launch_bounds__(kBlock) void flow_consistency_mask_kernel(
+    const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, const float* __restrict__ color0,
+    const float* __restrict__ color1, int C, float thr_flow, float thr_color, int H, int W, float* __restrict__ mask_fwd,
+    float* __restrict__ mask_bwd) {
+    const int HW = H * W, b = blockIdx.z, k = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* fl = (k == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
+    const float* fo = (k == 0 ? flow_bwd : flow_fwd) + (size_t)b * 2 * HW;
+    const float* cr = (k == 0 ? color0 : color1) + (size_t)b * C * HW;
+    const float* ct = (k == 0 ? color1 : color0) + (size_t)b * C * HW;
+    const float u = fl[p], v = fl[HW + p];
+    const double idx_x = (double)u + (double)x, idx_y = (double)v + (double)y;
+    const bool inside = idx_x >= 0.0 && idx_x <= (double)(W - 1) && idx_y >= 0.0 && idx_y <= (double)(H - 1);
+    const TapsB t = taps_border_grid(idx_x, idx_y, W, H);
+    // flow test: flow_k - (-(flow_{1-k} warped)) = flow_k + warped   (negation commutes exactly with the weighted sum)
+    const float du = __fadd_rn(u, tap_sum(fo, W, t)), dv = __fadd_rn(v, tap_sum(fo + HW, W, t));
+    const float sse_f = __fadd_rn(__fmul_rn(du, du), __fmul_rn(dv, dv));
+    float sse_c = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = __fsub_rn(cr[(size_t)c * HW + p], tap_sum(ct + (size_t)c * HW, W, t));
+        sse_c = c == 0 ? __fmul_rn(d, d) : __fadd_rn(sse_c, __fmul_rn(d, d));
+    }
+    const bool m = inside && sse_f < thr_flow && sse_c < thr_color;
+    (k == 0 ? mask_fwd : mask_bwd)[(size_t)b * HW + p] = m ? 1.f : 0.f;
+}
+
 }  // namespace cd
 
 extern "C" int cd_sample_bilinear_border(const float* data, const float* uv, int B, int C, int H, int W, float* out,
@@ -36,6 +103,20 @@ extern "C" int cd_sample_bilinear_border(const float* data, const float* uv, int
     const int HW = H * W;
     hipLaunchKernelGGL(cd::sample_kernel, dim3((HW + cd::kBlock - 1) / cd::kBlock, B), dim3(cd::kBlock), 0,
                        (hipStream_t)stream, data, uv, C, H, W, out);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+extern "C" int cd_flow_consistency_masks(const float* flow_fwd, const float* flow_bwd, const float* color0, const float* color1,
+                                         int C, double flow_thresh, double color_thresh, int B, int H, int W, float* mask_fwd,
+                                         float* mask_bwd, void* stream) {
+    if (!flow_fwd || !flow_bwd || !color0 || !color1 || !mask_fwd || !mask_bwd) return CD_ERR_INVALID_ARG;
+    if (B <= 0 || B > 65535 || C <= 0 || H < 2 || W < 2 || !(flow_thresh > 0.0) || !(color_thresh > 0.0)) return CD_ERR_INVALID_ARG;
+    // the reference compares fp32 sums with python floats under NumPy's weak-scalar rule: the thresholds are rounded to fp32
+    const float thr_f = (float)(flow_thresh * flow_thresh), thr_c = (float)((double)C * (color_thresh * color_thresh));
+    const int HW = H * W;
+    hipLaunchKernelGGL(cd::flow_consistency_mask_kernel, dim3((HW + cd::kBlock - 1) / cd::kBlock, 2, B), dim3(cd::kBlock), 0,
+                       (hipStream_t)stream, flow_fwd, flow_bwd, color0, color1, C, thr_f, thr_c, H, W, mask_fwd, mask_bwd);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -35,6 +35,11 @@ class PairStore:
         self.frame_ids = list(frame_ids) if frame_ids is not None else list(range(self.color.shape[0]))
         P = self.flows.shape[0]
         assert self.masks.shape[0] == P and self.pair_frames.shape == (P, 2)
+        self._refresh_constants()
+
+    def _refresh_constants(self):
+        """Dataset constants derived from the masks and flows: the loss normalisers and the gradient kernel's windows."""
+        P, dev = self.flows.shape[0], self.device
         self.mask_sums = torch.empty(P, 2, dtype=torch.float32, device=dev)
         wins = []
         for s in range(0, P, 256):
@@ -43,6 +48,22 @@ class PairStore:
             self.mask_sums[s:s + 256] = _mask_sums(mk[0], mk[1])
             wins.append(_tile_windows(fl, mk))
         self.tile_windows = torch.cat(wins, 0)  # (P, bytes_per_pair) uint8
+
+    def rebuild_masks(self, flow_thresh: float = 1.0, color_thresh: float = 1.0):
+        """Recompute the flow-consistency masks of every pair ON THE DEVICE from the resident flows and colours -- the
+        reference's offline `mask_valid_correspondences` stage (flow.py:199-228 -> utils/consistency.py), bit-identical
+        masks -- and refresh the constants that depend on them.  For datasets that ship flows without mask PNGs, or to
+        try other thresholds without touching the disk."""
+        from ..utils import consistency
+        for s in range(0, len(self), 256):
+            pf = self.pair_frames[s:s + 256]
+            m0, m1 = consistency.consistent_flow_masks_batch(
+                self.flows[s:s + 256, 0].contiguous(), self.flows[s:s + 256, 1].contiguous(),
+                self.color[pf[:, 0]], self.color[pf[:, 1]], flow_thresh, color_thresh)
+            self.masks[s:s + 256, 0] = m0
+            self.masks[s:s + 256, 1] = m1
+        self._refresh_constants()
+        return self
 
     def __len__(self):
         return self.flows.shape[0]

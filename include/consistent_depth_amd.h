@@ -139,6 +139,16 @@ int cd_debug_set_loss_chunk(int pairs);
 int cd_sample_bilinear_border(const float* data, const float* uv, int B, int C, int H, int W,
                               float* out, void* stream);
 
+/* Flow-consistency masks of B frame pairs -- the reference's mask_valid_correspondences (flow.py:199-228 ->
+ * utils/consistency.py:32-67): mask_k = the flow of direction k stays inside the image, agrees with the opposite flow
+ * warped by it within flow_thresh pixels, and the colours agree within color_thresh per channel (RMS).  The warp is
+ * consistency.py's own sampler (grid in fp64 -> fp32, border padding, ix = u - 0.5).  flows (B,2,H,W), colours (B,C,H,W)
+ * of frame 0 / frame 1 of each pair, masks out (B,1,H,W) as 0.0 / 1.0 -- the form the loss kernels consume.
+ * Bit-identical to the reference's boolean masks (every rounding step is reproduced). */
+int cd_flow_consistency_masks(const float* flow_fwd, const float* flow_bwd, const float* color0,
+                              const float* color1, int C, double flow_thresh, double color_thresh, int B, int H,
+                              int W, float* mask_fwd, float* mask_bwd, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Depth CNN layers (reference: the un-vendored Mannequin-Challenge hourglass called at
  * monodepth/mannequin_challenge_model.py:60; architecture SURVEY.md appendix A.3).
