@@ -73,6 +73,7 @@ class ConvUnit:
         self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None,
                        scale=bn_mod.weight if affine else None, shift=bn_mod.bias if affine else None, needs_grad=False)
         self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
+        self.bn_fused = False             # True: the owning inception runs the BN passes of its three branch outputs jointly
         self.pk, self.pkT = eng.packed(conv_mod)
         # launch shapes, timed once per distinct convolution shape (ops/conv.py::tuned_config)
         N, _, H, W = dst_buf.shape
@@ -86,7 +87,7 @@ class ConvUnit:
         C.conv2d(s.buf, self.pk, self.cin, self.cout, self.ks, bias=self.conv.bias, x_coff=s.coff, out=self.dst_buf,
                  y_coff=self.dst_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu,
                  stats=self.stats.view(-1) if (self.bn is not None and training) else None, cfg=self.cfg_f)
-        if self.bn is not None:
+        if self.bn is not None and not self.bn_fused:
             if training:
                 L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS, self.bn.running_mean,
                                self.bn.running_var, BN_MOMENTUM)
@@ -101,7 +102,9 @@ class ConvUnit:
         """gbuf[:, g_coff:+cout] holds d loss / d (activated output); on return the parameter grads are
         written and the source activation's gradient received this unit's contribution."""
         s = self.src
-        if self.bn is not None:
+        if self.bn_fused:
+            pass   # the inception already turned gbuf into the gradient w.r.t. the raw convolution output
+        elif self.bn is not None:
             affine = self.bn.affine
             L.bn_relu_bwd(gbuf, g_coff, self.dst_buf, self.dst_coff, self.cout, self.mi, self.sums,
                           gamma=self.bn.weight if affine else None, beta=self.bn.bias if affine else None,
@@ -130,8 +133,9 @@ class _Member:
 class PointwiseGroup:
     """The four branch-entry 1x1 convolutions of an inception as ONE convolution X -> P[:, 0:ctot]."""
 
-    def __init__(self, eng, members, src: Act, P, Pg, stats, mean_invstd, filt, filtT):
+    def __init__(self, eng, members, src: Act, P, Pg, stats, mean_invstd, filt, filtT, running):
         self.eng, self.members, self.src, self.P, self.Pg, self.stats, self.mi = eng, members, src, P, Pg, stats, mean_invstd
+        self.running = running            # (running_mean, running_var) of the members, contiguous in member order
         self.ctot = sum(m.cout for m in members)
         self.cin = members[0].cin
         self.cout, self.ks = self.ctot, 1          # the group is ONE unit for the arenas (wgrad workspace, BN sums)
@@ -157,16 +161,7 @@ class PointwiseGroup:
         C.conv2d(s.buf, pk, self.cin, self.ctot, 1, bias=self._fused_bias(), x_coff=s.coff, out=self.P, y_coff=0,
                  in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, stats=self.stats.view(-1) if training else None,
                  cfg=self.cfg_f)
-        cnt = float(self.P.shape[0] * self.P.shape[2] * self.P.shape[3])
-        for m in self.members:
-            if training:
-                L.bn_normalize(self.P, m.coff, m.cout, self.stats, self.mi, BN_EPS, m.bn.running_mean, m.bn.running_var,
-                               BN_MOMENTUM)
-            else:
-                rm, rv = m.bn.running_mean.double(), m.bn.running_var.double()
-                self.stats[0, m.coff:m.coff + m.cout, 0] = rm * cnt
-                self.stats[0, m.coff:m.coff + m.cout, 1] = (rv + rm * rm) * cnt
-                L.bn_normalize(self.P, m.coff, m.cout, self.stats, self.mi, BN_EPS)
+        self.eng.bn_forward(self.P, 0, self.ctot, self.stats, self.mi, self.running, training)   # [m1|m2|m3|b0] in one launch
 
     def backward(self):
         s = self.src
@@ -203,6 +198,7 @@ class HourglassEngine:
         self._pack = C.PackTable(self.device)
         self._pack_index = {}
         self._group_filters = {}
+        self._bn_flat = {}
         grouped = set()
         for inc in net.modules():
             if isinstance(inc, HG.Inception):
@@ -216,6 +212,10 @@ class HourglassEngine:
                     off += c.out_channels
                     grouped.add(id(c))
                 self._group_filters[id(inc)] = (f, fT)
+                # the BatchNorms of adjacent channel slices share launches: their running statistics become views of
+                # contiguous buffers (entry convs [m1|m2|m3|b0], branch outputs [o1|o2|o3]); names / state_dict unchanged
+                self._bn_flat[id(inc)] = (self._rehome_running_stats([br[1] for br in list(inc.convs)[1:]] + [inc.convs[0][1]]),
+                                          self._rehome_running_stats([br[4] for br in list(inc.convs)[1:]]))
         for m in net.modules():
             if isinstance(m, torch.nn.Conv2d) and m is not net.uncertainty_layer[0] and id(m) not in grouped:
                 self._pack_index[id(m)] = (self._pack.add(m.weight, False), self._pack.add(m.weight, True))
@@ -234,6 +234,20 @@ class HourglassEngine:
         self._wgrad_stream = torch.cuda.Stream(device=self.device) \
             if mode != "none" and os.environ.get("CD_AMD_ENGINE_WGRAD_STREAM", "0") == "1" else None
         self._wgrad_pending = False
+
+    def _rehome_running_stats(self, bns):
+        n = sum(b.num_features for b in bns)
+        rm, rv = torch.empty(n, device=self.device), torch.empty(n, device=self.device)
+        off = 0
+        with torch.no_grad():
+            for b in bns:
+                assert not b.affine and b.track_running_stats
+                c = b.num_features
+                rm[off:off + c].copy_(b.running_mean)
+                rv[off:off + c].copy_(b.running_var)
+                b.running_mean, b.running_var = rm[off:off + c], rv[off:off + c]
+                off += c
+        return rm, rv
 
     def packed(self, conv_mod):
         i, j = self._pack_index[id(conv_mod)]
@@ -262,6 +276,17 @@ class HourglassEngine:
             done = torch.cuda.Event()
             done.record(st)
             cur.wait_event(done)
+
+    def bn_forward(self, buf, coff, C, stats, mi, running, training):
+        """Train-mode BatchNorm (or eval: normalise with the running statistics) of C adjacent channels in ONE launch."""
+        rm, rv = running
+        if training:
+            L.bn_normalize(buf, coff, C, stats, mi, BN_EPS, rm, rv, BN_MOMENTUM)
+        else:   # synthesised sums in slot 0 (the others stay zero); nothing is updated
+            cnt = float(buf.shape[0] * buf.shape[2] * buf.shape[3])
+            stats[0, coff:coff + C, 0] = rm.double() * cnt
+            stats[0, coff:coff + C, 1] = (rv.double() + rm.double() * rm.double()) * cnt
+            L.bn_normalize(buf, coff, C, stats, mi, BN_EPS)
 
     def on_wgrad_stream(self, job):
         """Run `job` (a weight-gradient launch sequence) on the wgrad stream, ordered after everything enqueued so far
@@ -326,17 +351,20 @@ class HourglassEngine:
             moff += mids[i]
         members.append(_Member(mod.convs[0][0], mod.convs[0][1], M))
         filt, filtT = self._group_filters[id(mod)]
-        group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT)
+        run_entry, run_out = self._bn_flat[id(mod)]
+        group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT, run_entry)
         units, ooff, moff = [], M + a0, 0
         for i, br in enumerate(list(mod.convs)[1:]):
             mid = Act(P, moff, mids[i], relu=True, needs_grad=False)
             mid.gbuf = Pg
             units.append((ConvUnit(self, br[3], br[4], mid, P, ooff, stats, mi), Pg, ooff))
+            units[-1][0].bn_fused = True
             ooff += outs[i + 1]
             moff += mids[i]
         out = Act(P, M, Co, relu=True, needs_grad=False)
         out.gbuf = Pg
-        steps.append(_Node("inception", group=group, units=units, out=out, src=x))
+        steps.append(_Node("inception", group=group, units=units, out=out, src=x, P=P, Pg=Pg, stats=stats, mi=mi,
+                           bn_coff=M + a0, bn_C=sum(outs[1:]), bn_running=run_out, bn_sums=None))
         plan["convs"] += [group] + [u for u, _, _ in units]
         return out
 
@@ -407,6 +435,13 @@ class HourglassEngine:
         plan["wgrad_arena"] = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
         plan["sums_arena"] = torch.zeros(sum(2 * u.cout for u in units), dtype=torch.float64, device=self.device)
         o = so = 0
+        for step in self._all_steps(plan["steps"]):
+            if step.kind == "inception":   # the three branch units' sums are consecutive in the arena: one joint view
+                us = [u for u, _, _ in step.units]
+                i0 = units.index(us[0])
+                assert units[i0:i0 + 3] == us
+                s0 = sum(2 * u.cout for u in units[:i0])
+                step.bn_sums = plan["sums_arena"][s0:s0 + 2 * step.bn_C]
         unpack = plan["unpack"] = C.UnpackTable(self.device)
         N, _, H, W = plan["x"].shape
         for u, n in zip(units, sizes):
@@ -422,6 +457,13 @@ class HourglassEngine:
             else:
                 unpack.add(u.wgrad_ws, (lambda u=u: _grad_of(u.conv.weight)), u.cin, u.ks, layout)
 
+    def _all_steps(self, steps):
+        for st in steps:
+            yield st
+            if st.kind == "channels":
+                yield from self._all_steps(st.flat)
+                yield from self._all_steps(st.up)
+
     def plan(self, N, H, W):
         key = (N, H, W)
         if key not in self._plans:
@@ -436,6 +478,7 @@ class HourglassEngine:
             elif step.kind == "inception":
                 step.group.forward(training)
                 self._fork_join([(lambda u=u: u.forward(training)) for u, _, _ in step.units])
+                self.bn_forward(step.P, step.bn_coff, step.bn_C, step.stats, step.mi, step.bn_running, training)   # [o1|o2|o3]
             elif step.kind == "pool":
                 s = step.src
                 L.avgpool2_fwd(s.buf, s.coff, s.C, step.out.buf, 0, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
@@ -455,6 +498,7 @@ class HourglassEngine:
             elif step.kind == "inception":
                 # the concat output's gradient is complete: k x k convolutions first (they fill the gradient of the
                 # mid activations), then the fused entry convolution
+                L.bn_relu_bwd(step.Pg, step.bn_coff, step.P, step.bn_coff, step.bn_C, step.mi, step.bn_sums, sums_prezeroed=True)
                 self._fork_join([(lambda u=u, g=gbuf, o=g_coff: u.backward(g, o)) for u, gbuf, g_coff in step.units])
                 step.group.backward()
             elif step.kind == "pool":
