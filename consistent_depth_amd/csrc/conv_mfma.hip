@@ -16,11 +16,13 @@
 // keeps (TY/4 rows x 2) M-tiles x CO_T N-tiles of accumulators in registers and walks the taps
 // with immediate LDS offsets; input channels are streamed through LDS in chunks of CI_CHUNK.
 //
-// Fusions: the producer's BatchNorm-apply + ReLU is applied while the input tile is staged
-// (per-channel scale/shift), and the per-channel sum / sum-of-squares of the raw output (the batch
-// statistics the FOLLOWING train-mode BatchNorm needs) are accumulated in the epilogue -- so a
-// conv+BN+ReLU chain never makes a separate pass over the activations.
+// Fusions: the producer's affine + ReLU is applied while the input tile is staged (per-channel
+// scale/shift), and the per-channel sum / sum-of-squares of the raw output (the batch statistics the
+// FOLLOWING train-mode BatchNorm needs) are accumulated in the epilogue (fp64, one atomic pair per
+// channel per block into one of CD_BN_STAT_SLOTS copies).
 // The input-gradient convolution (dgrad) is the same kernel on flipped/transposed packed weights.
+// Launch shape (tile rows x channel slices per block) is a run-time choice with bit-identical results;
+// staging is 16-byte wide (aligned superset rows) and software-pipelined through registers where it fits.
 #include "cd_common.h"
 
 namespace cd {

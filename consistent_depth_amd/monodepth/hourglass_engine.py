@@ -3,7 +3,7 @@
 Executes the same network as consistent_depth_amd/monodepth/hourglass.py (whose nn.Module stays the
 parameter / state_dict container) on the gfx950 kernels behind the C ABI:
 
-    conv (all 157)      cd_conv2d_fwd        fp32 MFMA direct convolution; the producer's ReLU (and the stem's
+    conv (all 157)      cd_conv2d_fwd_cfg    fp32 MFMA direct convolution; the producer's ReLU (and the stem's
                                              affine) is applied while loading, the batch statistics of the
                                              raw output are accumulated in the epilogue
     BatchNorm (train)   cd_bn_normalize      in place -> x_hat (pre-ReLU); running stats updated like PyTorch
@@ -16,10 +16,16 @@ Inception layout: every inception owns ONE buffer [m1|m2|m3 | b0|o1|o2|o3] (mid 
 the concat output), so its four branch-entry 1x1 convolutions are a single convolution over a contiguous
 channel range: X is read once in the forward and dX written once in the backward (PointwiseGroup).
 
-Streams: the three k x k branches of an inception are independent, in the forward and in the backward
-pass; they run on three side HIP streams (fork/join with events around every inception), which keeps the
-256 CUs busy on the deep 96x56 ... 24x14 levels where a single convolution has too few workgroups, and
-overlaps the memory-bound BatchNorm kernels of one branch with the MFMA-bound convolutions of another.
+Streams (CD_AMD_ENGINE_STREAMS, default "level"): the full-resolution (skip) side of every Channels block runs on
+its own HIP stream, concurrent with the chain through the deeper levels -- that keeps the 256 CUs busy while the
+96x56 ... 24x14 levels run kernels with too few workgroups.  ("branch" additionally forks the three k x k branches
+of every inception; measured slower.)  All forks/joins are event-based, so a whole training step is capturable
+into a HIP graph (consistent_depth_amd/engine.py::GraphedFineTuneStep).
+
+Launch economy: one launch re-packs all filters per step, one writes all weight gradients at the end of the
+backward, the BatchNorm passes of adjacent channel slices of an inception share launches ([m1|m2|m3|b0] and
+[o1|o2|o3]; their running statistics are views of contiguous buffers), and each convolution's launch shape is
+timed once per distinct shape (ops/conv.py::tuned_config).
 
 No autograd tape is built for the network: the backward pass is the explicit reverse walk of the plan.
 Towards PyTorch the engine is ONE autograd node: forward(x) returns pred_d attached to the graph, and
