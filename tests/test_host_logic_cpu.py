@@ -96,3 +96,32 @@ def test_graph_step_runs_eagerly_first_and_falls_back_when_capture_is_unavailabl
     finally:
         torch.cuda.synchronize = real_sync
     assert g.graphed is False and "capture unsupported" in g.capture_error
+
+
+def test_every_python_file_compiles():
+    """tools/, oracle/, bench.py, main.py ... are only partly imported by the other tests: byte-compile all of them."""
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 0
+    for base, dirs, files in os.walk(root):
+        dirs[:] = [d for d in dirs if d not in (".git", "__pycache__", "gpurun_out", "build")]
+        for f in files:
+            if f.endswith(".py"):
+                py_compile.compile(os.path.join(base, f), doraise=True)
+                n += 1
+    assert n > 40
+
+
+def test_bench_cli_contract():
+    """bench.py must accept exactly the driver's flags and default to N=1 (the run itself needs the GPU)."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_cli", os.path.join(root, "bench.py"))
+    src = open(os.path.join(root, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert f'"{flag}"' in src
+    assert spec is not None and '"cpu_baseline"' in src and '"roofline"' in src and "higher_is_better" in src
+    del sys
