@@ -124,12 +124,14 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
                 run()
             except RuntimeError:      # launch shape not available for this filter (LDS budget)
                 continue
-            e0.record()
-            for _ in range(iters):
-                run()
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
+            t = float("inf")
+            for _ in range(2):        # best of two repetitions: one noisy sample must not pick the launch shape
+                e0.record()
+                for _ in range(iters):
+                    run()
+                e1.record()
+                e1.synchronize()
+                t = min(t, e0.elapsed_time(e1))
             if t < best_t:
                 best, best_t = (ty, cot), t
     _TUNED[key] = best
