@@ -252,20 +252,46 @@ __global__ __launch_bounds__(kBlock) void upsample2x_bwd_kernel(const float* __r
         const int yb = ry > 0.f ? min(H - 1, (int)ceilf((float)(yy + 1) / ry) + 1) : H - 1;
         const int xa = rx > 0.f ? max(0, (int)floorf((float)(xx - 1) / rx) - 1) : 0;
         const int xb = rx > 0.f ? min(W - 1, (int)ceilf((float)(xx + 1) / rx) + 1) : W - 1;
+        // column weights once per output pixel (identical arithmetic to the forward); the candidate window is at most
+        // 2/rx + 4 <= kMaxCand wide for every w >= 2 (rx >= 1/3), rows use the same bound
+        constexpr int kMaxCand = 12;
+        float wxs[kMaxCand];
+        const int nx = min(xb - xa + 1, kMaxCand);
+#pragma unroll
+        for (int q = 0; q < kMaxCand; ++q) {
+            const int x = xa + q;
+            const float sx = rx * (float)x;
+            const int x0 = min((int)sx, w - 1), x1 = min(x0 + 1, w - 1);
+            const float tx = sx - (float)x0;
+            wxs[q] = q < nx ? (x0 == xx ? 1.f - tx : 0.f) + (x1 == xx ? tx : 0.f) : 0.f;
+        }
         float acc = 0.f;
-        for (int y = ya; y <= yb; ++y) {
-            // identical arithmetic to the forward: sy, y0 = min((int)sy, h-1), y1 = min(y0+1, h-1), ty
-            const float sy = ry * (float)y;
-            const int y0 = min((int)sy, h - 1), y1 = min(y0 + 1, h - 1);
-            const float ty = sy - (float)y0;
-            const float wy = (y0 == yy ? 1.f - ty : 0.f) + (y1 == yy ? ty : 0.f);
-            if (wy == 0.f) continue;
-            for (int x = xa; x <= xb; ++x) {
-                const float sx = rx * (float)x;
-                const int x0 = min((int)sx, w - 1), x1 = min(x0 + 1, w - 1);
-                const float tx = sx - (float)x0;
-                const float wx = (x0 == xx ? 1.f - tx : 0.f) + (x1 == xx ? tx : 0.f);
-                acc += wy * wx * d[y * W + x];
+        if (xb - xa + 1 <= kMaxCand) {
+            for (int y = ya; y <= yb; ++y) {
+                const float sy = ry * (float)y;
+                const int y0 = min((int)sy, h - 1), y1 = min(y0 + 1, h - 1);
+                const float ty = sy - (float)y0;
+                const float wy = (y0 == yy ? 1.f - ty : 0.f) + (y1 == yy ? ty : 0.f);
+                if (wy == 0.f) continue;
+                const float* row = d + y * W + xa;
+#pragma unroll
+                for (int q = 0; q < kMaxCand; ++q)
+                    if (q < nx) acc += wy * wxs[q] * row[q];
+            }
+        } else {   // degenerate sizes (w == 1: every column is a candidate): the plain double loop
+            for (int y = ya; y <= yb; ++y) {
+                const float sy = ry * (float)y;
+                const int y0 = min((int)sy, h - 1), y1 = min(y0 + 1, h - 1);
+                const float ty = sy - (float)y0;
+                const float wy = (y0 == yy ? 1.f - ty : 0.f) + (y1 == yy ? ty : 0.f);
+                if (wy == 0.f) continue;
+                for (int x = xa; x <= xb; ++x) {
+                    const float sx = rx * (float)x;
+                    const int x0 = min((int)sx, w - 1), x1 = min(x0 + 1, w - 1);
+                    const float tx = sx - (float)x0;
+                    const float wx = (x0 == xx ? 1.f - tx : 0.f) + (x1 == xx ? tx : 0.f);
+                    acc += wy * wx * d[y * W + x];
+                }
             }
         }
         o[i] = accumulate ? o[i] + acc : acc;
