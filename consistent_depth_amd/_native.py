@@ -36,6 +36,8 @@ SIGNATURES = {
     "cd_profile_end": (c_i, [c_p, c_p, c_i, c_p]),
     "cd_sample_bilinear_border": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "cd_flow_consistency_masks": (c_i, [c_p, c_p, c_p, c_p, c_i, ctypes.c_double, ctypes.c_double, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "cd_warp_image": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "cd_depth_to_points": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "cd_conv2d_packed_weight_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "cd_conv2d_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "cd_conv2d_pack_weights_table": (c_i, [c_p, c_i, c_p]),

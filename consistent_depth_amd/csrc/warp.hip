@@ -95,6 +95,92 @@ __global__ __launch_bounds__(kBlock) void flow_consistency_mask_kernel(
     (k == 0 ? mask_fwd : mask_bwd)[(size_t)b * HW + p] = m ? 1.f : 0.f;
 }
 
+// ---------------------------------------------------------------- depth-based warp (offline stages around the hot path)
+// Replaces /root/reference/utils/geometry.py:130-139 depth_to_points, :179-200 warping_field, :213-227 warp_image
+// (used by scale_calibration.py:84-120) and the point-cloud means of :142-176 calibrate_scale.  Conventions as in the
+// fused loss: ray = ((x-cx)/fx, -(y-cy)/fy, -1), x_world = R p + t, camera looks along -z.
+//   uv[i]     = project_t( R_t^T (R_i (d * ray) + t_i - t_t) ),  t = tgt_ids[i]
+//   warped[i] = sample(images[t], uv[i])          (the geometry.sample mapping of sample_kernel above)
+__global__ __launch_bounds__(kBlock) void warp_image_kernel(const float* __restrict__ images, const float* __restrict__ depths,
+                                                            const float* __restrict__ intr, const float* __restrict__ extr,
+                                                            const int* __restrict__ tgt_ids, int C, int H, int W,
+                                                            float* __restrict__ uv_out, float* __restrict__ warped) {
+    const int HW = H * W, i = blockIdx.y, t = tgt_ids[i];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= HW) return;
+    const float* Ei = extr + i * 12;
+    const float* Et = extr + t * 12;
+    // M = R_t^T R_i, c = R_t^T (t_i - t_t)        (rows of E: [R | t], R[r][c] = E[r*4 + c])
+    float M[9], c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) M[r * 3 + q] = Et[0 + r] * Ei[0 + q] + Et[4 + r] * Ei[4 + q] + Et[8 + r] * Ei[8 + q];
+        c[r] = Et[0 + r] * (Ei[3] - Et[3]) + Et[4 + r] * (Ei[7] - Et[7]) + Et[8 + r] * (Ei[11] - Et[11]);
+    }
+    const float fx = intr[i * 4], fy = intr[i * 4 + 1], cx = intr[i * 4 + 2], cy = intr[i * 4 + 3];
+    const float fxt = intr[t * 4], fyt = intr[t * 4 + 1], cxt = intr[t * 4 + 2], cyt = intr[t * 4 + 3];
+    const int y = p / W, x = p - y * W;
+    const float d = depths[(size_t)i * HW + p];
+    const float r0 = ((float)x - cx) / fx, r1 = -((float)y - cy) / fy;
+    const float px = d * r0, py = d * r1, pz = -d;
+    const float X = M[0] * px + M[1] * py + M[2] * pz + c[0];
+    const float Y = M[3] * px + M[4] * py + M[5] * pz + c[1];
+    const float Z = M[6] * px + M[7] * py + M[8] * pz + c[2];
+    const float u = (X / -Z) * fxt + cxt, v = -((Y / -Z) * fyt) + cyt;
+    if (uv_out) {
+        uv_out[(size_t)i * 2 * HW + p] = u;
+        uv_out[(size_t)i * 2 * HW + HW + p] = v;
+    }
+    if (warped) {
+        const float sx = (float)W / (float)(W - 1), sy = (float)H / (float)(H - 1);
+        const float ix = fminf(fmaxf(u * sx - 0.5f, 0.f), (float)(W - 1));
+        const float iy = fminf(fmaxf(v * sy - 0.5f, 0.f), (float)(H - 1));
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float tx = ix - fx0, ty = iy - fy0;
+        const int xa = (int)fx0, ya = (int)fy0, xb = min(xa + 1, W - 1), yb = min(ya + 1, H - 1);
+        const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+        for (int ch = 0; ch < C; ++ch) {
+            const float* src = images + ((size_t)t * C + ch) * HW;
+            warped[((size_t)i * C + ch) * HW + p] =
+                src[ya * W + xa] * w00 + src[ya * W + xb] * w01 + src[yb * W + xa] * w10 + src[yb * W + xb] * w11;
+        }
+    }
+}
+
+// points[n] = depth * ray (3, H, W); optionally only their per-frame sums (fp64 partials) for calibrate_scale
+__global__ __launch_bounds__(kBlock) void depth_points_kernel(const float* __restrict__ depths, const float* __restrict__ intr,
+                                                              int H, int W, float* __restrict__ points,
+                                                              double* __restrict__ sums) {
+    __shared__ double red[3][kBlock / kWave];
+    const int HW = H * W, n = blockIdx.y;
+    const float fx = intr[n * 4], fy = intr[n * 4 + 1], cx = intr[n * 4 + 2], cy = intr[n * 4 + 3];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < HW; p += gridDim.x * kBlock) {
+        const int y = p / W, x = p - y * W;
+        const float d = depths[(size_t)n * HW + p];
+        const float px = d * (((float)x - cx) / fx), py = d * (-((float)y - cy) / fy), pz = -d;
+        if (points) {
+            points[((size_t)n * 3 + 0) * HW + p] = px;
+            points[((size_t)n * 3 + 1) * HW + p] = py;
+            points[((size_t)n * 3 + 2) * HW + p] = pz;
+        }
+        a0 += (double)px; a1 += (double)py; a2 += (double)pz;
+    }
+    if (!sums) return;   // block-uniform
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off, kWave); a1 += __shfl_down(a1, off, kWave); a2 += __shfl_down(a2, off, kWave);
+    }
+    if (lane == 0) { red[0][wid] = a0; red[1][wid] = a1; red[2][wid] = a2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+        for (int w = 0; w < kBlock / kWave; ++w) s += red[threadIdx.x][w];
+        atomicAdd(&sums[n * 3 + threadIdx.x], s);
+    }
+}
+
 }  // namespace cd
 
 extern "C" int cd_sample_bilinear_border(const float* data, const float* uv, int B, int C, int H, int W, float* out,
@@ -117,6 +203,30 @@ extern "C" int cd_flow_consistency_masks(const float* flow_fwd, const float* flo
     const int HW = H * W;
     hipLaunchKernelGGL(cd::flow_consistency_mask_kernel, dim3((HW + cd::kBlock - 1) / cd::kBlock, 2, B), dim3(cd::kBlock), 0,
                        (hipStream_t)stream, flow_fwd, flow_bwd, color0, color1, C, thr_f, thr_c, H, W, mask_fwd, mask_bwd);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+extern "C" int cd_warp_image(const float* images, const float* depths, const float* intrinsics, const float* extrinsics,
+                             const int* tgt_ids, int N, int C, int H, int W, float* uv_out, float* warped_out, void* stream) {
+    if (!depths || !intrinsics || !extrinsics || !tgt_ids || (!uv_out && !warped_out) || (warped_out && (!images || C <= 0))) return CD_ERR_INVALID_ARG;
+    if (N <= 0 || N > 65535 || H < 2 || W < 2) return CD_ERR_INVALID_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(cd::warp_image_kernel, dim3((HW + cd::kBlock - 1) / cd::kBlock, N), dim3(cd::kBlock), 0, (hipStream_t)stream,
+                       images, depths, intrinsics, extrinsics, tgt_ids, C, H, W, uv_out, warped_out);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+extern "C" int cd_depth_to_points(const float* depths, const float* intrinsics, int N, int H, int W, float* points_out,
+                                  double* sums_out, void* stream) {
+    if (!depths || !intrinsics || (!points_out && !sums_out) || N <= 0 || N > 65535 || H <= 0 || W <= 0) return CD_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (sums_out && hipMemsetAsync(sums_out, 0, sizeof(double) * 3 * N, s) != hipSuccess) return CD_ERR_LAUNCH;
+    const int HW = H * W;
+    int bx = (HW + cd::kBlock * 8 - 1) / (cd::kBlock * 8);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(cd::depth_points_kernel, dim3(bx, N), dim3(cd::kBlock), 0, s, depths, intrinsics, H, W, points_out, sums_out);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

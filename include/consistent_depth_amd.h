@@ -149,6 +149,18 @@ int cd_flow_consistency_masks(const float* flow_fwd, const float* flow_bwd, cons
                               const float* color1, int C, double flow_thresh, double color_thresh, int B, int H,
                               int W, float* mask_fwd, float* mask_bwd, void* stream);
 
+/* Depth-based warp of frames into each other (offline stages around the hot path: scale_calibration.py:84-120 ->
+ * geometry.py:179-227 warping_field / warp_image):  uv_out[i] (2,H,W) = where pixel (x,y) of frame i, lifted with
+ * depths[i] and moved through the two poses, lands in frame tgt_ids[i]; warped_out[i] (C,H,W) = images[tgt_ids[i]]
+ * sampled there (the `sample` of cd_sample_bilinear_border).  N frames: images (N,C,H,W), depths (N,1,H,W),
+ * intrinsics (N,4) = fx,fy,cx,cy, extrinsics (N,3,4) = [R|t], tgt_ids (N) int32 on the device.  Either output may be NULL. */
+int cd_warp_image(const float* images, const float* depths, const float* intrinsics, const float* extrinsics,
+                  const int* tgt_ids, int N, int C, int H, int W, float* uv_out, float* warped_out, void* stream);
+/* Camera-space points depth * ray (geometry.py:130-139 depth_to_points) -> points_out (N,3,H,W) and/or their per-frame
+ * sums over the pixels -> sums_out[N][3] (fp64, zeroed inside) -- the scene centres of geometry.py:142-176 calibrate_scale. */
+int cd_depth_to_points(const float* depths, const float* intrinsics, int N, int H, int W, float* points_out,
+                       double* sums_out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Depth CNN layers (reference: the un-vendored Mannequin-Challenge hourglass called at
  * monodepth/mannequin_challenge_model.py:60; architecture SURVEY.md appendix A.3).
