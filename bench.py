@@ -180,6 +180,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if args.graph and getattr(step, "graphed", None) is None:
+        # fewer warm-up steps than the capture needs (eager steps + 1): finish the one-time capture outside the timed region
+        for i in range(4):
+            run(1, offset=args.warmup + i)
+            torch.cuda.synchronize()
+            if step.graphed is not None:
+                break
+        log(f"graph capture finished in {i + 1} extra untimed step(s)")
     graphed = bool(args.graph) and getattr(step, "graphed", None) is True
     if args.graph and not graphed:
         log(f"HIP graph capture not active ({getattr(step, 'capture_error', None) or 'needs >= 3 warm-up steps'}); eager steps")
