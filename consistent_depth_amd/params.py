@@ -27,56 +27,66 @@ _PASSTHROUGH = (
 )
 
 
+# the pipeline's own flags, in the reference's order of stages (params.py:24-76)
+def _stage_flags():
+    return (
+        ("--op", dict(choices=["all", "extract_frames"], default="all")),
+        ("--path", dict(type=str, help="dataset directory (inputs and outputs)")),
+        ("--video_file", dict(type=str, help="input video (ignored by the fine-tuning engine)")),
+        ("--configure", dict(choices=["default", "kitti"], default="default")),
+        ("--size", dict(type=int, default=384, help="long image side of the depth maps")),
+        ("--align", dict(type=int, default=0, help="<= 0: the depth network's requirement")),
+        ("--flow_ops", dict(nargs="*", choices=frame_sampling.SamplePairsMode.names(), default=["hierarchical2"])),
+        ("--flow_checkpoint", dict(choices=["FlowNet2", "FlowNet2-KITTI"], default="FlowNet2")),
+        ("--overlap_ratio", dict(type=float, default=0.2)),
+    ) + _PASSTHROUGH
+
+
+def _tail_flags():
+    return (
+        ("--model_type", dict(type=str, choices=get_depth_model_list(), default="mc")),
+        ("--frame_range", dict(default="", type=frame_range.parse_frame_range, help="frames to fine-tune, e.g. 0,2-10,21-40")),
+        ("--make_video", dict(action="store_true")),
+        ("--seed", dict(type=int, default=0)),      # extension: seed of the epoch permutations / random init
+    )
+
+
+# what `--configure kitti` overrides (params.py:86-93) and which unset flags fall back to the model's class attributes
+_KITTI = dict(flow_checkpoint="FlowNet2-KITTI", model_type="monodepth2", overlap_ratio=0.5, matcher="sequential")
+_MODEL_DEFAULTS = (("align", lambda v: v <= 0), ("learning_rate", lambda v: v <= 0), ("lambda_view_baseline", lambda v: v < 0))
+
+
 class Video3dParamsParser:
+    """`Video3dParamsParser().parse(argv)` -> namespace, like the reference's class of the same name."""
+
     def __init__(self):
         self.parser = argparse.ArgumentParser()
         self.initialized = False
 
     def initialize(self):
-        ap = self.parser
-        ap.add_argument("--op", choices=["all", "extract_frames"], default="all")
-        ap.add_argument("--path", type=str, help="dataset directory (inputs and outputs)")
-        ap.add_argument("--video_file", type=str, help="input video (ignored by the fine-tuning engine)")
-        ap.add_argument("--configure", choices=["default", "kitti"], default="default")
-        # video
-        ap.add_argument("--size", type=int, default=384, help="long image side of the depth maps")
-        ap.add_argument("--align", type=int, default=0, help="<= 0: the depth network's requirement")
-        # flow
-        ap.add_argument("--flow_ops", nargs="*", choices=frame_sampling.SamplePairsMode.names(),
-                        default=["hierarchical2"])
-        ap.add_argument("--flow_checkpoint", choices=["FlowNet2", "FlowNet2-KITTI"], default="FlowNet2")
-        ap.add_argument("--overlap_ratio", type=float, default=0.2)
-        # calibration / make-video groups (accepted, unused by the engine)
-        for flag, kw in _PASSTHROUGH:
-            ap.add_argument(flag, **kw)
-        # fine-tuning
-        DepthFineTuningParams.add_arguments(ap)
-        ap.add_argument("--model_type", type=str, choices=get_depth_model_list(), default="mc")
-        ap.add_argument("--frame_range", default="", type=frame_range.parse_frame_range,
-                        help="frames to fine-tune, e.g. 0,2-10,21-40")
-        ap.add_argument("--make_video", action="store_true")
-        # extension (not in the reference): seed of the epoch permutations / random init
-        ap.add_argument("--seed", type=int, default=0)
+        for flag, kw in _stage_flags():
+            self.parser.add_argument(flag, **kw)
+        DepthFineTuningParams.add_arguments(self.parser)
+        for flag, kw in _tail_flags():
+            self.parser.add_argument(flag, **kw)
         self.initialized = True
 
     def print(self):
+        shown = {k: (v.name if isinstance(v, frame_range.NamedOptionalSet) else v) for k, v in vars(self.params).items()}
         print("------------ Parameters -------------")
-        for k, v in sorted(vars(self.params).items()):
-            print(f"{k}: '{v.name}'" if isinstance(v, frame_range.NamedOptionalSet) else f"{k}: {v}")
+        for key in sorted(shown):
+            print(f"{key}: {shown[key]!r}" if isinstance(vars(self.params)[key], frame_range.NamedOptionalSet) else f"{key}: {shown[key]}")
         print("-------------------------------------")
 
     def parse(self, args=None, namespace=None):
         if not self.initialized:
             self.initialize()
-        self.params = p = self.parser.parse_args(args, namespace=namespace)
-        if p.configure == "kitti":
-            p.flow_checkpoint, p.model_type, p.overlap_ratio, p.matcher = "FlowNet2-KITTI", "monodepth2", 0.5, "sequential"
-        model = get_depth_model(p.model_type)
-        if p.align <= 0:
-            p.align = model.align
-        if p.learning_rate <= 0:
-            p.learning_rate = model.learning_rate
-        if p.lambda_view_baseline < 0:
-            p.lambda_view_baseline = model.lambda_view_baseline
+        self.params = chosen = self.parser.parse_args(args, namespace=namespace)
+        if chosen.configure == "kitti":
+            vars(chosen).update(_KITTI)
+        model_cls = get_depth_model(chosen.model_type)
+        for name, unset in _MODEL_DEFAULTS:
+            if unset(getattr(chosen, name)):
+                setattr(chosen, name, getattr(model_cls, name))
         self.print()
-        return p
+        return chosen

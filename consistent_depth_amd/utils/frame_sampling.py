@@ -1,35 +1,75 @@
-"""Frame-pair sampling (consecutive / hierarchical / hierarchical2 / exhausted).
-Same public surface as /root/reference/utils/frame_sampling.py:12-155 (SamplePairsMode,
-SamplePairsOptions, Pair, SamplePairs.sample/to_one_way, to_in_range).
+"""Which frame pairs to fine-tune on.
 
-hierarchical: for every level l with 2^l in [min_dist, max_dist], pair (s, s + 2^l) for s stepping
-by 2^l; hierarchical2 ("include_mid_point") steps by 2^(l-1) instead.  244 frames -> 715 one-way
-pairs, 1000 frames -> 2979.  `sample_exhausted` is broken in the
-reference (TypeError); here it works.
-"""
+Public names follow the reference's module of the same name (/root/reference/utils/frame_sampling.py:12-155 --
+`SamplePairsMode`, `SamplePairsOptions`, `Pair`, `SamplePairs.sample / to_one_way`, `to_in_range`), because
+`video_dataset` / `params` / the pair store address it by those names.  The sampling itself is written as plain pair
+generators over frame *indices*:
+
+  dyadic(n, level, stride)   (s, s + 2^level) for s = 0, stride, 2*stride, ... < n
+  hierarchical               levels with min_dist <= 2^level <= max_dist, stride 2^level
+  hierarchical2              same levels, stride 2^(level-1): every window also starts at its mid point
+  consecutive                level 0 only;   exhausted: all i < j (the reference's version raises TypeError)
+
+244 frames -> 715 one-way pairs with hierarchical2, 1000 frames -> 2979."""
 from __future__ import annotations
 
+import enum
 from collections import namedtuple
-from enum import Enum, auto, unique
-from typing import Any, Dict, Iterable, NamedTuple, Set
+from typing import Any, Dict, Iterable, Iterator, NamedTuple, Optional, Set, Tuple
 
 from .frame_range import FrameRange
 
+Pair = namedtuple("Pair", ["first", "second"])
+Pairs_t = Set[Pair]
 
-@unique
-class SamplePairsMode(Enum):
+
+# ---------------------------------------------------------------------------- generators over frame indices
+def _dyadic(n: int, level: int, stride: int, both_ways: bool) -> Iterator[Tuple[int, int]]:
+    reach = 1 << level
+    for s in range(0, n, stride):
+        if s + reach < n:
+            yield s, s + reach
+        if both_ways and s - reach >= 0:
+            yield s, s - reach
+
+
+def _dyadic_levels(lo: int, hi: int) -> Iterator[int]:
+    if lo < 1:
+        raise ValueError("min_dist must be >= 1")
+    level = max(0, (lo - 1).bit_length())          # smallest level with 2^level >= lo
+    while (1 << level) <= hi:
+        yield level
+        level += 1
+
+
+def _hierarchy(n: int, both_ways: bool, lo: int, hi: Optional[int], mid_points: bool) -> Pairs_t:
+    hi = n - 1 if hi is None else hi
+    found: Pairs_t = set()
+    for level in _dyadic_levels(lo, hi):
+        stride = 1 << (level - 1 if (mid_points and level > 0) else level)
+        found.update(Pair(a, b) for a, b in _dyadic(n, level, stride, both_ways))
+    return found
+
+
+def _all_pairs(n: int, both_ways: bool) -> Pairs_t:
+    return {Pair(i, j) for i in range(n) for j in range(n) if (i < j or (both_ways and i != j))}
+
+
+# ---------------------------------------------------------------------------- the reference's surface
+@enum.unique
+class SamplePairsMode(enum.Enum):
     EXHAUSTED = 0
-    CONSECUTIVE = auto()
-    HIERARCHICAL = auto()
-    HIERARCHICAL2 = auto()
+    CONSECUTIVE = 1
+    HIERARCHICAL = 2
+    HIERARCHICAL2 = 3
 
     @classmethod
-    def name_mode_map(cls):
-        return {m.name.lower(): m for m in cls}
+    def name_mode_map(cls) -> Dict[str, "SamplePairsMode"]:
+        return {member.name.lower(): member for member in cls}
 
     @classmethod
     def names(cls):
-        return [m.name.lower() for m in cls]
+        return list(cls.name_mode_map())
 
 
 class SamplePairsOptions(NamedTuple):
@@ -37,83 +77,50 @@ class SamplePairsOptions(NamedTuple):
     params: Dict[str, Any] = {}
 
 
-Pair = namedtuple("Pair", ["first", "second"])
-Pairs_t = Set[Pair]
-
-
-def _levels(min_dist: int, max_dist: int):
-    level = 0
-    while (1 << level) < min_dist:
-        level += 1
-    while (1 << level) <= max_dist:
-        yield level
-        level += 1
-
-
 class SamplePairs:
-    @classmethod
-    def sample(cls, opts: Iterable[SamplePairsOptions], frame_range: FrameRange, two_way=False) -> Pairs_t:
-        n = len(frame_range)
-        rel = set()
-        for opt in opts:
-            rel |= cls.factory(n, opt, two_way)
-        wanted = set(frame_range.frames())
-        to_frame = frame_range.index_to_frame
-        return {Pair(to_frame[a], to_frame[b]) for a, b in rel if to_frame[a] in wanted or to_frame[b] in wanted}
+    """Facade with the reference's method names; every method returns a set of index `Pair`s."""
+
+    sample_exhausted = staticmethod(_all_pairs)
+
+    @staticmethod
+    def sample_hierarchical(num_frames, two_way, min_dist=1, max_dist=None, include_mid_point=False) -> Pairs_t:
+        return _hierarchy(num_frames, two_way, min_dist, max_dist, include_mid_point)
+
+    @staticmethod
+    def sample_hierarchical2(num_frames, two_way, min_dist=1, max_dist=None) -> Pairs_t:
+        return _hierarchy(num_frames, two_way, min_dist, max_dist, True)
+
+    @staticmethod
+    def sample_consecutive(num_frames, two_way) -> Pairs_t:
+        return _hierarchy(num_frames, two_way, 1, 1, False)
 
     @classmethod
     def factory(cls, num_frames: int, opt: SamplePairsOptions, two_way: bool) -> Pairs_t:
-        table = {
-            SamplePairsMode.EXHAUSTED: cls.sample_exhausted,
-            SamplePairsMode.CONSECUTIVE: cls.sample_consecutive,
-            SamplePairsMode.HIERARCHICAL: cls.sample_hierarchical,
-            SamplePairsMode.HIERARCHICAL2: cls.sample_hierarchical2,
-        }
-        return table[opt.mode](num_frames, two_way, **opt.params)
+        return getattr(cls, "sample_" + opt.mode.name.lower())(num_frames, two_way, **opt.params)
+
+    @classmethod
+    def sample(cls, opts: Iterable[SamplePairsOptions], frame_range: FrameRange, two_way=False) -> Pairs_t:
+        """Union of the requested samplings over len(frame_range) indices, mapped to frame numbers; a pair is kept when
+        at least one of its frames is in the range."""
+        by_index: Pairs_t = set()
+        for opt in opts:
+            by_index |= cls.factory(len(frame_range), opt, two_way)
+        number, inside = frame_range.index_to_frame, set(frame_range.frames())
+        return {Pair(number[a], number[b]) for a, b in by_index if number[a] in inside or number[b] in inside}
 
     @staticmethod
-    def sample_hierarchical(num_frames: int, two_way: bool, min_dist=1, max_dist=None,
-                            include_mid_point=False) -> Pairs_t:
-        if min_dist < 1:
-            raise ValueError("min_dist must be >= 1")
-        if max_dist is None:
-            max_dist = num_frames - 1
-        pairs = set()
-        for level in _levels(min_dist, max_dist):
-            dist = 1 << level
-            step = 1 << (max(0, level - 1) if include_mid_point else level)
-            for start in range(0, num_frames, step):
-                for end in ((start - dist, start + dist) if two_way else (start + dist,)):
-                    if 0 <= end < num_frames:
-                        pairs.add(Pair(start, end))
-        return pairs
-
-    @classmethod
-    def sample_hierarchical2(cls, num_frames: int, two_way: bool, min_dist=1, max_dist=None) -> Pairs_t:
-        return cls.sample_hierarchical(num_frames, two_way, min_dist, max_dist, include_mid_point=True)
-
-    @classmethod
-    def sample_consecutive(cls, num_frames: int, two_way: bool) -> Pairs_t:
-        return cls.sample_hierarchical(num_frames, two_way, min_dist=1, max_dist=1)
-
-    @staticmethod
-    def sample_exhausted(num_frames: int, two_way: bool) -> Pairs_t:
-        return {Pair(i, j) for i in range(num_frames) for j in range(num_frames)
-                if i != j and (two_way or i < j)}
-
-    @classmethod
-    def to_one_way(cls, pairs) -> Pairs_t:
-        return {Pair(*sorted(p)) for p in pairs}
+    def to_one_way(pairs) -> Pairs_t:
+        return {Pair(min(p), max(p)) for p in pairs}
 
 
 def to_in_range(pairs, frame_range=None):
     if frame_range is None:
         return pairs
-    lo, hi = frame_range
-    return [p for p in pairs if all(lo <= i < hi for i in p)]
+    first, stop = frame_range
+    return [p for p in pairs if first <= min(p) and max(p) < stop]
 
 
 def sample_pairs(frame_range: FrameRange, flow_ops):
-    """flow_ops names -> two-way pair set (reference: video.py:18-28)."""
-    modes = SamplePairsMode.name_mode_map()
-    return SamplePairs.sample([SamplePairsOptions(mode=modes[op]) for op in flow_ops], frame_range, two_way=True)
+    """flow_ops names ("hierarchical2", ...) -> two-way pair set, as video.py:18-28 builds it."""
+    known = SamplePairsMode.name_mode_map()
+    return SamplePairs.sample([SamplePairsOptions(mode=known[name]) for name in flow_ops], frame_range, two_way=True)
