@@ -84,3 +84,21 @@ def test_warp_oracle_vs_live_reference(ref):
         np.testing.assert_allclose(uv, want_uv, rtol=0, atol=1e-11)
         np.testing.assert_allclose(w, want_w, rtol=0, atol=1e-12)
         assert go.calibrate_scale(b["extrinsics"][p], b["intrinsics"][p], b["depth"][p][:, None]) == pytest.approx(want_s, rel=1e-11)
+
+
+def test_pair_sampling_and_frame_ranges_vs_live_reference(ref):
+    """Host logic either side of the hot path: the frame-pair sets and the canonical range names must be the reference's."""
+    from utils import frame_range as rfr, frame_sampling as rfs        # the reference's modules (fixture put it first on sys.path)
+    from consistent_depth_amd.utils import frame_range as mfr, frame_sampling as mfs
+    for spec in ("", "0,2-6,8", "6,5,8,0,2-4,5-6,10,9", "3", "0-40", "1-10,15,21-40,51-62"):
+        a, b = mfr.parse_frame_range(spec), rfr.parse_frame_range(spec)
+        assert a.name == b.name and a.set.set == b.set.set
+    for n, spec in ((17, ""), (64, "3-40"), (244, ""), (100, "0,2-10,21-40,97")):
+        for mode in ("hierarchical", "hierarchical2", "consecutive"):
+            for two_way in (False, True):
+                mine = mfs.SamplePairs.sample([mfs.SamplePairsOptions(mode=mfs.SamplePairsMode.name_mode_map()[mode])],
+                                              mfr.FrameRange(mfr.parse_frame_range(spec).set, n), two_way=two_way)
+                theirs = rfs.SamplePairs.sample([rfs.SamplePairsOptions(mode=rfs.SamplePairsMode.name_mode_map()[mode])],
+                                                rfr.FrameRange(rfr.parse_frame_range(spec).set, n), two_way=two_way)
+                assert {tuple(p) for p in mine} == {tuple(p) for p in theirs}, (n, spec, mode, two_way)
+    assert len(mfs.SamplePairs.to_one_way(mfs.sample_pairs(mfr.FrameRange(mfr.OptionalSet(), 244), ["hierarchical2"]))) == 715
