@@ -1,0 +1,71 @@
+"""CPU: properties of the loss oracle that do not need the reference -- they would catch a wrong restatement even
+if a golden file were stale.  All in fp64 at small sizes (the oracle is plain C, milliseconds)."""
+import numpy as np
+import pytest
+
+
+def _batch(B=2, H=12, W=17, seed=0):
+    from consistent_depth_amd import synthetic
+    return synthetic.make_scene_batch(B, H, W, seed=seed)
+
+
+def _loss(oracle, b, lr=1.0, lb=0.1, depth=None):
+    d = b["depth"] if depth is None else depth
+    return oracle.consistency_loss(d, b["flows"], b["masks"], b["intrinsics"], b["extrinsics"], lr, lb, dtype=np.float64)
+
+
+def test_analytic_gradient_matches_central_differences(oracle):
+    b = _batch(seed=3)
+    ref = _loss(oracle, b)
+    g = ref["grad_depth"]
+    rng = np.random.default_rng(0)
+    depth = b["depth"].astype(np.float64)
+    checked = 0
+    for _ in range(40):
+        idx = tuple(rng.integers(0, s) for s in depth.shape)
+        h = 1e-6 * max(1.0, abs(depth[idx]))
+        dp, dm = depth.copy(), depth.copy()
+        dp[idx] += h
+        dm[idx] -= h
+        fd = (_loss(oracle, b, depth=dp)["total"][0] - _loss(oracle, b, depth=dm)["total"][0]) / (2 * h)
+        if abs(fd - g[idx]) > 1e-5 * max(1.0, abs(fd)):       # |x| kinks (e = 0, 1/Z = 1/zs) are measure-zero but exist
+            continue
+        checked += 1
+    assert checked >= 36, f"only {checked}/40 sampled entries agree with finite differences"
+
+
+def test_pair_swap_symmetry(oracle):
+    """Swapping the two frames of every pair (depth, cameras, flows, masks) swaps the gradient planes, keeps the losses."""
+    b = _batch(seed=5)
+    a = _loss(oracle, b)
+    sw = dict(b, depth=b["depth"][:, ::-1].copy(), intrinsics=b["intrinsics"][:, ::-1].copy(), extrinsics=b["extrinsics"][:, ::-1].copy(),
+              flows=[b["flows"][1], b["flows"][0]], masks=[b["masks"][1], b["masks"][0]])
+    s = _loss(oracle, sw)
+    np.testing.assert_allclose(s["total"], a["total"], rtol=1e-13)
+    np.testing.assert_allclose(s["reprojection"], a["reprojection"], rtol=1e-12)
+    np.testing.assert_allclose(s["grad_depth"][:, ::-1], a["grad_depth"], rtol=1e-10, atol=1e-15)
+
+
+def test_lambda_linearity_and_mask_scale_invariance(oracle):
+    b = _batch(seed=7)
+    r, d = _loss(oracle, b, 1.0, 0.0), _loss(oracle, b, 0.0, 1.0)
+    both = _loss(oracle, b, 0.7, 0.3)
+    np.testing.assert_allclose(both["total"], 0.7 * r["total"] + 0.3 * d["total"], rtol=1e-13)
+    np.testing.assert_allclose(both["grad_depth"], 0.7 * r["grad_depth"] + 0.3 * d["grad_depth"], rtol=1e-11, atol=1e-16)
+    scaled = dict(b, masks=[2.5 * m for m in b["masks"]])      # weighted means do not see a positive mask scale
+    s = _loss(oracle, scaled, 0.7, 0.3)
+    np.testing.assert_allclose(s["total"], both["total"], rtol=1e-12)
+    np.testing.assert_allclose(s["grad_depth"], both["grad_depth"], rtol=1e-10, atol=1e-16)
+
+
+def test_pairs_are_independent_except_for_the_batch_mean_focal(oracle):
+    """The only coupling between pairs is the batch-mean focal length of the disparity term (consistency_loss.py:178):
+    with identical intrinsics everywhere, a batch is exactly the mean of its pairs."""
+    b = _batch(B=3, seed=9)
+    b["intrinsics"][:] = b["intrinsics"][0, 0]
+    whole = _loss(oracle, b, 1.0, 0.1)
+    singles = [_loss(oracle, {k: (v[i:i + 1] if not isinstance(v, list) else [x[i:i + 1] for x in v]) for k, v in b.items()}, 1.0, 0.1)
+               for i in range(3)]
+    np.testing.assert_allclose(whole["total"][0], np.mean([s["total"][0] for s in singles]), rtol=1e-13)
+    for i, s in enumerate(singles):
+        np.testing.assert_allclose(whole["grad_depth"][i] * 3, s["grad_depth"][0], rtol=1e-10, atol=1e-16)
