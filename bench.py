@@ -201,15 +201,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if graphed:       # the same kernel timed in 3 eager steps after the timed region
-        assert lib.cd_profile_begin(16) == 0
+    # With graph replay the in-step loss kernel is timed in 3 eager steps after the timed region.  Those steps contain the
+    # gradient all-reduce, so the decision to run them must be the same on every rank (capture could fail on a single one).
+    extra = graphed
+    if world > 1:
+        flag = torch.tensor([1.0 if graphed else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        extra = flag.item() > 0
+    if extra:
+        if graphed:       # (an eager rank has had the profiler on since before the timed region)
+            assert lib.cd_profile_begin(16) == 0
         for i in range(3):
             images, meta, _, _ = pool[i % len(pool)]
             eager_step(images, meta)
         torch.cuda.synchronize()
-        ms_step, _ = profile_collect(lib, 16)
-    else:
-        ms_step, _ = profile_collect(lib, args.steps + 8)
+    ms_step, _ = profile_collect(lib, 16 if graphed else args.steps + 8)
     if world > 1:
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
