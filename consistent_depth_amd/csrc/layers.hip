@@ -156,8 +156,8 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
     const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
     const float k = g * mean_invstd[2 * (x_coff + c) + 1];
     if (dgamma && blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
-        dgamma[c] = (float)sums[2 * c + 1];
-        dbeta[c] = (float)sums[2 * c];
+        dgamma[c] += (float)sums[2 * c + 1];   // accumulated like every parameter gradient of the engine
+        dbeta[c] += (float)sums[2 * c];
     }
     float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;

@@ -34,7 +34,9 @@ flat Adam buffer).  The unused `uncertainty_layer` head is not evaluated (its ou
 the reference, mannequin_challenge_model.py:60, and its parameters never receive gradients).
 
 Conv biases in front of a train-mode BatchNorm have an identically zero gradient (the mean subtraction
-removes them); the engine leaves those gradients at exactly 0 instead of computing round-off noise.
+removes them); the engine leaves those gradients untouched instead of adding round-off noise.
+Every parameter gradient is ACCUMULATED into p.grad (torch's convention; the optimiser's zero_grad clears them once
+per step), so gradients other autograd nodes put there first -- ParameterLoss with lambda_parameter > 0 -- survive.
 """
 from __future__ import annotations
 
@@ -117,7 +119,7 @@ class ConvUnit:
                           dgamma=_grad_of(self.bn.weight) if affine else None,
                           dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True)
         else:
-            L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias))
+            L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias), accumulate=True)
         # the partial sums stay packed in the arena; plan["unpack"] writes every weight gradient at the end of the backward
         self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
             s.buf, gbuf, self.cin, self.cout, self.ks, None, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,

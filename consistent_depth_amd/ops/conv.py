@@ -176,7 +176,10 @@ class UnpackTable:
 
     add(workspace, grad, Cin, ks, plan, row0=0) registers a destination gradient tensor (rows = grad.shape[0]) fed from the
     output-channel rows [row0, row0+rows) of a packed workspace; run() launches, rebuilding the device table first if a
-    gradient tensor moved (FlatAdam re-homes .grad; zero_grad(set_to_none) would reallocate)."""
+    gradient tensor moved (FlatAdam re-homes .grad; zero_grad(set_to_none) would reallocate).
+    The gradients are ACCUMULATED into their destinations (p.grad += dW, torch's convention): whatever another autograd
+    node has already put there -- the lambda_parameter * sign(p - p0) pull of ParameterLoss -- survives; zero_grad()
+    clears them once per step."""
 
     _DT = [("packed", "<u8"), ("dw", "<u8"), ("Cin", "<i4"), ("ks", "<i4"), ("cob", "<i4"), ("cib", "<i4"), ("cig", "<i4"),
            ("row0", "<i4"), ("rows", "<i4"), ("acc", "<i4")]
@@ -194,7 +197,7 @@ class UnpackTable:
         for j, ((ws, _, Cin, ks, (cob, cib), row0), g) in enumerate(zip(self._entries, grads)):
             if not (g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda and g.shape[1] == Cin and g.shape[2] == ks):
                 raise RuntimeError("weight gradients must be contiguous fp32 (rows, Cin, k, k) on the HIP device")
-            tab[j] = (ws.data_ptr(), g.data_ptr(), Cin, ks, cob, cib, (Cin + cib - 1) // cib, row0, g.shape[0], 0)
+            tab[j] = (ws.data_ptr(), g.data_ptr(), Cin, ks, cob, cib, (Cin + cib - 1) // cib, row0, g.shape[0], 1)
         self._ptrs = [g.data_ptr() for g in grads]
         self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
 

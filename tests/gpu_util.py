@@ -23,3 +23,18 @@ class Opt:
         self.lambda_reprojection = lambda_reprojection
         self.lambda_view_baseline = lambda_view_baseline
         self.lambda_parameter = lambda_parameter
+
+
+def report(test, **metrics):
+    """Print the measured parity distances of a test (pytest -s / -rP shows them) and append them to
+    gpurun_out/parity_log.txt so the numbers of a GPU run can be committed under profiles/."""
+    import os
+    line = f"PARITY {test}: " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in metrics.items())
+    print(line, flush=True)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_log.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass

@@ -3,20 +3,27 @@
   (2) the CPU oracle on seeded inputs at BASELINE sizes (B=4, 384x224),
   (3) size-independent properties (pair-swap symmetry, lambda linearity, autograd scaling).
 
-Tolerances (fp32 kernel vs fp64 reference): loss values 2e-5 relative, depth gradient 2e-4
-relative-L1 -- the reference's own fp32-vs-fp64 noise floor is 1e-7 / 7e-6 (SURVEY.md section 4);
-BASELINE's 1e-3 budget is for accumulated training drift.
+Tolerances (fp32 kernel vs the fp64 reference): loss values 1e-6 relative; depth gradient within 4x of the
+distance the REFERENCE's own fp32 arithmetic has to its fp64 self on the same inputs (torch fp32 for the goldens,
+the fp32 build of the oracle elsewhere; floor 2e-6).  Every test prints its measured distances (`PARITY ...`,
+also appended to gpurun_out/parity_log.txt; a run is committed as profiles/parity_loss_r02.txt): the kernels sit
+at 0.7-1.4x the reference's fp32 distance on every case, the `stress` golden included.
 """
 import numpy as np
 import pytest
 
 from conftest import golden_loss_cases, load_loss_case
-from gpu_util import Opt, metadata_of, to_dev
+from gpu_util import Opt, metadata_of, report, to_dev
 
 pytestmark = pytest.mark.gpu
 
-LOSS_RTOL = 2e-5
-GRAD_REL_L1 = 2e-4
+LOSS_RTOL = 1e-6
+GRAD_X_REF = 4.0     # allowed multiple of the reference's own fp32-vs-fp64 gradient distance
+GRAD_FLOOR = 2e-6
+
+
+def grad_tol(ref_fp32_dist):
+    return max(GRAD_X_REF * ref_fp32_dist, GRAD_FLOOR)
 
 
 @pytest.fixture(scope="module")
@@ -50,14 +57,16 @@ def variant(request):
 
 @pytest.mark.parametrize("name", golden_loss_cases())
 def test_golden_vectors(torch_cuda, oracle, name, variant):
-    batch, lr, lb, ref64, _ = load_loss_case(name)
+    batch, lr, lb, ref64, ref32 = load_loss_case(name)
     total, reproj, disp, grad = _run(torch_cuda, batch, lr, lb)
+    report(f"golden[{name},v{variant}]", loss_rel=abs(total - ref64["total"][0]) / abs(ref64["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, ref64["grad_depth"]),
+           ref_fp32_grad_rel_l1=oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]),
+           ref_fp32_loss_rel=abs(float(ref32["total"][0]) - ref64["total"][0]) / abs(ref64["total"][0]))
     np.testing.assert_allclose(total, ref64["total"][0], rtol=LOSS_RTOL)
     np.testing.assert_allclose(reproj, ref64["reprojection"], rtol=LOSS_RTOL, atol=1e-7)
     np.testing.assert_allclose(disp, ref64["disparity"], rtol=LOSS_RTOL, atol=1e-7)
-    # the stress case has taps that hop a pixel border under fp32 rounding of the sample position
-    tol = 5e-3 if name.startswith("stress") else GRAD_REL_L1
-    assert oracle.rel_l1(grad, ref64["grad_depth"]) < tol
+    assert oracle.rel_l1(grad, ref64["grad_depth"]) < grad_tol(oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]))
 
 
 @pytest.mark.parametrize("gen", ["scene", "unrelated"])
@@ -71,10 +80,16 @@ def test_baseline_size_vs_oracle(torch_cuda, oracle, H, W, gen, variant):
     ref = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"],
                                   batch["extrinsics"], 1.0, 0.1, dtype=np.float64)
     total, reproj, disp, grad = _run(torch_cuda, batch, 1.0, 0.1)
+    r32 = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"],
+                                  batch["extrinsics"], 1.0, 0.1, dtype=np.float32)
+    report(f"baseline_size[{gen},{H}x{W},v{variant}]", loss_rel=abs(total - ref["total"][0]) / abs(ref["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, ref["grad_depth"]),
+           ref_fp32_grad_rel_l1=oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]),
+           ref_fp32_loss_rel=abs(float(r32["total"][0]) - ref["total"][0]) / abs(ref["total"][0]))
     np.testing.assert_allclose(total, ref["total"][0], rtol=LOSS_RTOL)
     np.testing.assert_allclose(reproj, ref["reprojection"], rtol=LOSS_RTOL)
     np.testing.assert_allclose(disp, ref["disparity"], rtol=LOSS_RTOL)
-    assert oracle.rel_l1(grad, ref["grad_depth"]) < GRAD_REL_L1
+    assert oracle.rel_l1(grad, ref["grad_depth"]) < grad_tol(oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -89,8 +104,10 @@ def test_fused_depth_heads(torch_cuda, oracle, mode, variant):
                                   1.0, 0.1, dtype=np.float64)
     b2 = dict(batch, depth=x.astype(np.float32))
     total, reproj, disp, grad = _run(torch_cuda, b2, 1.0, 0.1, mode=mode)
-    np.testing.assert_allclose(total, ref["total"][0], rtol=5e-5)
-    assert oracle.rel_l1(grad, ref["grad_depth"] * jac) < 5e-4
+    report(f"fused_head[mode{mode},v{variant}]", loss_rel=abs(total - ref["total"][0]) / abs(ref["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, ref["grad_depth"] * jac))
+    np.testing.assert_allclose(total, ref["total"][0], rtol=LOSS_RTOL)
+    assert oracle.rel_l1(grad, ref["grad_depth"] * jac) < 1e-5
 
 
 def test_forward_only_and_cached_mask_sums(torch_cuda):
@@ -121,16 +138,17 @@ def test_overflow_list_and_device_fallback(torch_cuda, oracle, name, cap, varian
     through the overflow list (cap large), and when the list itself overflows (cap tiny) the
     device-side fallback recomputes the gradient.  Forced here with the debug capacity hook."""
     from consistent_depth_amd import _native
-    batch, lr, lb, ref64, _ = load_loss_case(name)
+    batch, lr, lb, ref64, ref32 = load_loss_case(name)
     lib = _native.lib()
     try:
         assert lib.cd_debug_set_overflow_capacity(cap) == 0
         total, reproj, disp, grad = _run(torch_cuda, batch, lr, lb)
     finally:
         lib.cd_debug_set_overflow_capacity(-1)
+    report(f"overflow[{name},cap{cap},v{variant}]", loss_rel=abs(total - ref64["total"][0]) / abs(ref64["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, ref64["grad_depth"]))
     np.testing.assert_allclose(total, ref64["total"][0], rtol=LOSS_RTOL)
-    tol = 5e-3 if name.startswith("stress") else GRAD_REL_L1
-    assert oracle.rel_l1(grad, ref64["grad_depth"]) < tol
+    assert oracle.rel_l1(grad, ref64["grad_depth"]) < grad_tol(oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]))
 
 
 def test_wild_flow_full_size_vs_oracle(torch_cuda, oracle, variant):
@@ -141,8 +159,13 @@ def test_wild_flow_full_size_vs_oracle(torch_cuda, oracle, variant):
     ref = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"],
                                   batch["extrinsics"], 1.0, 0.1, dtype=np.float64)
     total, reproj, disp, grad = _run(torch_cuda, batch, 1.0, 0.1)
+    r32 = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"],
+                                  batch["extrinsics"], 1.0, 0.1, dtype=np.float32)
+    report(f"wild_flow[v{variant}]", loss_rel=abs(total - ref["total"][0]) / abs(ref["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, ref["grad_depth"]),
+           ref_fp32_grad_rel_l1=oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
     np.testing.assert_allclose(total, ref["total"][0], rtol=LOSS_RTOL)
-    assert oracle.rel_l1(grad, ref["grad_depth"]) < GRAD_REL_L1
+    assert oracle.rel_l1(grad, ref["grad_depth"]) < grad_tol(oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
 
 
 def test_cached_tile_windows_bitwise(torch_cuda):

@@ -27,15 +27,13 @@ def test_loss_oracle_f32_matches_reference_f32(oracle, name):
     batch, lr, lb, ref64, ref32 = load_loss_case(name)
     out = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"],
                                   batch["extrinsics"], lr, lb, dtype=np.float32)
-    # fp32 noise floor of the reference itself is ~1e-7 (loss) / 7e-6 rel-L1 (grad): SURVEY.md section 4
-    np.testing.assert_allclose(out["total"], ref64["total"], rtol=2e-5)
-    np.testing.assert_allclose(out["reprojection"], ref64["reprojection"], rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(out["disparity"], ref64["disparity"], rtol=2e-5, atol=1e-7)
-    tol = 5e-3 if name.startswith("stress") else 1e-4  # stress: taps hop across pixel borders in fp32
-    assert oracle.rel_l1(out["grad_depth"], ref64["grad_depth"]) < tol
-    # and the fp32 reference is as far from fp64 as we are (same noise class)
+    # the fp32 build of the oracle follows the reference's op order: it must be as far from fp64 as the reference's own
+    # fp32 run is (measured: 0.98-1.06x on every golden, `stress` included; loss 2e-8 ... 2.3e-7)
+    np.testing.assert_allclose(out["total"], ref64["total"], rtol=1e-6)
+    np.testing.assert_allclose(out["reprojection"], ref64["reprojection"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(out["disparity"], ref64["disparity"], rtol=1e-6, atol=1e-7)
     ref_noise = oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"])
-    assert oracle.rel_l1(out["grad_depth"], ref64["grad_depth"]) < max(tol, 10 * ref_noise)
+    assert oracle.rel_l1(out["grad_depth"], ref64["grad_depth"]) < max(2 * ref_noise, 1e-6)
 
 
 def test_sample_oracle_matches_reference(oracle):
