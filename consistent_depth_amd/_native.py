@@ -30,6 +30,7 @@ SIGNATURES = {
     "cd_debug_set_overflow_capacity": (c_i, [c_i]),
     "cd_debug_set_loss_variant": (c_i, [c_i]),
     "cd_debug_set_loss_chunk": (c_i, [c_i]),
+    "cd_debug_set_loss_sweep": (c_i, [c_i]),
     "cd_consistency_loss_fwd_bwd": (c_i, [c_p] * 9 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 4 + [c_p, c_sz, c_p]),
     "cd_consistency_loss_fwd": (c_i, [c_p] * 8 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 3 + [c_p, c_sz, c_p]),
     "cd_profile_begin": (c_i, [c_i]),

@@ -50,38 +50,21 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const float* __restrict__ 
         if (threadIdx.x == 0) fbar_s[k] = acc / (2.f * (float)B);
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < B * 2; i += kBlock) {
-        const int b = i >> 1, k = i & 1;
-        const float* ir = intr + (b * 2 + k) * 4;
-        const float* it = intr + (b * 2 + (1 - k)) * 4;
-        const float* er = extr + (b * 2 + k) * 12;
-        const float* et = extr + (b * 2 + (1 - k)) * 12;
-        PairCam c;
-        for (int j = 0; j < 3; ++j) {
-            for (int l = 0; l < 3; ++l)
-                c.M[j * 3 + l] = et[0 * 4 + j] * er[0 * 4 + l] + et[1 * 4 + j] * er[1 * 4 + l] + et[2 * 4 + j] * er[2 * 4 + l];
-            c.c[j] = et[0 * 4 + j] * (er[3] - et[3]) + et[1 * 4 + j] * (er[7] - et[7]) + et[2 * 4 + j] * (er[11] - et[11]);
-        }
-        c.ifx_r = 1.f / ir[0]; c.ify_r = 1.f / ir[1]; c.cx_r = ir[2]; c.cy_r = ir[3];
-        c.fx_t = it[0]; c.fy_t = it[1]; c.cx_t = it[2]; c.cy_t = it[3];
-        const float S = fmaxf(mask_sum[i], 1e-6f);
-        c.invS = 1.f / S;
-        c.fbar = fbar_s[k];
-        c.gr = lambda_r > 0.f ? lambda_r / (2.f * (float)B * S) : 0.f;
-        c.gb = lambda_b > 0.f ? lambda_b * fbar_s[k] / (2.f * (float)B * S) : 0.f;
-        c.sx = (float)W / (float)(W - 1);
-        c.sy = (float)H / (float)(H - 1);
-        for (int j = 0; j < 6; ++j) c.pad[j] = 0.f;
-        cams[i] = c;
-    }
+    for (int b = threadIdx.x; b < B; b += kBlock)
+        prep_pair(intr + b * 8, extr + b * 24, mask_sum + b * 2, fbar_s, lambda_r, lambda_b, B, H, W, cams + b * 2);
 }
 
 // ---------------------------------------------------------------- fixed-order reductions
+// alt_flag (may be null): when *alt_flag != 0 the guarded v1 pass has recomputed everything (overflow list overflowed, or the
+// row sweep met a degenerate depth): its partial sums (alt_partial, alt_nblk per plane) are the loss.
 __global__ __launch_bounds__(kWave) void finalize_pairs_kernel(const float* __restrict__ partial,
                                                                const PairCam* __restrict__ cams, int nblk,
                                                                float lambda_r, float lambda_b,
-                                                               float* __restrict__ reproj, float* __restrict__ disp) {
+                                                               float* __restrict__ reproj, float* __restrict__ disp,
+                                                               const int* __restrict__ alt_flag,
+                                                               const float* __restrict__ alt_partial, int alt_nblk) {
     const int b = blockIdx.x;
+    if (alt_flag != nullptr && *alt_flag != 0) { partial = alt_partial; nblk = alt_nblk; }
     double r[2], q[2];
     for (int k = 0; k < 2; ++k) {
         double ar = 0.0, ad = 0.0;
@@ -179,7 +162,7 @@ static inline size_t ws_layout(int B, int H, int W, void* base, Workspace* w) {
 }
 
 static int g_force_overflow_cap = -1;  // test hook: shrink the overflow list (cd_debug_set_overflow_capacity)
-static int g_loss_variant = 3;         // 3 = evaluate-once + slab reduce (default), 2 = owner-computes
+static int g_loss_variant = 0;         // 0 = by batch and geometry (row sweep v4 when it fills the chip, else v3), 2 / 3 / 4 forced
 
 static int run_loss(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb,
                     const float* mask_sum, const void* tile_windows, const float* intr, const float* extr,
@@ -206,7 +189,8 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
     const bool vec4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(depth) | reinterpret_cast<uintptr_t>(ff) |
                                         reinterpret_cast<uintptr_t>(fb) | reinterpret_cast<uintptr_t>(mf) |
                                         reinterpret_cast<uintptr_t>(mb)) % 16 == 0);
-    int nparts;
+    int nparts, alt_nparts = 0;
+    const int* alt_flag = nullptr;
     if (!grad) {
         g_prof.pending_batch = -B;
         prof_before(s);
@@ -221,7 +205,11 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         }
         g_prof.pending_batch = B;
         const int cap = (g_force_overflow_cap >= 0 && g_force_overflow_cap < w.ovf_cap) ? g_force_overflow_cap : w.ovf_cap;
-        if (g_loss_variant == 2)
+        const bool use_sweep = d_on && sweep_supported(H, W) && (g_loss_variant == 4 || (g_loss_variant == 0 && sweep_preferred(B, H, W)));
+        if (use_sweep)
+            rc = launch_sweep(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf, cap,
+                              s, prof_before, prof_after);
+        else if (g_loss_variant == 2)
             rc = launch_owner(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf,
                               cap, s, prof_before, prof_after);
         else
@@ -234,9 +222,12 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         if ((rc = launch_zero_guarded(grad, (size_t)B * 2 * HW, flag, s)) != CD_OK) return rc;
         if ((rc = launch_v1(depth, ff, fb, mf, mb, w.cams, depth_mode, r_on, d_on, fb_vec4, B, H, W, w.partial_fb, grad, flag, s)) != CD_OK)
             return rc;
-        nparts = owner_ntiles(H, W);
+        alt_flag = flag;
+        alt_nparts = v1_blocks_per_plane(HW, fb_vec4 ? 4 : 1);
+        nparts = use_sweep ? 1 : owner_ntiles(H, W);
     }
-    hipLaunchKernelGGL(finalize_pairs_kernel, dim3(B), dim3(kWave), 0, s, w.partial, w.cams, nparts, lambda_r, lambda_b, reproj, disp);
+    hipLaunchKernelGGL(finalize_pairs_kernel, dim3(B), dim3(kWave), 0, s, w.partial, w.cams, nparts, lambda_r, lambda_b, reproj, disp,
+                       alt_flag, w.partial_fb, alt_nparts);
     CD_CHECK_LAUNCH();
     hipLaunchKernelGGL(finalize_total_kernel, dim3(1), dim3(kBlock), 0, s, reproj, disp, B, total);
     CD_CHECK_LAUNCH();
@@ -287,8 +278,14 @@ int cd_debug_set_loss_chunk(int pairs) {
 }
 
 int cd_debug_set_loss_variant(int v) {
-    if (v != 2 && v != 3) return CD_ERR_INVALID_ARG;
+    if (v != 0 && v != 2 && v != 3 && v != 4) return CD_ERR_INVALID_ARG;
     cd::g_loss_variant = v;
+    return CD_OK;
+}
+
+int cd_debug_set_loss_sweep(int pixels_per_thread) {
+    if (pixels_per_thread != 0 && pixels_per_thread != 1 && pixels_per_thread != 2 && pixels_per_thread != 4) return CD_ERR_INVALID_ARG;
+    cd::set_sweep_pxt(pixels_per_thread);
     return CD_OK;
 }
 

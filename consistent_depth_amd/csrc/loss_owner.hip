@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void tile_window_kernel(const float* __rest
                                                              const float* __restrict__ flow_bwd,
                                                              const float* __restrict__ mask_fwd,
                                                              const float* __restrict__ mask_bwd, int H, int W,
-                                                             int tiles_x, int ntiles, TileWin* __restrict__ wins) {
+                                                             int tiles_x, int ntiles, int wstride, TileWin* __restrict__ wins) {
     __shared__ int red[4][kBlock / kWave];
     const int j = blockIdx.y, b = blockIdx.z, tile = blockIdx.x;
     const int HW = H * W;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void tile_window_kernel(const float* __rest
             if (wh > WMAXH) { y0 += (wh - WMAXH) / 2; wh = WMAXH; }
             w.x0 = (short)x0; w.y0 = (short)y0; w.w = (short)ww; w.h = (short)wh;
         }
-        wins[(size_t)(b * 2 + j) * ntiles + tile] = w;
+        wins[(size_t)b * wstride + (size_t)j * ntiles + tile] = w;
     }
 }
 
@@ -101,7 +101,7 @@ template <int MODE, bool REPROJ>
 __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
     const float* __restrict__ depth, const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd,
     const float* __restrict__ mask_fwd, const float* __restrict__ mask_bwd, const PairCam* __restrict__ cams,
-    const TileWin* __restrict__ wins, int H, int W, int tiles_x, int ntiles, float* __restrict__ partial,
+    const TileWin* __restrict__ wins, int H, int W, int tiles_x, int ntiles, int wstride, float* __restrict__ partial,
     float* __restrict__ grad, Overflow* ovf, unsigned* __restrict__ oidx, float* __restrict__ oval) {
     __shared__ float sA[WMAXH * WMAXW];   // depth of frame k over the window
     __shared__ float sB[SBH * SBW];       // depth of frame j over T + halo
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(kBlock) void loss_owner_kernel(
     const int X0 = txi * TW, Y0 = tyi * TH;
     const PairCam& cj = cams[b * 2 + j];  // direction j: ref = frame j, tgt = frame k
     const PairCam& ck = cams[b * 2 + k];  // direction k: ref = frame k, tgt = frame j
-    const TileWin win = expand_win(wins[(size_t)(b * 2 + j) * ntiles + tile], EXPAND_V2, W, H);
-    const TileWin* __restrict__ wins_k = wins + (size_t)(b * 2 + k) * ntiles;
+    const TileWin win = expand_win(wins[(size_t)b * wstride + (size_t)j * ntiles + tile], EXPAND_V2, W, H);
+    const TileWin* __restrict__ wins_k = wins + (size_t)b * wstride + (size_t)k * ntiles;
     const float* __restrict__ v_j = depth + (size_t)(b * 2 + j) * HW;
     const float* __restrict__ v_k = depth + (size_t)(b * 2 + k) * HW;
     const float* __restrict__ fl_j = (j == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void overflow_apply_kernel(Overflow* ovf, c
                                                                 const float* __restrict__ oval,
                                                                 float* __restrict__ grad) {
     const int count = ovf->count, cap = ovf->cap;
-    if (count > cap) {  // list overflowed: nothing here can be trusted; ask the v1 path to redo the gradient
+    if (count > cap || ovf->degenerate) {  // list overflowed (or the sweep met a degenerate depth): ask the v1 path to redo the gradient
         if (blockIdx.x == 0 && threadIdx.x == 0) ovf->fallback = 1;
         return;
     }
@@ -288,26 +288,29 @@ namespace cd {
 
 int owner_tiles_x(int W) { return (W + TW - 1) / TW; }
 int owner_ntiles(int H, int W) { return owner_tiles_x(W) * ((H + TH - 1) / TH); }
-size_t owner_windows_bytes(int B, int H, int W) { return sizeof(TileWin) * (size_t)B * 2 * owner_ntiles(H, W); }
+// the blob the callers cache per pair: one record per pair = tile windows [+ the row-sweep plan, loss_sweep.hip]
+size_t owner_windows_bytes(int B, int H, int W) { return (size_t)B * pair_record_bytes(H, W); }
 
 int launch_tile_windows(const float* ff, const float* fb, const float* mf, const float* mb, int B, int H, int W,
                         void* wins, hipStream_t s) {
     const int tx = owner_tiles_x(W), nt = owner_ntiles(H, W);
-    hipLaunchKernelGGL(tile_window_kernel, dim3(nt, 2, B), dim3(kBlock), 0, s, ff, fb, mf, mb, H, W, tx, nt, (TileWin*)wins);
-    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+    const int wstride = (int)(pair_record_bytes(H, W) / sizeof(TileWin));
+    hipLaunchKernelGGL(tile_window_kernel, dim3(nt, 2, B), dim3(kBlock), 0, s, ff, fb, mf, mb, H, W, tx, nt, wstride, (TileWin*)wins);
+    if (hipGetLastError() != hipSuccess) return CD_ERR_LAUNCH;
+    return launch_sweep_plan(ff, fb, mf, mb, B, H, W, wins, s);
 }
 
 template <int MODE>
 static void launch_owner_mode(bool reproj, dim3 grid, hipStream_t s, const float* depth, const float* ff,
                               const float* fb, const float* mf, const float* mb, const PairCam* cams,
-                              const TileWin* wins, int H, int W, int tx, int nt, float* partial, float* grad,
+                              const TileWin* wins, int H, int W, int tx, int nt, int wstride, float* partial, float* grad,
                               Overflow* ovf, unsigned* oidx, float* oval) {
     if (reproj)
         hipLaunchKernelGGL((loss_owner_kernel<MODE, true>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins,
-                           H, W, tx, nt, partial, grad, ovf, oidx, oval);
+                           H, W, tx, nt, wstride, partial, grad, ovf, oidx, oval);
     else
         hipLaunchKernelGGL((loss_owner_kernel<MODE, false>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins,
-                           H, W, tx, nt, partial, grad, ovf, oidx, oval);
+                           H, W, tx, nt, wstride, partial, grad, ovf, oidx, oval);
 }
 
 // Enqueues: [overflow header reset] owner kernel, overflow apply.  `ovf_mem` holds the Overflow header
@@ -317,6 +320,7 @@ int launch_owner(const float* depth, const float* ff, const float* fb, const flo
                  float* grad, void* ovf_mem, int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t),
                  void (*after_main)(hipStream_t)) {
     const int tx = owner_tiles_x(W), nt = owner_ntiles(H, W);
+    const int wstride = (int)(pair_record_bytes(H, W) / sizeof(TileWin));
     Overflow* ovf = (Overflow*)ovf_mem;
     unsigned* oidx = (unsigned*)((char*)ovf_mem + 256);
     float* oval = (float*)(oidx + ovf_cap);
@@ -327,11 +331,11 @@ int launch_owner(const float* depth, const float* ff, const float* fb, const flo
     const dim3 grid(nt, 2, B);
     if (before_main) before_main(s);
     if (mode == CD_DEPTH_EXP)
-        launch_owner_mode<CD_DEPTH_EXP>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, ovf, oidx, oval);
+        launch_owner_mode<CD_DEPTH_EXP>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, wstride, partial, grad, ovf, oidx, oval);
     else if (mode == CD_DEPTH_RECIPROCAL)
-        launch_owner_mode<CD_DEPTH_RECIPROCAL>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, ovf, oidx, oval);
+        launch_owner_mode<CD_DEPTH_RECIPROCAL>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, wstride, partial, grad, ovf, oidx, oval);
     else
-        launch_owner_mode<CD_DEPTH_IDENTITY>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, ovf, oidx, oval);
+        launch_owner_mode<CD_DEPTH_IDENTITY>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, wstride, partial, grad, ovf, oidx, oval);
     if (after_main) after_main(s);
     if (hipGetLastError() != hipSuccess) return CD_ERR_LAUNCH;
     hipLaunchKernelGGL(overflow_apply_kernel, dim3(64), dim3(kBlock), 0, s, ovf, oidx, oval, grad);

@@ -40,7 +40,7 @@ template <int MODE, bool REPROJ>
 __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     const float* __restrict__ depth, const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd,
     const float* __restrict__ mask_fwd, const float* __restrict__ mask_bwd, const PairCam* __restrict__ cams,
-    const TileWin* __restrict__ wins, int H, int W, int tiles_x, int ntiles, float* __restrict__ partial,
+    const TileWin* __restrict__ wins, int H, int W, int tiles_x, int ntiles, int wstride, float* __restrict__ partial,
     float* __restrict__ grad, float* __restrict__ slabs, Overflow* ovf, unsigned* __restrict__ oidx,
     float* __restrict__ oval, int b0) {
     __shared__ float sA[V3W * V3W];                     // depth of frame k over the window
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int X0 = txi * TW, Y0 = tyi * TH;
     const PairCam& cj = cams[b * 2 + j];
-    const TileWin win = crop_win(wins[(size_t)(b * 2 + j) * ntiles + tile]);
+    const TileWin win = crop_win(wins[(size_t)b * wstride + (size_t)j * ntiles + tile]);
     const float* __restrict__ v_j = depth + (size_t)(b * 2 + j) * HW;
     const float* __restrict__ v_k = depth + (size_t)(b * 2 + k) * HW;
     const float* __restrict__ fl_j = (j == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
@@ -195,14 +195,14 @@ __global__ __launch_bounds__(kBlock) void loss_source_kernel(
 // distinct elements of the LDS tile accumulator.
 __global__ __launch_bounds__(kBlock) void loss_gather_kernel(const TileWin* __restrict__ wins,
                                                              const float* __restrict__ slabs, int H, int W,
-                                                             int tiles_x, int ntiles, float* __restrict__ grad, int b0) {
+                                                             int tiles_x, int ntiles, int wstride, float* __restrict__ grad, int b0) {
     __shared__ float sAcc[TH * TW];
     __shared__ unsigned sBits[MAXT_LDS / 32];
     __shared__ TileWin sWin[MAXT_LDS];
     const int k = blockIdx.y, b = b0 + blockIdx.z, tile = blockIdx.x, j = 1 - k;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int X0 = txi * TW, Y0 = tyi * TH, X1 = min(X0 + TW, W), Y1 = min(Y0 + TH, H);
-    const TileWin* __restrict__ wj = wins + (size_t)(b * 2 + j) * ntiles;
+    const TileWin* __restrict__ wj = wins + (size_t)b * wstride + (size_t)j * ntiles;
     const float* __restrict__ sl = slabs + (size_t)(blockIdx.z * 2 + j) * ntiles * SLAB_STRIDE;
     for (int i = threadIdx.x; i < TH * TW; i += kBlock) sAcc[i] = 0.f;
     if (threadIdx.x < MAXT_LDS / 32) sBits[threadIdx.x] = 0u;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void loss_gather_kernel(const TileWin* __re
 // adds its float4 of each listed slab that covers it: no barriers in the accumulation, fixed order of summation.
 __global__ __launch_bounds__(kBlock) void loss_gather4_kernel(const TileWin* __restrict__ wins,
                                                               const float* __restrict__ slabs, int H, int W,
-                                                              int tiles_x, int ntiles, float* __restrict__ grad, int b0) {
+                                                              int tiles_x, int ntiles, int wstride, float* __restrict__ grad, int b0) {
     static_assert(kBlock == TH * TW / 4, "one float4 per thread");
     __shared__ unsigned sBits[MAXT_LDS / 32];
     __shared__ int4 sEnt[MAXT_LDS];   // y0, h, xa0, padded width of the overlapping slabs, in increasing s
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void loss_gather4_kernel(const TileWin* __r
     const int k = blockIdx.y, b = b0 + blockIdx.z, tile = blockIdx.x, j = 1 - k;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int X0 = txi * TW, Y0 = tyi * TH, X1 = min(X0 + TW, W), Y1 = min(Y0 + TH, H);
-    const TileWin* __restrict__ wj = wins + (size_t)(b * 2 + j) * ntiles;
+    const TileWin* __restrict__ wj = wins + (size_t)b * wstride + (size_t)j * ntiles;
     const float* __restrict__ sl = slabs + (size_t)(blockIdx.z * 2 + j) * ntiles * SLAB_STRIDE;
     if (threadIdx.x < MAXT_LDS / 32) sBits[threadIdx.x] = 0u;
     __syncthreads();
@@ -318,14 +318,14 @@ size_t slab_floats(int B, int H, int W) {
 template <int MODE>
 static void launch_source_mode(bool reproj, dim3 grid, hipStream_t s, const float* depth, const float* ff,
                                const float* fb, const float* mf, const float* mb, const PairCam* cams,
-                               const TileWin* wins, int H, int W, int tx, int nt, float* partial, float* grad,
+                               const TileWin* wins, int H, int W, int tx, int nt, int wstride, float* partial, float* grad,
                                float* slabs, Overflow* ovf, unsigned* oidx, float* oval, int b0) {
     if (reproj)
         hipLaunchKernelGGL((loss_source_kernel<MODE, true>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins, H, W,
-                           tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+                           tx, nt, wstride, partial, grad, slabs, ovf, oidx, oval, b0);
     else
         hipLaunchKernelGGL((loss_source_kernel<MODE, false>), grid, dim3(kBlock), 0, s, depth, ff, fb, mf, mb, cams, wins, H, W,
-                           tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+                           tx, nt, wstride, partial, grad, slabs, ovf, oidx, oval, b0);
 }
 
 // Enqueues: overflow header reset, [before_main] source pass, gather pass [after_main], overflow apply.
@@ -334,6 +334,7 @@ int launch_slab(const float* depth, const float* ff, const float* fb, const floa
                 float* grad, float* slabs, void* ovf_mem, int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t),
                 void (*after_main)(hipStream_t)) {
     const int tx = owner_tiles_x(W), nt = owner_ntiles(H, W);
+    const int wstride = (int)(pair_record_bytes(H, W) / sizeof(TileWin));
     Overflow* ovf = (Overflow*)ovf_mem;
     unsigned* oidx = (unsigned*)((char*)ovf_mem + 256);
     float* oval = (float*)(oidx + ovf_cap);
@@ -346,15 +347,15 @@ int launch_slab(const float* depth, const float* ff, const float* fb, const floa
     for (int b0 = 0; b0 < B; b0 += ch) {
         const dim3 grid(nt, 2, min(ch, B - b0));
         if (mode == CD_DEPTH_EXP)
-            launch_source_mode<CD_DEPTH_EXP>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+            launch_source_mode<CD_DEPTH_EXP>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, wstride, partial, grad, slabs, ovf, oidx, oval, b0);
         else if (mode == CD_DEPTH_RECIPROCAL)
-            launch_source_mode<CD_DEPTH_RECIPROCAL>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+            launch_source_mode<CD_DEPTH_RECIPROCAL>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, wstride, partial, grad, slabs, ovf, oidx, oval, b0);
         else
-            launch_source_mode<CD_DEPTH_IDENTITY>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, partial, grad, slabs, ovf, oidx, oval, b0);
+            launch_source_mode<CD_DEPTH_IDENTITY>(reproj, grid, s, depth, ff, fb, mf, mb, (const PairCam*)cams, (const TileWin*)wins, H, W, tx, nt, wstride, partial, grad, slabs, ovf, oidx, oval, b0);
         if (W % 4 == 0 && nt <= MAXT_LDS && reinterpret_cast<uintptr_t>(grad) % 16 == 0)
-            hipLaunchKernelGGL(loss_gather4_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, grad, b0);
+            hipLaunchKernelGGL(loss_gather4_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, wstride, grad, b0);
         else
-            hipLaunchKernelGGL(loss_gather_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, grad, b0);
+            hipLaunchKernelGGL(loss_gather_kernel, grid, dim3(kBlock), 0, s, (const TileWin*)wins, slabs, H, W, tx, nt, wstride, grad, b0);
     }
     if (after_main) after_main(s);
     if (hipGetLastError() != hipSuccess) return CD_ERR_LAUNCH;

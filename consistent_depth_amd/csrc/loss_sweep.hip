@@ -1,0 +1,268 @@
+// Fused geometric-consistency loss, v4: the ROW SWEEP -- one workgroup per frame pair, every input byte read once,
+// every gradient byte written once, scatter through 64-bit integer LDS atomics into sliding row rings.
+// Design, plan and the per-thread phase functions: loss_sweep_core.h (shared with the host emulation of the CPU tests).
+//
+// Replaces (reference, /root/reference): loss/consistency_loss.py:98-253 + the utils/geometry.py chain :9-128,201-208 and
+// the autograd backward of all of it -- for batches large enough to give every CU a pair (bench.py's roofline launch,
+// validation-sized batches); small batches (the B = 4 training step) stay on the tile kernels of loss_slab.hip, which
+// have 2 * B * tiles workgroups to spread.
+#include "loss_tiles.h"
+#include "loss_sweep_core.h"
+
+namespace cd {
+
+using namespace sweep;
+
+static int g_sweep_pxt = 0;   // cd_debug_set_loss_sweep: pixels per thread (0 = rule below)
+
+int sweep_pxt(int H, int W) {
+    if (g_sweep_pxt > 0) return g_sweep_pxt;
+    (void)H;
+    // two columns per thread fill 7/8 of the 512 lanes of a frame at W = 224 and keep G (rows per item) small, which
+    // leaves the ring's rows to the flow's vertical spread
+    return W <= 512 ? 2 : 4;
+}
+void set_sweep_pxt(int pxt) { g_sweep_pxt = pxt > 0 && pxt <= kMaxPXT ? pxt : 0; }
+
+Geo sweep_geo(int H, int W) { return make_geo(H, W, sweep_pxt(H, W)); }
+
+// per-pair record of the "tile windows" blob: [TileWin wins[2 * ntiles]] [PlanHeader + Item[max_items]] (16-byte aligned parts)
+size_t pair_record_bytes(int H, int W) {
+    const size_t wins = align_up(sizeof(TileWin) * 2 * (size_t)owner_ntiles(H, W), 16);
+    const Geo g = sweep_geo(H, W);
+    return wins + (g.ok && g.max_items <= 2560 ? align_up(plan_bytes(g), 16) : 0);
+}
+static size_t plan_offset(int H, int W) { return align_up(sizeof(TileWin) * 2 * (size_t)owner_ntiles(H, W), 16); }
+
+// ---------------------------------------------------------------- plan (dataset constant: flows and masks only)
+constexpr int kPlanItemsLds = 2560;   // Item scratch of the planner (8 B each); plans longer than this are not made (-> v3)
+
+__global__ __launch_bounds__(kBlock) void sweep_plan_kernel(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd,
+                                                            const float* __restrict__ mask_fwd, const float* __restrict__ mask_bwd,
+                                                            const Geo g, char* __restrict__ blob, size_t stride, size_t plan_off) {
+    __shared__ int lo_i[2 * kMaxGroups], hi_i[2 * kMaxGroups];
+    __shared__ short lo_s[2 * kMaxGroups], hi_s[2 * kMaxGroups], suf[2 * (kMaxGroups + 1)];
+    __shared__ Item items[kPlanItemsLds];
+    const int b = blockIdx.x, HW = g.H * g.W, NG = g.NG;
+    for (int i = threadIdx.x; i < 2 * NG; i += kBlock) { lo_i[i] = kNoRow; hi_i[i] = -1; }
+    __syncthreads();
+    for (int f = 0; f < 2; ++f) {
+        const float* fl = (f == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
+        const float* mk = (f == 0 ? mask_fwd : mask_bwd) + (size_t)b * HW;
+        for (int p = threadIdx.x; p < HW; p += kBlock) {
+            if (mk[p] != 0.f) {
+                const int y = p / g.W, x = p - y * g.W;
+                int ya, yb;
+                tap_rows((float)x, (float)y, fl[p], fl[HW + p], g.W, g.H, &ya, &yb);
+                atomicMin(&lo_i[f * NG + y / g.G], ya);
+                atomicMax(&hi_i[f * NG + y / g.G], yb);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NG; i += kBlock) { lo_s[i] = (short)lo_i[i]; hi_s[i] = (short)hi_i[i]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PlanHeader* ph = reinterpret_cast<PlanHeader*>(blob + (size_t)b * stride + plan_off);
+        const int n = plan_items(g, lo_s, hi_s, suf, items);
+        if (n > 0) expand_plan(g, items, n, reinterpret_cast<PlanItem*>(ph + 1));
+        ph->n_items = n; ph->G = g.G; ph->R = g.R; ph->PXT = g.PXT;
+    }
+}
+
+int launch_sweep_plan(const float* ff, const float* fb, const float* mf, const float* mb, int B, int H, int W, void* blob,
+                      hipStream_t s) {
+    const Geo g = sweep_geo(H, W);
+    if (!g.ok || g.max_items > kPlanItemsLds) return CD_OK;
+    hipLaunchKernelGGL(sweep_plan_kernel, dim3(B), dim3(kBlock), 0, s, ff, fb, mf, mb, g, (char*)blob, pair_record_bytes(H, W),
+                       plan_offset(H, W));
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- the sweep
+struct DevEnv {
+    Overflow* ovf; unsigned* oidx; float* oval;
+    __device__ __forceinline__ static void add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }   // ds_add_u64, no return
+    __device__ __forceinline__ static bool any(bool x) { return __any(x) != 0; }
+    __device__ __forceinline__ void push(bool need, unsigned idx, float v) { ovf_push(need, ovf, oidx, oval, idx, v); }
+    __device__ __forceinline__ void degenerate() { ovf->degenerate = 1; }
+};
+
+struct SweepShape { Geo g; size_t stride, plan_off; };
+
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+template <int MODE, bool REPROJ, int PXT>
+__global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
+    const float* __restrict__ depth, const float* __restrict__ ff, const float* __restrict__ fb, const float* __restrict__ mf,
+    const float* __restrict__ mb, const PairCam* __restrict__ cams, const char* __restrict__ blob, float* __restrict__ partial,
+    float* __restrict__ grad, Overflow* ovf, unsigned* __restrict__ oidx, float* __restrict__ oval, const SweepShape sh) {
+    extern __shared__ __align__(16) unsigned long long smem[];
+    const Geo g = sh.g;
+    const int b = blockIdx.x, HW = g.H * g.W, ring = g.R * g.RW;
+    const int f = uni((int)(threadIdx.x / kFrameThreads)), k = 1 - f;   // whole waves serve one frame: everything derived from f is scalar
+    View v;
+    v.H = g.H; v.W = g.W; v.R = g.R; v.RW = g.RW; v.RP = g.RP; v.G = g.G; v.CG = g.CG; v.HW = (unsigned)HW;
+    const float* dpair = depth + (size_t)b * 2 * HW;
+    v.vj = dpair + (f ? HW : 0); v.vk = dpair + (f ? 0 : HW);
+    v.flj = (f ? fb : ff) + (size_t)b * 2 * HW;
+    v.mkj = (f ? mb : mf) + (size_t)b * HW;
+    v.gradj = grad + (size_t)b * 2 * HW + (f ? HW : 0);
+    float* D0 = reinterpret_cast<float*>(smem + 2 * ring);
+    v.Aj = smem + (f ? ring : 0); v.Ak = smem + (f ? 0 : ring);
+    v.Dj = D0 + (f ? ring : 0); v.Dk = D0 + (f ? 0 : ring);
+    float* red = D0 + 2 * ring;
+    {   // the direction's constants, once, into scalar registers
+        const PairCam& pc = cams[b * 2 + f];
+        Cam c = make_cam(pc);
+        float* cf = reinterpret_cast<float*>(&c);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(Cam) / sizeof(float)); ++i) cf[i] = uni(cf[i]);
+        v.cj = c;
+        v.unit_k_s = uni(cams[b * 2 + k].unit) * (1.f / SWEEP_FX_ONE_F);
+    }
+    v.gbj = (unsigned)b * 2u * (unsigned)HW + (f ? (unsigned)HW : 0u);
+    v.gbk = (unsigned)b * 2u * (unsigned)HW + (f ? 0u : (unsigned)HW);
+    const PlanHeader* ph = reinterpret_cast<const PlanHeader*>(blob + (size_t)b * sh.stride + sh.plan_off);
+    const PlanItem* __restrict__ items = reinterpret_cast<const PlanItem*>(ph + 1);
+    const int n_items = ph->n_items;
+    if (n_items <= 0 || ph->G != g.G || ph->R != g.R || ph->PXT != g.PXT) {
+        // no plan, or one made for another geometry (cannot happen through the C ABI): fail loudly -- NaN loss, which skips the step
+        if ((threadIdx.x & (kFrameThreads - 1)) == 0) {
+            float* o = partial + (size_t)(b * 2 + f) * 2;
+            o[0] = o[1] = __int_as_float(0x7fc00000);
+        }
+        return;
+    }
+    DevEnv env{ovf, oidx, oval};
+    const Lane<PXT> l = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);
+    Regs<PXT> r;
+    init_regs<PXT>(r);
+    for (int i = threadIdx.x; i < 2 * ring; i += kThreads) smem[i] = 0ull;
+    const int init_hi = init_stage_hi(g);
+    for (int lo = 0; lo < init_hi; lo += kStagePasses * g.RP) {     // prologue: the initial window [0, R)
+        const int hi = min(lo + kStagePasses * g.RP, init_hi);
+        float sv[kStagePasses][PXT];
+        load_stage<PXT>(v, l, lo, hi, sv);
+        r.bad = !stage_rows<MODE, PXT>(v, l, lo, hi, 0, 0, sv) || r.bad;
+    }
+    // One barrier per item.  During item t three things run side by side, on disjoint ring rows by construction of the plan:
+    //   rows [fl_lo, fl_hi) -- which no source of item t or later touches -- leave ring j (accumulator -> gradient row),
+    //   rows [s_lo, s_hi) enter ring j in the slots just vacated (their depth was loaded during item t - 1),
+    //   the source rows of item t are evaluated against rows staged BEFORE item t (Rec::nv).
+    // Software pipeline: the depth rows entering at item t + 1 are loaded during item t (r.sv is free once item t's rows are
+    // staged); the flow / mask of item t + 1's sources go into a second register set when the pixel count allows it (DB),
+    // else they are loaded at the top of their own item, covered by its flush / stage work.
+    constexpr bool DB = PXT <= 2;
+    Rec me = items[0].f[f];
+    int wk = items[0].f[k].w, wsk = items[0].f[k].ws, nvk = items[0].f[k].nv;
+    if (DB) load_inputs<PXT>(v, l, me.p, r.fx, r.fy, r.m);
+    __syncthreads();
+    for (int it = 0; it < n_items; ++it) {
+        if (!DB) load_inputs<PXT>(v, l, me.p, r.fx, r.fy, r.m);
+        r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, me.w, me.ws, r.sv) || r.bad;
+        const bool more = it + 1 < n_items;
+        const int nt = more ? it + 1 : it;
+        const Rec nx = items[nt].f[f];
+        const int nwk = items[nt].f[k].w, nwsk = items[nt].f[k].ws, nnvk = items[nt].f[k].nv;
+        load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
+        float nfx[DB ? PXT : 1], nfy[DB ? PXT : 1], nm[DB ? PXT : 1];
+        if (DB) load_inputs<PXT>(v, l, more ? nx.p : -1, nfx, nfy, nm);
+        flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi, me.fl_slot);
+        process_rows<MODE, REPROJ, PXT>(v, env, r, l, me.p, me.w, me.ws, wk, wsk, nvk);
+        __syncthreads();
+        if (DB) {
+#pragma unroll
+            for (int i = 0; i < PXT; ++i) { r.fx[i] = nfx[i]; r.fy[i] = nfy[i]; r.m[i] = nm[i]; }
+        }
+        me = nx; wk = nwk; wsk = nwsk; nvk = nnvk;
+    }
+    if (env.any(r.bad) && (threadIdx.x & (kWave - 1)) == 0) env.degenerate();
+    // loss partial sums: one (reprojection, disparity) pair per (pair, direction)
+    float ar = wave_sum((float)r.acc_r), ad = wave_sum((float)r.acc_d);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    if (lane == 0) { red[wid * 2] = ar; red[wid * 2 + 1] = ad; }
+    __syncthreads();
+    if ((threadIdx.x & (kFrameThreads - 1)) == 0) {
+        const int w0 = f * (kFrameThreads / kWave);
+        float sr = 0.f, sd = 0.f;
+        for (int i = 0; i < kFrameThreads / kWave; ++i) { sr += red[(w0 + i) * 2]; sd += red[(w0 + i) * 2 + 1]; }
+        float* o = partial + (size_t)(b * 2 + f) * 2;
+        o[0] = sr; o[1] = sd;
+    }
+}
+
+struct SweepArgs {
+    const float* depth; const float* ff; const float* fb; const float* mf; const float* mb;
+    const PairCam* cams; const char* blob; float* partial; float* grad; Overflow* ovf; unsigned* oidx; float* oval;
+    SweepShape sh;
+};
+
+template <int MODE, bool REPROJ, int PXT>
+static int launch_sweep_inst(const SweepArgs& a, int B, size_t lds, hipStream_t s) {
+    static bool configured = false;   // raise the dynamic-LDS limit of this instantiation once
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_sweep_kernel<MODE, REPROJ, PXT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess)
+            return CD_ERR_LAUNCH;
+        configured = true;
+    }
+    hipLaunchKernelGGL((loss_sweep_kernel<MODE, REPROJ, PXT>), dim3(B), dim3(kThreads), lds, s, a.depth, a.ff, a.fb, a.mf, a.mb,
+                       a.cams, a.blob, a.partial, a.grad, a.ovf, a.oidx, a.oval, a.sh);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+template <int MODE, bool REPROJ>
+static int launch_sweep_pxt(const SweepArgs& a, int B, size_t lds, hipStream_t s) {
+    switch (a.sh.g.PXT) {
+        case 1: return launch_sweep_inst<MODE, REPROJ, 1>(a, B, lds, s);
+        case 2: return launch_sweep_inst<MODE, REPROJ, 2>(a, B, lds, s);
+        case 4: return launch_sweep_inst<MODE, REPROJ, 4>(a, B, lds, s);
+    }
+    return CD_ERR_UNSUPPORTED;
+}
+
+template <int MODE>
+static int launch_sweep_mode(bool reproj, const SweepArgs& a, int B, size_t lds, hipStream_t s) {
+    return reproj ? launch_sweep_pxt<MODE, true>(a, B, lds, s) : launch_sweep_pxt<MODE, false>(a, B, lds, s);
+}
+
+bool sweep_supported(int H, int W) {
+    const Geo g = sweep_geo(H, W);
+    return g.ok != 0 && g.max_items <= kPlanItemsLds;
+}
+
+// The rule of the default dispatch (loss_api.hip): the sweep needs a pair per CU to fill the chip and a ring tall enough for
+// the flow's vertical spread (R = 30 rows at W = 224; 17 at W = 384: the tile kernels keep those).
+bool sweep_preferred(int B, int H, int W) {
+    const Geo g = sweep_geo(H, W);
+    return sweep_supported(H, W) && g.R >= 24 && B >= 96;
+}
+
+// Enqueues: overflow header reset, [before_main] sweep [after_main], overflow apply.  Partial sums: partial[(b*2+k)*2 + {0,1}].
+int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, const void* cams,
+                 const void* blob, int mode, bool reproj, int B, int H, int W, float* partial, float* grad, void* ovf_mem,
+                 int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t)) {
+    const Geo g = sweep_geo(H, W);
+    if (!sweep_supported(H, W)) return CD_ERR_UNSUPPORTED;
+    Overflow* ovf = (Overflow*)ovf_mem;
+    unsigned* oidx = (unsigned*)((char*)ovf_mem + 256);
+    float* oval = (float*)(oidx + ovf_cap);
+    if (hipMemsetAsync(ovf, 0, sizeof(Overflow), s) != hipSuccess) return CD_ERR_LAUNCH;
+    if (hipMemsetD32Async((hipDeviceptr_t)&ovf->cap, ovf_cap, 1, s) != hipSuccess) return CD_ERR_LAUNCH;
+    SweepArgs prm{depth, ff, fb, mf, mb, (const PairCam*)cams, (const char*)blob, partial, grad, ovf, oidx, oval,
+                  SweepShape{g, pair_record_bytes(H, W), plan_offset(H, W)}};
+    const size_t lds = ring_lds_bytes(g);
+    if (before_main) before_main(s);
+    int rc;
+    if (mode == CD_DEPTH_EXP) rc = launch_sweep_mode<CD_DEPTH_EXP>(reproj, prm, B, lds, s);
+    else if (mode == CD_DEPTH_RECIPROCAL) rc = launch_sweep_mode<CD_DEPTH_RECIPROCAL>(reproj, prm, B, lds, s);
+    else rc = launch_sweep_mode<CD_DEPTH_IDENTITY>(reproj, prm, B, lds, s);
+    if (after_main) after_main(s);
+    if (rc != CD_OK) return rc;
+    launch_overflow_apply(ovf_mem, ovf_cap, grad, s);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+}  // namespace cd

@@ -1,0 +1,540 @@
+// Row-sweep formulation (v4) of the fused geometric-consistency loss + gradient: geometry, the per-pair schedule
+// ("plan") and the per-thread phase functions.  Host/device neutral: hipcc compiles it into loss_sweep.hip, g++ into
+// tests/emul (sequential execution of the same phase functions -- checks plans, ring indexing and flush logic on the
+// CPU; never part of the product path).
+//
+// Why a sweep.  The gradient has a SCATTER part: source pixel (j, y, x) adds to the 4 bilinear taps of frame k = 1 - j
+// at (y + flow_y, x + flow_x).  v1 scatters with global atomics (memory-side on MI355X: 4 % of the HBM roofline), v2/v3
+// give every 32x32 tile a workgroup and pay for the tile halos with re-evaluation (v2, 2.07x) or with slabs written to
+// and re-read from memory by a second pass (v3, 1.6-2.6x the algorithmic traffic, 22 % of the roofline).  Here ONE
+// workgroup owns ONE pair and walks both frames top to bottom in lock step, a few rows per step ("item"):
+//
+//   * each frame has a RING of R image rows in LDS: depth (fp32, head already applied) and a 64-bit fixed-point
+//     gradient accumulator.  Ring f is the sampling source AND the scatter target of the sources of frame 1-f, and it
+//     also receives the direct gradient term of frame f's own sources;
+//   * per item: rows that no later source can touch leave the ring (accumulator -> float -> ONE coalesced store of
+//     the finished gradient row), new rows enter (depth loaded ONCE, exp/reciprocal applied once), then the
+//     G source rows of each frame are evaluated: 5 LDS reads and 5 ds_add_u64 per pixel, no global atomics;
+//   * every input byte is read once and every gradient byte written once: HBM traffic = the algorithmic 10*H*W*4 bytes
+//     per pair, in row order (fully coalesced);
+//   * the two frames need not advance at the same rate: a per-pair PLAN (dataset constant, like the tile windows: it
+//     depends only on flows and masks) lists, per item, which row group of which frame is processed and where the two
+//     ring windows start, so that the taps of the valid sources fall inside the rings (global vertical offsets between
+//     the frames, zoom, slow drifts are absorbed by the schedule; only the vertical SPREAD inside one item must fit);
+//   * anything that does not fit (wild flow, |value| beyond the fixed-point range, NaN/inf) goes through the same
+//     overflow list + guarded v1 fallback as v2/v3: exact for ANY input, fast for consistent flow.
+//
+// Integer accumulation is order independent: the gradient is bit-reproducible run to run.
+#pragma once
+#include "loss_math.h"
+
+namespace cd {
+namespace sweep {
+
+constexpr int kThreads = 1024;       // one workgroup per pair = 16 waves = one CU at 4 waves per SIMD
+constexpr int kFrameThreads = 512;   // threads [0, 512) serve frame 0, [512, 1024) frame 1 (whole waves per frame)
+constexpr int kStagePasses = 2;      // at most SMAX = kStagePasses * RP rows enter / leave a ring per item
+constexpr int kMaxGroups = 1024;     // row groups per frame the planner handles
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kLdsReserve = 1024;    // reduction scratch etc.
+constexpr int kMaxPXT = 4;
+
+struct Geo {
+    int H, W;
+    int PXT;        // pixels per thread: columns cg + i * CG, i < PXT (adjacent lanes = adjacent columns: conflict-free LDS, coalesced HBM)
+    int CG;         // column groups = ceil(W / PXT)
+    int RP;         // image rows per pass of the 512 threads of a frame = kFrameThreads / CG
+    int G;          // source rows per item and frame (<= RP)
+    int RW;         // ring row stride in elements: W + 1 pad column (weight-0 taps land there), rounded up to even
+    int R;          // ring rows per frame
+    int NG;         // row groups per frame = ceil(H / G)
+    int SMAX;       // max ring-window advance per item
+    int max_items;  // capacity of a plan
+    int ok;         // this geometry is supported by the sweep kernel (else: v3)
+};
+
+CD_HD Geo make_geo(int H, int W, int pxt) {
+    Geo g;
+    memset(&g, 0, sizeof(g));
+    g.H = H; g.W = W; g.PXT = pxt;
+    if (H < 2 || W < 2 || H > 16384 || pxt < 1 || pxt > kMaxPXT) return g;
+    g.CG = (W + pxt - 1) / pxt;
+    if (g.CG > kFrameThreads) return g;
+    g.RP = kFrameThreads / g.CG;
+    if (g.RP > 16) g.RP = 16;
+    g.RW = (W + 2) & ~1;
+    int R = (kLdsBytes - kLdsReserve) / (2 * g.RW * 12);
+    if (R > H + 2) R = H + 2;                 // rows 0 .. H (H = the pad row under the image) never need more
+    if (R > 512) R = 512;
+    g.R = R;
+    if (R < 12) return g;
+    g.G = g.RP < (R - 8) / 3 ? g.RP : (R - 8) / 3;    // small images: fewer source rows per item than the threads could take
+    if (g.G < 1) return g;
+    g.SMAX = kStagePasses * g.RP;
+    if (g.SMAX > R - g.G - 8) g.SMAX = R - g.G - 8;   // leave room for the taps' spread
+    g.NG = (H + g.G - 1) / g.G;
+    if (g.SMAX < g.G || g.NG > kMaxGroups) return g;  // windows must be able to follow the sources: else v3
+    g.max_items = 4 * g.NG + 3 * ((H + 1 + R) / g.SMAX + 2) + 8;   // groups (+ a forced slide each, worst case) + window-only items
+    g.ok = 1;
+    return g;
+}
+
+CD_HD size_t ring_lds_bytes(const Geo& g) { return (size_t)2 * g.R * g.RW * 12 + kLdsReserve; }
+
+// ---------------------------------------------------------------- plan
+struct Item {
+    short p[2];   // first source row of frame f processed in this item (-1: none)
+    short w[2];   // first image row held by ring f during this item (rows [w, w + R))
+};
+
+constexpr short kNoRow = 32767;
+
+// lo / hi: [2][NG] first / last ring row (of frame 1-f) touched by the taps of the VALID sources of each row group of
+// frame f (lo = kNoRow, hi = -1: no valid source).  suf: scratch [2][NG + 1].  Returns the number of items (<= max_items)
+// or -1.  Guarantees (checked by tests/test_sweep_plan_cpu.py):
+//   * every row group of both frames is processed exactly once, in increasing order;
+//   * windows never move back and advance by at most SMAX rows per item;
+//   * the G source rows of a processed group lie inside their own frame's window AND below the previous item's window top
+//     (own depth and the direct term live in the ring; rows entering during an item are not used by it);  the taps lie
+//     inside the other ring, below its previous top, whenever the flow allows it (otherwise: overflow path);
+//   * the last items move both windows to H, i.e. every gradient row has left the rings.
+CD_HD int plan_items(const Geo& g, const short* lo, const short* hi, short* suf, Item* items) {
+    const int NG = g.NG, G = g.G, R = g.R, H = g.H, SMAX = g.SMAX;
+    for (int f = 0; f < 2; ++f) {
+        suf[f * (NG + 1) + NG] = kNoRow;
+        for (int i = NG - 1; i >= 0; --i) {
+            const short a = lo[f * NG + i], b = suf[f * (NG + 1) + i + 1];
+            suf[f * (NG + 1) + i] = a < b ? a : b;
+        }
+    }
+    int p[2] = {0, 0}, w[2] = {0, 0}, n = 0;
+    while (p[0] < NG || p[1] < NG) {
+        if (n >= g.max_items - 2) return -1;
+        int target[2];
+        bool ready[2] = {false, false};
+        for (int f = 0; f < 2; ++f) {
+            const int k = 1 - f;
+            const int own = p[f] < NG ? p[f] * G : H + 1;                       // next own source row: must stay in ring f
+            const int need = p[k] < NG ? (int)suf[k * (NG + 1) + p[k]] : (int)kNoRow;   // lowest row a later source of k samples
+            int t = own < need ? own : need;
+            if (t > H + 1) t = H + 1;
+            target[f] = w[f] > t ? w[f] : t;
+        }
+        // An item's rows enter and leave the rings WHILE its sources are evaluated (one barrier per item), so a group can only
+        // use rows staged before: rows below the PREVIOUS window's top w[.] + R (and at or above the new bases target[.]).
+        for (int f = 0; f < 2; ++f) {
+            const int k = 1 - f;
+            if (p[f] >= NG) continue;
+            const bool own_fit = p[f] * G + G <= w[f] + R;
+            const bool taps_fit = (int)hi[f * NG + p[f]] < w[k] + R;
+            ready[f] = own_fit && taps_fit;
+        }
+        bool slide_only = false;
+        if (!ready[0] && !ready[1]) {
+            if (target[0] > w[0] || target[1] > w[1]) slide_only = true;     // let the windows catch up first
+            else {
+                // windows are stuck and no group fits: force the frame that is further behind.  Its own rows must fit (make
+                // room by dropping the lowest rows of its ring); whatever its taps miss goes through the overflow list.
+                const int f = (p[0] < NG && (p[1] >= NG || p[0] <= p[1])) ? 0 : 1;
+                const int base = p[f] * G + G - R;
+                if (base > w[f]) { target[f] = base; slide_only = true; }
+                else ready[f] = true;
+            }
+        }
+        bool big = false;
+        for (int f = 0; f < 2; ++f) big = big || (target[f] - w[f] > SMAX);
+        if (big || slide_only) {   // slide in steps the staging registers can feed
+            for (int f = 0; f < 2; ++f) w[f] = target[f] < w[f] + SMAX ? target[f] : w[f] + SMAX;
+            Item it; it.p[0] = it.p[1] = -1; it.w[0] = (short)w[0]; it.w[1] = (short)w[1];
+            items[n++] = it;
+            continue;
+        }
+        w[0] = target[0]; w[1] = target[1];
+        Item it;
+        it.p[0] = ready[0] ? (short)(p[0] * G) : (short)-1;
+        it.p[1] = ready[1] ? (short)(p[1] * G) : (short)-1;
+        it.w[0] = (short)w[0]; it.w[1] = (short)w[1];
+        items[n++] = it;
+        if (ready[0]) ++p[0];
+        if (ready[1]) ++p[1];
+    }
+    while (w[0] < H || w[1] < H) {   // tail: the remaining rows leave the rings
+        if (n >= g.max_items) return -1;
+        for (int f = 0; f < 2; ++f) if (w[f] < H) w[f] = H < w[f] + SMAX ? H : w[f] + SMAX;
+        Item it; it.p[0] = it.p[1] = -1; it.w[0] = (short)w[0]; it.w[1] = (short)w[1];
+        items[n++] = it;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------- expanded plan: what the kernel reads
+// One record per item and frame with everything the phases need as plain ints (a wave reads its frame's record with one
+// 32-byte scalar load per item, plus w / ws of the other frame): no window bookkeeping inside the kernel.
+struct Rec {
+    int w, ws;         // first image row held by the ring during this item, and its slot
+    int nv;            // rows [w, w + nv) can be used by this item's sources: staged BEFORE it (= previous window top - w)
+    int p;             // first source row of the group processed in this item (-1: none)
+    int fl_lo, fl_hi;  // rows [fl_lo, fl_hi) leave the ring at the start of this item ...
+    int fl_slot;       // ... fl_lo sits in this slot
+    int s_lo, s_hi;    // rows [s_lo, s_hi) enter the ring during this item (row H = the pad row)
+    int pad[3];
+};
+static_assert(sizeof(Rec) == 48, "Rec layout");
+struct PlanItem { Rec f[2]; };
+struct PlanHeader { int n_items, G, R, PXT; };
+CD_HD size_t plan_bytes(const Geo& g) { return sizeof(PlanHeader) + sizeof(PlanItem) * (size_t)g.max_items; }
+
+CD_HD int wrap_slot(int s, int R) { return s >= R ? s - R : s; }
+CD_HD unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+CD_HD unsigned wrapu(unsigned s, unsigned R) { return umin(s, s - R); }   // s in [0, 2R): s - R wraps to a huge number when s < R
+#if defined(__HIP_DEVICE_COMPILE__)
+CD_HD unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }   // v_mad_u32_u24 (operands < 2^24)
+#else
+CD_HD unsigned mad24(unsigned a, unsigned b, unsigned c) { return a * b + c; }
+#endif
+
+// rows [0, init_hi) are staged by the kernel's prologue (window of item 0 = [0, R))
+CD_HD int init_stage_hi(const Geo& g) { return g.R < g.H + 1 ? g.R : g.H + 1; }
+
+CD_HD void expand_plan(const Geo& g, const Item* items, int n, PlanItem* out) {
+    int wprev[2] = {0, 0}, wsprev[2] = {0, 0}, staged[2];
+    staged[0] = staged[1] = init_stage_hi(g);
+    for (int t = 0; t < n; ++t) {
+        for (int f = 0; f < 2; ++f) {
+            Rec r;
+            r.w = items[t].w[f];
+            r.ws = wrap_slot(wsprev[f] + (r.w - wprev[f]), g.R);
+            r.p = items[t].p[f];
+            r.nv = wprev[f] + g.R - r.w;
+            r.pad[0] = r.pad[1] = r.pad[2] = 0;
+            r.fl_lo = wprev[f];
+            r.fl_hi = r.w < g.H ? r.w : g.H;
+            if (r.fl_hi < r.fl_lo) r.fl_hi = r.fl_lo;
+            r.fl_slot = wsprev[f];
+            r.s_lo = staged[f];
+            const int top = r.w + g.R < g.H + 1 ? r.w + g.R : g.H + 1;
+            r.s_hi = top > r.s_lo ? top : r.s_lo;
+            staged[f] = r.s_hi;
+            wprev[f] = r.w; wsprev[f] = r.ws;
+            out[t].f[f] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- execution state
+struct Cam {   // the fields of PairCam the sweep uses, copied once into registers
+    float M[9], c[3], ifx_r, ify_r, cx_r, cy_r, fx_t, fy_t, cx_t, cy_t, sx, sy;
+    float drs, dbs, scs;   // dr, db, sc of PairCam times 2^34: the algebra produces fixed-point-ready values (exact scaling)
+    float unit_s;          // unit * 2^-34: accumulator integer -> gradient, and pre-scaled value -> gradient (overflow list)
+};
+CD_HD Cam make_cam(const PairCam& p) {
+    Cam c;
+    for (int i = 0; i < 9; ++i) c.M[i] = p.M[i];
+    for (int i = 0; i < 3; ++i) c.c[i] = p.c[i];
+    c.ifx_r = p.ifx_r; c.ify_r = p.ify_r; c.cx_r = p.cx_r; c.cy_r = p.cy_r;
+    c.fx_t = p.fx_t; c.fy_t = p.fy_t; c.cx_t = p.cx_t; c.cy_t = p.cy_t;
+    c.sx = p.sx; c.sy = p.sy;
+    c.drs = p.dr * SWEEP_FX_ONE_F; c.dbs = p.db * SWEEP_FX_ONE_F; c.scs = p.sc * SWEEP_FX_ONE_F;
+    c.unit_s = p.unit * (1.f / SWEEP_FX_ONE_F);
+    return c;
+}
+
+// What one wave works with: its own frame j (whose source rows it evaluates, whose ring rows it flushes and stages)
+// and the other frame k (whose ring its sources sample and scatter into).  Wave-uniform.
+struct View {
+    int H, W, R, RW, RP, G, CG;
+    unsigned HW;
+    const float* vj;           // raw depth plane of frame j
+    const float* vk;           // ... of frame k (slow path only)
+    const float* flj;          // flow of direction j: dx plane, dy plane at + HW
+    const float* mkj;          // mask of direction j
+    float* gradj;              // gradient plane of frame j (w.r.t. the raw depth input)
+    float* Dj; float* Dk;      // LDS depth rings [R][RW]
+    unsigned long long* Aj; unsigned long long* Ak;   // LDS accumulator rings [R][RW]
+    Cam cj;                    // direction j
+    float unit_k_s;            // accumulator unit of ring k, times 2^-34
+    unsigned gbj, gbk;         // element index of the two gradient planes in the whole gradient tensor (overflow list)
+};
+
+template <int PXT> struct Lane {   // per-thread constants
+    int rr;                 // row inside a pass / group
+    unsigned rrW;           // rr * W
+    bool on, gon;           // takes part in flush / stage passes (rr < RP); in source groups (rr < G)
+    unsigned x[PXT];        // its columns: cg + i * CG (adjacent lanes = adjacent columns: conflict-free LDS, coalesced HBM)
+    bool cok[PXT];          // x < W
+    static constexpr int NA = PXT <= 2 ? PXT : 1;   // hoisted only while the registers allow it
+    float a0[NA], a1[NA], a2[NA];      // M[0], M[3], M[6] * r0(x): the column part of a = M (r0, r1, -1)
+};
+template <int PXT> CD_HD Lane<PXT> make_lane(const View& v, int lt /* thread index inside its frame's 512 */) {
+    Lane<PXT> l;
+    l.rr = lt / v.CG;
+    const int cg = lt - l.rr * v.CG;
+    l.rrW = (unsigned)(l.rr * v.W);
+    l.on = l.rr < v.RP;
+    l.gon = l.rr < v.G;
+    for (int i = 0; i < PXT; ++i) {
+        l.x[i] = (unsigned)(cg + i * v.CG);
+        l.cok[i] = (int)l.x[i] < v.W;
+        if (PXT <= 2) {
+            const float r0 = ((float)l.x[i] - v.cj.cx_r) * v.cj.ifx_r;
+            l.a0[i] = v.cj.M[0] * r0; l.a1[i] = v.cj.M[3] * r0; l.a2[i] = v.cj.M[6] * r0;
+        }
+    }
+    if (PXT > 2) l.a0[0] = l.a1[0] = l.a2[0] = 0.f;
+    return l;
+}
+
+// global load / store at a 32-bit BYTE offset from a wave-uniform base: the address is base (SGPRs) + offset (one VGPR)
+CD_HD float ldg(const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
+CD_HD void stg(float* base, unsigned byte_off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+
+template <int PXT> struct Regs {
+    float fx[PXT], fy[PXT], m[PXT];      // inputs of the source rows being processed
+    float sv[kStagePasses][PXT];         // raw depth of the rows entering the ring
+    double acc_r, acc_d;                 // loss partial sums of this thread (its frame = direction)
+    bool bad;                            // a staged depth was not a positive finite number (see stage_rows)
+};
+template <int PXT> CD_HD void init_regs(Regs<PXT>& r) {
+    for (int i = 0; i < PXT; ++i) {
+        r.fx[i] = r.fy[i] = r.m[i] = 0.f;
+        for (int s = 0; s < kStagePasses; ++s) r.sv[s][i] = 0.f;
+    }
+    r.acc_r = r.acc_d = 0.0;
+    r.bad = false;
+}
+
+// inputs of the source rows [p, p + G) of the wave's frame (p < 0: nothing).  32-bit element offsets from uniform bases.
+template <int PXT> CD_HD void load_inputs(const View& v, const Lane<PXT>& l, int p, float* fx, float* fy, float* m) {
+    const bool rowok = l.gon && p >= 0 && p + l.rr < v.H;
+    const unsigned rowoff = (unsigned)(p < 0 ? 0 : p) * (unsigned)v.W + l.rrW;
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) {
+        const bool ok = rowok && l.cok[i];
+        const unsigned q = ok ? (rowoff + l.x[i]) << 2 : 0u;
+        const float a = ldg(v.flj, q), b = ldg(v.flj + v.HW, q), mm = ldg(v.mkj, q);
+        fx[i] = ok ? a : 0.f; fy[i] = ok ? b : 0.f; m[i] = ok ? mm : 0.f;
+    }
+}
+
+// raw depth of the rows [s_lo, s_hi) that enter the wave's ring
+template <int PXT> CD_HD void load_stage(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, float (*sv)[PXT]) {
+#pragma unroll
+    for (int s = 0; s < kStagePasses; ++s) {
+        const int row = s_lo + s * v.RP + l.rr;
+        const bool rowok = l.on && row < s_hi && row < v.H;
+        const unsigned rowoff = (unsigned)(s_lo + s * v.RP) * (unsigned)v.W + l.rrW;
+#pragma unroll
+        for (int i = 0; i < PXT; ++i) {
+            const bool ok = rowok && l.cok[i];
+            const float a = ldg(v.vj, ok ? (rowoff + l.x[i]) << 2 : 0u);
+            sv[s][i] = ok ? a : 0.f;
+        }
+    }
+}
+
+// rows [s_lo, s_hi) enter the ring (their values are in sv); window base w at slot ws.  Returns false if a staged depth
+// is not a positive finite number (such an input takes the exact v1 path: see process_rows, "lenient").
+template <int MODE, int PXT>
+CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, int w, int ws, const float (*sv)[PXT]) {
+    bool good = true;
+#pragma unroll
+    for (int s = 0; s < kStagePasses; ++s) {
+        const int row = s_lo + s * v.RP + l.rr;
+        if (l.on && row < s_hi) {
+            int slot = ws + (row - w);          // row - w <= R: at most one wrap
+            if (slot >= v.R) slot -= v.R;
+            const unsigned base = (unsigned)(slot * v.RW);
+            const bool img = row < v.H;         // row H is the pad row: finite depth, only ever sampled with weight 0
+#pragma unroll
+            for (int i = 0; i < PXT; ++i) {
+                if (l.cok[i]) {
+                    const float d = img ? to_depth<MODE>(sv[s][i]) : 1.f;
+                    good = good && (d > 0.f && d < INFINITY);
+                    v.Dj[base + l.x[i]] = d;
+                }
+            }
+            if (l.x[0] == 0u) { v.Dj[base + (unsigned)v.W] = 1.f; v.Dj[base + (unsigned)v.RW - 1u] = 1.f; }   // the pad column(s)
+        }
+    }
+    return good;
+}
+
+// rows [lo, hi) leave the ring (lo sits in slot `slot0`): accumulator -> gradient row (one plain store), accumulator
+// cleared for the next tenant
+template <int PXT>
+CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi, int slot0) {
+    const double unit = (double)v.cj.unit_s;
+#pragma unroll
+    for (int s = 0; s < kStagePasses; ++s) {
+        const int row = lo + s * v.RP + l.rr;
+        if (l.on && row < hi) {
+            int slot = slot0 + (row - lo);
+            if (slot >= v.R) slot -= v.R;
+            const unsigned base = (unsigned)(slot * v.RW);
+            const unsigned goff = (unsigned)(lo + s * v.RP) * (unsigned)v.W + l.rrW;
+#pragma unroll
+            for (int i = 0; i < PXT; ++i) {
+                if (l.cok[i]) {
+                    const unsigned long long n = v.Aj[base + l.x[i]];
+                    v.Aj[base + l.x[i]] = 0ull;
+                    stg(v.gradj, (goff + l.x[i]) << 2, (float)((double)(long long)n * unit));
+                }
+            }
+            if (l.x[0] == 0u) { v.Aj[base + (unsigned)v.W] = 0ull; v.Aj[base + (unsigned)v.RW - 1u] = 0ull; }
+        }
+    }
+}
+
+// Evaluate the source rows [p, p + G) of the wave's frame j: loss partials, direct gradient -> ring j, the 4 tap
+// contributions -> ring k.  Closed form: SURVEY.md appendix A.1 (= oracle/cd_oracle_body.inc).
+// Env supplies what differs between the GPU and the host emulation:
+//   env.add64(p, v)   64-bit LDS atomic add            env.any(x)   wave vote
+//   env.push(need, idx, v)   wave-aggregated append to the overflow list (gradient element idx += v)
+// The pixels of a thread go through the stages TOGETHER, two at a time (coordinates -> tap reads -> algebra -> atomics):
+// independent dependency chains per wave and one wave vote per stage instead of per pixel.
+//
+// "Lenient" lanes.  A source with mask == 0 scatters nothing and adds m * |...| = 0 to the loss -- unless a sampled depth is
+// zero, negative or not finite (0 * inf = NaN in the reference).  Such sources are mostly the ones whose flow points out of
+// the frame, i.e. whose taps are far from the ring.  Instead of sending their whole wave down the exact slow path, they
+// sample a resident row (any finite positive depth gives the same 0), and stage_rows watches the ONLY inputs for which this
+// could differ from the reference: if any depth of the pair is not a positive finite number, the kernel raises the fallback
+// flag and the exact v1 pass recomputes gradient and loss (loss_api.hip).
+template <int MODE, bool REPROJ, int PXT, class Env>
+CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& l, int p, int wj, int wsj, int wk, int wsk, int nvk) {
+    const int y = p + l.rr;
+    const bool rowok = l.gon && p >= 0 && y < v.H;
+    const Cam& cj = v.cj;
+    const float yf = (float)y;
+    const float r1 = -(yf - cj.cy_r) * cj.ify_r;
+    const float B0 = cj.M[1] * r1 - cj.M[2], B1 = cj.M[4] * r1 - cj.M[5], B2 = cj.M[7] * r1 - cj.M[8];
+    const unsigned own = rowok ? mad24(wrapu((unsigned)(wsj + (y - wj)), (unsigned)v.R), (unsigned)v.RW, 0u) : 0u;
+    const int R = v.R, RW = v.RW, W = v.W, H = v.H;
+    // at most 2 pixels share the staged registers (a 1024-thread workgroup has 128 VGPRs per lane); PXT = 4 runs two batches
+    constexpr int NB = PXT < 2 ? PXT : 2;
+    float sum_r = 0.f, sum_d = 0.f;
+#pragma unroll
+    for (int b0 = 0; b0 < PXT; b0 += NB) {
+        // ---- stage 0: own depth, sampling coordinates, ring addresses
+        bool act[NB];
+        unsigned i0[NB], i1[NB];
+        float d[NB];
+        Taps tp[NB];
+        bool need_slow_rd = false;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            act[i] = rowok && l.cok[b0 + i];
+            d[i] = act[i] ? v.Dj[own + l.x[b0 + i]] : 1.f;
+            tp[i] = tap_coords((float)l.x[b0 + i], yf, r.fx[b0 + i], r.fy[b0 + i], cj.sx, cj.sy, W, H);
+            // Ring addressing uses the UNCLIPPED neighbours (xa + 1, ya + 1): the pad column / pad row hold a finite depth and
+            // the clipped tap's weight is exactly 0 there, so no min() is needed on the fast path.
+            const int ra = tp[i].ya - wk;
+            const bool inside = (unsigned)ra < (unsigned)(nvk - 1);      // rows ya, ya + 1 both in [wk, wk + nvk); nvk >= 1
+            const bool lenient = !act[i] || r.m[b0 + i] == 0.f;
+            need_slow_rd = need_slow_rd || (!inside && !lenient);
+            const unsigned rac = inside ? (unsigned)ra : 0u;              // outside (lenient lanes): the window's first row, always staged
+            const unsigned sa = wrapu((unsigned)wsk + rac, (unsigned)R), sb = wrapu(sa + 1u, (unsigned)R);
+            i0[i] = mad24(sa, (unsigned)RW, (unsigned)tp[i].xa); i1[i] = mad24(sb, (unsigned)RW, (unsigned)tp[i].xa);
+        }
+        const bool slow_rd = env.any(need_slow_rd);
+
+        // ---- stage 1: the 4 depth taps of frame k
+        float d00[NB], d01[NB], d10[NB], d11[NB];
+        if (!slow_rd) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { d00[i] = v.Dk[i0[i]]; d01[i] = v.Dk[i0[i] + 1]; d10[i] = v.Dk[i1[i]]; d11[i] = v.Dk[i1[i] + 1]; }
+        } else {   // some valid source of the wave samples outside the ring: every tap decides for itself (LDS or global)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const bool exact = act[i] && r.m[b0 + i] != 0.f;
+                auto tap = [&](int rq, int cq) -> float {
+                    const int rel = rq - wk;
+                    if ((unsigned)rel < (unsigned)nvk) return v.Dk[wrap_slot(wsk + rel, R) * RW + cq];
+                    return exact ? to_depth<MODE>(v.vk[(unsigned)(rq * W + cq)]) : v.Dk[wsk * RW + cq];
+                };
+                d00[i] = tap(tp[i].ya, tp[i].xa); d01[i] = tap(tp[i].ya, tp[i].xb);
+                d10[i] = tap(tp[i].yb, tp[i].xa); d11[i] = tap(tp[i].yb, tp[i].xb);
+            }
+        }
+
+        // ---- stage 2: the algebra
+        float gd[NB], c00[NB], c01[NB], c10[NB], c11[NB];
+        bool need_slow = false;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float xf = (float)l.x[b0 + i];
+            const float m = r.m[b0 + i], fx = r.fx[b0 + i], fy = r.fy[b0 + i];      // 0 for inactive lanes
+            float a0, a1, a2;
+            if (PXT <= 2) { a0 = l.a0[(b0 + i) % Lane<PXT>::NA] + B0; a1 = l.a1[(b0 + i) % Lane<PXT>::NA] + B1; a2 = l.a2[(b0 + i) % Lane<PXT>::NA] + B2; }
+            else { const float r0 = (xf - cj.cx_r) * cj.ifx_r; a0 = cj.M[0] * r0 + B0; a1 = cj.M[3] * r0 + B1; a2 = cj.M[6] * r0 + B2; }
+            const float X = d[i] * a0 + cj.c[0], Y = d[i] * a1 + cj.c[1], Z = d[i] * a2 + cj.c[2];
+            const float iZ = cd_rcp(Z);
+            float gdi = 0.f;   // direct term, in units of ring j
+            if (REPROJ) {
+                const float mx = xf + fx, my = yf + fy;
+                const float ex = (cj.cx_t - cj.fx_t * X * iZ) - mx, ey = (cj.cy_t + cj.fy_t * Y * iZ) - my;
+                const float e2 = ex * ex + ey * ey;
+                const float ie = e2 > 0.f ? cd_rsq(e2) : 0.f;       // subgradient 0 at e = 0
+                sum_r += act[i] ? m * (e2 * ie) : 0.f;              // multiply, not select: 0*inf = NaN exactly like the reference
+                const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
+                gdi = cj.drs * m * (ex * dpx + ey * dpy) * ie;
+            }
+            const float zs = -(d00[i] * tp[i].w00 + d01[i] * tp[i].w01 + d10[i] * tp[i].w10 + d11[i] * tp[i].w11);
+            const float izs = cd_rcp(zs);
+            const float dd = iZ - izs;
+            sum_d += act[i] ? m * fabsf(dd) : 0.f;
+            const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+            const float ms = m * sg;
+            gdi -= cj.dbs * ms * a2 * iZ * iZ;
+            gdi *= depth_jac<MODE>(d[i]);
+            const float gz = cj.scs * ms * izs * izs;           // scatter scale, in units of ring k (times 2^34)
+            c00[i] = -gz * tp[i].w00 * depth_jac<MODE>(d00[i]); c01[i] = -gz * tp[i].w01 * depth_jac<MODE>(d01[i]);
+            c10[i] = -gz * tp[i].w10 * depth_jac<MODE>(d10[i]); c11[i] = -gz * tp[i].w11 * depth_jac<MODE>(d11[i]);
+            gd[i] = gdi;
+            // inside the fixed-point range?  (a sum, not a max: NaN must fail the test)
+            const bool fits = fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]) + fabsf(gdi) <= SWEEP_FX_LIMIT_SCALED;
+            need_slow = need_slow || (act[i] && !fits);
+        }
+        const bool slow = slow_rd || env.any(need_slow);
+
+        // ---- stage 3: 5 integer LDS atomics per pixel
+        if (!slow) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (act[i]) {
+                    env.add64(&v.Aj[own + l.x[b0 + i]], sweep_scaled_to_fixed(gd[i]));
+                    if (r.m[b0 + i] != 0.f) {
+                        env.add64(&v.Ak[i0[i]], sweep_scaled_to_fixed(c00[i])); env.add64(&v.Ak[i0[i] + 1], sweep_scaled_to_fixed(c01[i]));
+                        env.add64(&v.Ak[i1[i]], sweep_scaled_to_fixed(c10[i])); env.add64(&v.Ak[i1[i] + 1], sweep_scaled_to_fixed(c11[i]));
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const bool dfit = fabsf(gd[i]) <= SWEEP_FX_LIMIT_SCALED;
+                if (act[i] && dfit) env.add64(&v.Aj[own + l.x[b0 + i]], sweep_scaled_to_fixed(gd[i]));
+                env.push(act[i] && !dfit, v.gbj + (unsigned)(y * W) + l.x[b0 + i], gd[i] * cj.unit_s);
+                const bool a = act[i];
+                auto scatter = [&](int rq, int cq, float cv) {
+                    const int rel = rq - wk;
+                    const bool live = a && cv != 0.f;                        // NaN != 0: it propagates like in the reference
+                    const bool in_ring = (unsigned)rel < (unsigned)nvk && fabsf(cv) <= SWEEP_FX_LIMIT_SCALED;
+                    if (live && in_ring) env.add64(&v.Ak[wrap_slot(wsk + rel, R) * RW + cq], sweep_scaled_to_fixed(cv));
+                    env.push(live && !in_ring, v.gbk + (unsigned)(rq * W + cq), cv * v.unit_k_s);
+                };
+                scatter(tp[i].ya, tp[i].xa, c00[i]); scatter(tp[i].ya, tp[i].xb, c01[i]);
+                scatter(tp[i].yb, tp[i].xa, c10[i]); scatter(tp[i].yb, tp[i].xb, c11[i]);
+            }
+        }
+    }
+    r.acc_r += (double)sum_r; r.acc_d += (double)sum_d;
+}
+
+// tap-row bounds of one source pixel for the planner (the same tap_coords as the kernels: identical rows)
+CD_HD void tap_rows(float xf, float yf, float fx, float fy, int W, int H, int* ya, int* yb) {
+    const Taps t = tap_coords(xf, yf, fx, fy, (float)W / (float)(W - 1), (float)H / (float)(H - 1), W, H);
+    *ya = t.ya; *yb = t.ya + 1;   // the unclipped neighbour row: what the fast path addresses (row H = the pad row)
+}
+
+}  // namespace sweep
+}  // namespace cd

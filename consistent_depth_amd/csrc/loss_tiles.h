@@ -16,8 +16,9 @@ struct TileWin { short x0, y0, w, h; };    // window in the OTHER frame's pixel 
 struct Overflow {          // global overflow list (workspace)
     int count;             // number of pushes attempted
     int cap;               // capacity of idx/val
-    int fallback;          // set by overflow_apply when count > cap
-    int pad;
+    int fallback;          // set by overflow_apply when count > cap or `degenerate` is set
+    int degenerate;        // set by the row-sweep kernel: a depth of the batch is not a positive finite number, the exact v1
+                           // pass must produce gradient AND loss (loss_sweep_core.h, "lenient" lanes)
 };
 
 // ---------------------------------------------------------------- fixed-point scatter accumulator

@@ -128,8 +128,13 @@ int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out);
 /* Test hook: cap the gradient kernel's overflow list at `cap` records (< 0 restores the default), to
  * force the overflow-apply and the device-side fallback paths in tests. */
 int cd_debug_set_overflow_capacity(int cap);
-/* Test / A-B hook: gradient-kernel formulation, 3 = evaluate once + slab reduce (default), 2 = owner-computes. */
+/* Test / A-B hook: gradient-kernel formulation.  0 = default dispatch (the row sweep when the batch gives every CU a pair
+ * and the image is narrow enough for a >= 24-row ring, else the tile kernels), 4 = row sweep (one workgroup per pair, row
+ * rings in LDS; falls back to 3 where its geometry is unsupported), 3 = evaluate once + slab reduce, 2 = owner-computes. */
 int cd_debug_set_loss_variant(int variant);
+/* Row sweep: pixels per thread (1, 2, 4; 0 = default rule).  It fixes the rows per item, hence the plan stored in the
+ * tile-windows blob: set it BEFORE cd_tile_windows_bytes / cd_tile_windows and keep it for the loss calls that use the blob. */
+int cd_debug_set_loss_sweep(int pixels_per_thread);
 /* pairs per source+gather launch pair of the evaluate-once gradient kernel (0 = default: slabs of one chunk sized
  * to stay resident in the Infinity Cache).  Changes cd_consistency_loss_workspace_bytes(); set it before the query. */
 int cd_debug_set_loss_chunk(int pairs);

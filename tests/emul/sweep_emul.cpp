@@ -1,0 +1,274 @@
+// TEST INFRASTRUCTURE ONLY -- sequential host execution of the row-sweep loss kernel's phase functions
+// (consistent_depth_amd/csrc/loss_sweep_core.h, the very code hipcc compiles into loss_sweep.hip).
+//
+// The GPU kernel is: prologue; per item { flush + stage | barrier | prefetch next ; process | barrier }; epilogue.
+// Between two barriers the 1024 threads are independent except for LDS atomics, so running them one after the other on
+// the host is a valid execution.  This catches plan, ring-index, window and flush mistakes without a GPU; it is built by
+// tests/emul/build.py with g++ and loaded only by tests/test_sweep_*_cpu.py.  Nothing under consistent_depth_amd/ links it.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "loss_sweep_core.h"
+
+using namespace cd;
+using namespace cd::sweep;
+
+namespace {
+
+int g_order = 0;   // 0: an item's sources run before its rows enter / leave, 1: after (see run_pair)
+
+struct HostEnv {
+    std::vector<unsigned>* idx;
+    std::vector<float>* val;
+    bool force_slow;
+    long* n_slow;
+    long* n_push;
+    bool* degen;
+    void degenerate() { *degen = true; }
+    static void add64(unsigned long long* p, unsigned long long v) { *p += v; }
+    bool any(bool x) {
+        if (x) ++*n_slow;
+        return x || force_slow;
+    }   // every thread is its own "wave"
+    void push(bool need, unsigned i, float v) {
+        if (need) { idx->push_back(i); val->push_back(v); ++*n_push; }
+    }
+};
+
+// bounds of the valid sources' tap rows per row group (what sweep_plan_kernel computes on the GPU)
+void group_bounds(const Geo& g, const float* flow, const float* mask, short* lo, short* hi) {
+    const int H = g.H, W = g.W;
+    for (int gi = 0; gi < g.NG; ++gi) { lo[gi] = kNoRow; hi[gi] = -1; }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int p = y * W + x;
+            if (mask[p] == 0.f) continue;
+            int ya, yb;
+            tap_rows((float)x, (float)y, flow[p], flow[H * W + p], W, H, &ya, &yb);
+            const int gi = y / g.G;
+            if (ya < lo[gi]) lo[gi] = (short)ya;
+            if (yb > hi[gi]) hi[gi] = (short)yb;
+        }
+}
+
+template <int MODE, bool REPROJ, int PXT>
+int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* fb, const float* mf, const float* mb,
+             const PairCam* cams, const Item* raw_items, int n_items, unsigned gbase0, float* grad_p, float* partial,
+             HostEnv& env) {
+    const int H = g.H, W = g.W, HW = H * W, ring = g.R * g.RW;
+    std::vector<float> D(2 * (size_t)ring, 0.f);
+    std::vector<unsigned long long> A(2 * (size_t)ring, 0ull);
+    std::vector<PlanItem> items(n_items);
+    expand_plan(g, raw_items, n_items, items.data());
+    View vw[2];
+    for (int f = 0; f < 2; ++f) {
+        View& v = vw[f];
+        v.H = H; v.W = W; v.R = g.R; v.RW = g.RW; v.RP = g.RP; v.G = g.G; v.CG = g.CG; v.HW = (unsigned)HW;
+        v.vj = depth_p + (f ? HW : 0); v.vk = depth_p + (f ? 0 : HW);
+        v.flj = f ? fb : ff; v.mkj = f ? mb : mf;
+        v.gradj = grad_p + (f ? HW : 0);
+        v.Aj = A.data() + (f ? ring : 0); v.Ak = A.data() + (f ? 0 : ring);
+        v.Dj = D.data() + (f ? ring : 0); v.Dk = D.data() + (f ? 0 : ring);
+        v.cj = make_cam(cams[f]); v.unit_k_s = cams[1 - f].unit * (1.f / SWEEP_FX_ONE_F);
+        v.gbj = gbase0 + (f ? HW : 0); v.gbk = gbase0 + (f ? 0 : HW);
+    }
+    std::vector<Regs<PXT>> regs(kThreads);
+    std::vector<Lane<PXT>> lanes(kThreads);
+    std::vector<int> fr(kThreads);
+    for (int t = 0; t < kThreads; ++t) {
+        fr[t] = t / kFrameThreads;
+        lanes[t] = make_lane<PXT>(vw[fr[t]], t - fr[t] * kFrameThreads);
+        init_regs<PXT>(regs[t]);
+    }
+    // prologue: the initial window [0, R) of both rings
+    const int init_hi = init_stage_hi(g);
+    for (int lo = 0; lo < init_hi; lo += kStagePasses * g.RP) {
+        const int hi = lo + kStagePasses * g.RP < init_hi ? lo + kStagePasses * g.RP : init_hi;
+        for (int t = 0; t < kThreads; ++t) {
+            float sv[kStagePasses][PXT];
+            load_stage<PXT>(vw[fr[t]], lanes[t], lo, hi, sv);
+            regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], lo, hi, 0, 0, sv) || regs[t].bad;
+        }
+    }
+    for (int t = 0; t < kThreads; ++t) load_inputs<PXT>(vw[fr[t]], lanes[t], items[0].f[fr[t]].p, regs[t].fx, regs[t].fy, regs[t].m);
+    int wlast[2] = {0, 0};
+    for (int it = 0; it < n_items; ++it) {
+        for (int f = 0; f < 2; ++f) {
+            const Rec& me = items[it].f[f];
+            if (me.w < wlast[f] || me.w - wlast[f] > g.SMAX) { fprintf(stderr, "emul: window step out of range\n"); return -2; }
+            if (me.s_hi - me.s_lo > kStagePasses * g.RP || me.fl_hi - me.fl_lo > kStagePasses * g.RP) { fprintf(stderr, "emul: stage/flush range too long\n"); return -3; }
+            if (me.p >= 0 && (me.p < me.w || me.p + g.G > me.w + me.nv)) { fprintf(stderr, "emul: own rows outside the usable part of the ring\n"); return -4; }
+            wlast[f] = me.w;
+        }
+        // ONE phase per item on the GPU: rows enter, rows leave and the sources are evaluated side by side.  The plan makes the
+        // three touch disjoint rows, so any order is a valid execution; the emulation runs the sources FIRST (`order` 0) or
+        // LAST (1): a plan that let them depend on this item's entering / leaving rows would give different results.
+        const bool more = it + 1 < n_items;
+        std::vector<Regs<PXT>> nxt;
+        if (more) {
+            nxt = regs;
+            for (int t = 0; t < kThreads; ++t) {
+                const Rec& nx = items[it + 1].f[fr[t]];
+                load_inputs<PXT>(vw[fr[t]], lanes[t], nx.p, nxt[t].fx, nxt[t].fy, nxt[t].m);
+                load_stage<PXT>(vw[fr[t]], lanes[t], nx.s_lo, nx.s_hi, nxt[t].sv);
+            }
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((pass == 0) == (g_order == 0)) {
+                for (int t = 0; t < kThreads; ++t) {
+                    const int f = fr[t];
+                    const Rec& me = items[it].f[f];
+                    const Rec& ot = items[it].f[1 - f];
+                    process_rows<MODE, REPROJ, PXT>(vw[f], env, regs[t], lanes[t], me.p, me.w, me.ws, ot.w, ot.ws, ot.nv);
+                }
+            } else {
+                for (int t = 0; t < kThreads; ++t) {
+                    const Rec& me = items[it].f[fr[t]];
+                    regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], me.s_lo, me.s_hi, me.w, me.ws, regs[t].sv) || regs[t].bad;
+                    flush_rows<PXT>(vw[fr[t]], lanes[t], me.fl_lo, me.fl_hi, me.fl_slot);
+                }
+            }
+        }
+        if (more)
+            for (int t = 0; t < kThreads; ++t)
+                for (int i = 0; i < PXT; ++i) {
+                    regs[t].fx[i] = nxt[t].fx[i]; regs[t].fy[i] = nxt[t].fy[i]; regs[t].m[i] = nxt[t].m[i];
+                    for (int s = 0; s < kStagePasses; ++s) regs[t].sv[s][i] = nxt[t].sv[s][i];
+                }
+    }
+    for (int f = 0; f < 2; ++f)
+        if (wlast[f] < H) { fprintf(stderr, "emul: rows left in ring %d\n", f); return -5; }
+    for (size_t i = 0; i < A.size(); ++i)
+        if (A[i] != 0ull) { fprintf(stderr, "emul: accumulator not drained at %zu\n", i); return -6; }
+    double ar[2] = {0, 0}, ad[2] = {0, 0};
+    for (int t = 0; t < kThreads; ++t) { ar[fr[t]] += (float)regs[t].acc_r; ad[fr[t]] += (float)regs[t].acc_d; if (regs[t].bad) env.degenerate(); }
+    for (int f = 0; f < 2; ++f) { partial[f * 2] = (float)ar[f]; partial[f * 2 + 1] = (float)ad[f]; }
+    return 0;
+}
+
+template <int MODE, int PXT>
+int run_pair_r(bool reproj, const Geo& g, const float* depth_p, const float* ff, const float* fb, const float* mf,
+               const float* mb, const PairCam* cams, const Item* items, int n_items, unsigned gbase0, float* grad_p,
+               float* partial, HostEnv& env) {
+    return reproj ? run_pair<MODE, true, PXT>(g, depth_p, ff, fb, mf, mb, cams, items, n_items, gbase0, grad_p, partial, env)
+                  : run_pair<MODE, false, PXT>(g, depth_p, ff, fb, mf, mb, cams, items, n_items, gbase0, grad_p, partial, env);
+}
+
+template <int PXT>
+int run_pair_m(int mode, bool reproj, const Geo& g, const float* depth_p, const float* ff, const float* fb, const float* mf,
+               const float* mb, const PairCam* cams, const Item* items, int n_items, unsigned gbase0, float* grad_p,
+               float* partial, HostEnv& env) {
+    if (mode == kDepthExp) return run_pair_r<kDepthExp, PXT>(reproj, g, depth_p, ff, fb, mf, mb, cams, items, n_items, gbase0, grad_p, partial, env);
+    if (mode == kDepthReciprocal) return run_pair_r<kDepthReciprocal, PXT>(reproj, g, depth_p, ff, fb, mf, mb, cams, items, n_items, gbase0, grad_p, partial, env);
+    return run_pair_r<kDepthIdentity, PXT>(reproj, g, depth_p, ff, fb, mf, mb, cams, items, n_items, gbase0, grad_p, partial, env);
+}
+
+}  // namespace
+
+extern "C" {
+
+void sweep_emul_set_order(int order) { g_order = order ? 1 : 0; }
+
+// geometry as the kernel would choose it: out[0..11] = the Geo fields; ring_rows > 0 overrides R (to force tiny rings)
+int sweep_emul_geo(int H, int W, int pxt, int ring_rows, int* out) {
+    Geo g = make_geo(H, W, pxt);
+    if (ring_rows > 0 && g.CG > 0) {   // same rules as make_geo with a smaller ring
+        g.R = ring_rows;
+        g.G = g.RP < (g.R - 8) / 3 ? g.RP : (g.R - 8) / 3;
+        g.SMAX = kStagePasses * g.RP;
+        if (g.SMAX > g.R - g.G - 8) g.SMAX = g.R - g.G - 8;
+        g.ok = g.G >= 1 && g.SMAX >= g.G;
+        g.NG = g.G >= 1 ? (H + g.G - 1) / g.G : 0;
+        g.max_items = g.ok ? 4 * g.NG + 3 * ((H + 1 + g.R) / g.SMAX + 2) + 8 : 0;
+    }
+    memcpy(out, &g, sizeof(g));
+    return g.ok;
+}
+
+// plan of one pair from its flows / masks; items_out: [max_items][4] shorts (p0, p1, w0, w1).  Returns n_items or < 0.
+int sweep_emul_plan(const int* geo, const float* ff, const float* fb, const float* mf, const float* mb, short* items_out,
+                    short* lo_out, short* hi_out) {
+    Geo g; memcpy(&g, geo, sizeof(g));
+    std::vector<short> lo(2 * g.NG), hi(2 * g.NG), suf(2 * (g.NG + 1));
+    group_bounds(g, ff, mf, lo.data(), hi.data());
+    group_bounds(g, fb, mb, lo.data() + g.NG, hi.data() + g.NG);
+    std::vector<Item> items(g.max_items);
+    const int n = plan_items(g, lo.data(), hi.data(), suf.data(), items.data());
+    for (int i = 0; i < n; ++i) { items_out[i * 4] = items[i].p[0]; items_out[i * 4 + 1] = items[i].p[1]; items_out[i * 4 + 2] = items[i].w[0]; items_out[i * 4 + 3] = items[i].w[1]; }
+    if (lo_out) memcpy(lo_out, lo.data(), sizeof(short) * 2 * g.NG);
+    if (hi_out) memcpy(hi_out, hi.data(), sizeof(short) * 2 * g.NG);
+    return n;
+}
+
+// the whole loss + gradient through the emulated sweep kernel.  stats[0] = lanes that asked for the slow path,
+// stats[1] = overflow-list entries, stats[2] = total items, stats[3] = 1 if a
+// degenerate depth was met (the product then recomputes everything with the exact v1 kernel; the emulation's result is not
+// meaningful in that case).
+int sweep_emul_loss(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, const float* intr,
+                    const float* extr, float lambda_r, float lambda_b, int mode, int B, int H, int W, int pxt, int ring_rows,
+                    int force_slow, float* reproj, float* disp, float* total, float* grad, long* stats) {
+    int gi[16];
+    if (!sweep_emul_geo(H, W, pxt, ring_rows, gi)) return -1;
+    Geo g; memcpy(&g, gi, sizeof(g));
+    const int HW = H * W;
+    std::vector<float> msum(B * 2);
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < 2; ++k) {
+            const float* m = (k == 0 ? mf : mb) + (size_t)b * HW;
+            float s = 0.f;
+            for (int p = 0; p < HW; ++p) s += m[p];
+            msum[b * 2 + k] = s;
+        }
+    float fbar[2];
+    for (int k = 0; k < 2; ++k) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += intr[(b * 2 + k) * 4] + intr[(b * 2 + k) * 4 + 1];
+        fbar[k] = acc / (2.f * (float)B);
+    }
+    std::vector<PairCam> cams(B * 2);
+    for (int b = 0; b < B; ++b) prep_pair(intr + b * 8, extr + b * 24, msum.data() + b * 2, fbar, lambda_r, lambda_b, B, H, W, cams.data() + b * 2);
+    std::vector<unsigned> oidx;
+    std::vector<float> oval;
+    long n_slow = 0, n_push = 0, n_items_total = 0;
+    bool degen = false;
+    HostEnv env{&oidx, &oval, force_slow != 0, &n_slow, &n_push, &degen};
+    std::vector<float> partial(B * 4);
+    std::vector<short> items_raw((size_t)g.max_items * 4);
+    for (int b = 0; b < B; ++b) {
+        const float* ffb = ff + (size_t)b * 2 * HW; const float* fbb = fb + (size_t)b * 2 * HW;
+        const float* mfb = mf + (size_t)b * HW; const float* mbb = mb + (size_t)b * HW;
+        const int n = sweep_emul_plan(gi, ffb, fbb, mfb, mbb, items_raw.data(), nullptr, nullptr);
+        if (n <= 0) return -10;
+        n_items_total += n;
+        std::vector<Item> items(n);
+        for (int i = 0; i < n; ++i) { items[i].p[0] = items_raw[i * 4]; items[i].p[1] = items_raw[i * 4 + 1]; items[i].w[0] = items_raw[i * 4 + 2]; items[i].w[1] = items_raw[i * 4 + 3]; }
+        int rc;
+        const bool rp = lambda_r > 0.f;
+        float* gp = grad + (size_t)b * 2 * HW;
+        const float* dp = depth + (size_t)b * 2 * HW;
+        const unsigned gb0 = (unsigned)((size_t)b * 2 * HW);
+        if (pxt == 1) rc = run_pair_m<1>(mode, rp, g, dp, ffb, fbb, mfb, mbb, cams.data() + b * 2, items.data(), n, gb0, gp, partial.data() + b * 4, env);
+        else if (pxt == 2) rc = run_pair_m<2>(mode, rp, g, dp, ffb, fbb, mfb, mbb, cams.data() + b * 2, items.data(), n, gb0, gp, partial.data() + b * 4, env);
+        else rc = run_pair_m<4>(mode, rp, g, dp, ffb, fbb, mfb, mbb, cams.data() + b * 2, items.data(), n, gb0, gp, partial.data() + b * 4, env);
+        if (rc != 0) return rc;
+    }
+    for (size_t i = 0; i < oidx.size(); ++i) grad[oidx[i]] += oval[i];   // overflow_apply_kernel
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) {   // finalize_pairs_kernel / finalize_total_kernel
+        double r[2], q[2];
+        for (int k = 0; k < 2; ++k) {
+            r[k] = (double)partial[b * 4 + k * 2] * (double)cams[b * 2 + k].invS;
+            q[k] = (double)cams[b * 2 + k].fbar * ((double)partial[b * 4 + k * 2 + 1] * (double)cams[b * 2 + k].invS);
+        }
+        reproj[b] = lambda_r > 0.f ? (float)((double)lambda_r * (r[0] + r[1]) * 0.5) : 0.f;
+        disp[b] = lambda_b > 0.f ? (float)((double)lambda_b * (q[0] + q[1]) * 0.5) : 0.f;
+        tot += (double)reproj[b] + (double)disp[b];
+    }
+    total[0] = (float)(tot / (double)B);
+    if (stats) { stats[0] = n_slow; stats[1] = n_push; stats[2] = n_items_total; stats[3] = degen ? 1 : 0; }
+    return 0;
+}
+
+}  // extern "C"

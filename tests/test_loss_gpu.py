@@ -45,14 +45,15 @@ def _run(torch, batch, lr, lb, mode=0, mask_sums=None):
     return total.item(), reproj.cpu().numpy(), disp.cpu().numpy(), g
 
 
-@pytest.fixture(params=[3, 2], ids=["slab", "owner"])
+@pytest.fixture(params=[4, 3, 2], ids=["sweep", "slab", "owner"])
 def variant(request):
-    """Both formulations of the gradient kernel (v3 evaluate-once + slab reduce = default, v2 owner-computes)."""
+    """Every formulation of the gradient kernel: v4 row sweep (one workgroup per pair; the default for large batches),
+    v3 evaluate-once + slab reduce (the default for small batches), v2 owner-computes."""
     from consistent_depth_amd import _native
     lib = _native.lib()
     assert lib.cd_debug_set_loss_variant(request.param) == 0
     yield request.param
-    lib.cd_debug_set_loss_variant(3)
+    lib.cd_debug_set_loss_variant(0)
 
 
 @pytest.mark.parametrize("name", golden_loss_cases())
@@ -166,6 +167,120 @@ def test_wild_flow_full_size_vs_oracle(torch_cuda, oracle, variant):
            ref_fp32_grad_rel_l1=oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
     np.testing.assert_allclose(total, ref["total"][0], rtol=LOSS_RTOL)
     assert oracle.rel_l1(grad, ref["grad_depth"]) < grad_tol(oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
+
+
+@pytest.mark.parametrize("pxt", [1, 4])
+@pytest.mark.parametrize("name", ["basic_b3_48x40", "stress_b2_32x48"])
+def test_sweep_pixels_per_thread(torch_cuda, oracle, name, pxt):
+    """The row sweep with 1 and 4 columns per thread (2 is the default covered above): other rows per item, other plans."""
+    from consistent_depth_amd import _native
+    batch, lr, lb, ref64, ref32 = load_loss_case(name)
+    lib = _native.lib()
+    try:
+        assert lib.cd_debug_set_loss_variant(4) == 0 and lib.cd_debug_set_loss_sweep(pxt) == 0
+        total, reproj, disp, grad = _run(torch_cuda, batch, lr, lb)
+    finally:
+        lib.cd_debug_set_loss_sweep(0)
+        lib.cd_debug_set_loss_variant(0)
+    report(f"sweep_pxt[{name},pxt{pxt}]", loss_rel=abs(total - ref64["total"][0]) / abs(ref64["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, ref64["grad_depth"]))
+    np.testing.assert_allclose(total, ref64["total"][0], rtol=LOSS_RTOL)
+    assert oracle.rel_l1(grad, ref64["grad_depth"]) < grad_tol(oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]))
+
+
+@pytest.mark.parametrize("force", [0, 3], ids=["default_dispatch", "slab_chunked"])
+def test_roofline_launch_vs_oracle(torch_cuda, oracle, force):
+    """The launch bench.py's roofline number is taken on -- B = 256 pairs of 384x224 in ONE call (0.88 GB, beyond the
+    Infinity Cache) -- against the fp64 oracle: the default dispatch (row sweep, one workgroup per pair) and the tile
+    kernels' chunked path (2 x 128 pairs)."""
+    from consistent_depth_amd import _native, synthetic
+    base = synthetic.make_scene_batch(16, 384, 224, seed=31)
+    rng = np.random.default_rng(0)
+    B = 256
+    batch = {"depth": np.concatenate([base["depth"] * np.exp(rng.normal(0, 0.01, base["depth"].shape)).astype(np.float32)
+                                      for _ in range(B // 16)]),
+             "flows": [np.tile(f, (B // 16, 1, 1, 1)) for f in base["flows"]],
+             "masks": [np.tile(m, (B // 16, 1, 1, 1)) for m in base["masks"]],
+             "intrinsics": np.tile(base["intrinsics"], (B // 16, 1, 1)),
+             "extrinsics": np.tile(base["extrinsics"], (B // 16, 1, 1, 1))}
+    ref = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"],
+                                  1.0, 0.1, dtype=np.float64)
+    lib = _native.lib()
+    try:
+        assert lib.cd_debug_set_loss_variant(force) == 0
+        total, reproj, disp, grad = _run(torch_cuda, batch, 1.0, 0.1)
+    finally:
+        lib.cd_debug_set_loss_variant(0)
+    # the reference's own fp32 distance on this generator at this size: 8.9e-6 (baseline_size[scene] above)
+    report(f"roofline_launch_b256[variant{force}]", loss_rel=abs(total - ref["total"][0]) / abs(ref["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, ref["grad_depth"]),
+           worst_pair_grad_rel_l1=max(oracle.rel_l1(grad[b], ref["grad_depth"][b]) for b in range(B)))
+    np.testing.assert_allclose(total, ref["total"][0], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(reproj, ref["reprojection"], rtol=2 * LOSS_RTOL)
+    np.testing.assert_allclose(disp, ref["disparity"], rtol=2 * LOSS_RTOL)
+    assert oracle.rel_l1(grad, ref["grad_depth"]) < 4e-5
+    assert max(oracle.rel_l1(grad[b], ref["grad_depth"][b]) for b in range(B)) < 1e-4
+
+
+def test_midas_scale_vs_oracle(torch_cuda, oracle, variant):
+    """BASELINE configs[4] settings: lambda_view_baseline 1e-4, 384x384, B = 8, reciprocal head -- the gradient scale is
+    ~1e-3 of the mc case; the accumulators count in O(1) units (sweep) / 2^-40 fixed point (tile kernels)."""
+    from consistent_depth_amd import synthetic
+    batch = synthetic.make_scene_batch(8, 384, 384, seed=17)
+    depth = batch["depth"].astype(np.float64)
+    args = (depth, batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], 1.0, 1e-4)
+    ref = oracle.consistency_loss(*args, dtype=np.float64)
+    r32 = oracle.consistency_loss(*args, dtype=np.float32)
+    b2 = dict(batch, depth=(1.0 / depth).astype(np.float32))
+    total, reproj, disp, grad = _run(torch_cuda, b2, 1.0, 1e-4, mode=2)
+    want = ref["grad_depth"] * (-depth * depth)
+    report(f"midas_scale[v{variant}]", loss_rel=abs(total - ref["total"][0]) / abs(ref["total"][0]),
+           grad_rel_l1=oracle.rel_l1(grad, want), ref_fp32_grad_rel_l1=oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
+    np.testing.assert_allclose(total, ref["total"][0], rtol=LOSS_RTOL)
+    assert oracle.rel_l1(grad, want) < grad_tol(oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
+
+
+def test_sweep_degenerate_depth_takes_the_exact_path(torch_cuda, oracle):
+    """A zero depth makes 1/zs infinite for whoever samples it -- also for masked-out sources (0 * inf = NaN in the
+    reference).  The row sweep lets masked-out sources with far-away taps sample a resident row instead; it is exact
+    because any depth that is not a positive finite number sends the whole call to the exact v1 kernels (gradient AND loss)."""
+    from consistent_depth_amd import _native, synthetic
+    lib = _native.lib()
+    batch = synthetic.make_scene_batch(2, 96, 128, seed=4)
+    batch["depth"][1, 1, 40:44, 60:64] = 0.0
+    args = (batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], 1.0, 0.1)
+    ref = oracle.consistency_loss(*args, dtype=np.float64)
+    r32 = oracle.consistency_loss(*args, dtype=np.float32)
+    try:
+        assert lib.cd_debug_set_loss_variant(4) == 0
+        total, reproj, disp, grad = _run(torch_cuda, batch, 1.0, 0.1)
+    finally:
+        lib.cd_debug_set_loss_variant(0)
+    assert np.isfinite(ref["reprojection"][0]) and np.isfinite(reproj[0])
+    np.testing.assert_allclose(reproj[0], ref["reprojection"][0], rtol=LOSS_RTOL)
+    np.testing.assert_array_equal(np.isfinite(disp), np.isfinite(ref["disparity"]))
+    np.testing.assert_array_equal(np.isfinite(grad), np.isfinite(ref["grad_depth"]))
+    # sources that sample next to the zero block see 1/zs^2 blow up: ill-conditioned for ANY fp32 arithmetic, so the yardstick
+    # is again the reference's own fp32 run (same finite / non-finite pattern required above)
+    fin = np.isfinite(ref["grad_depth"]) & np.isfinite(r32["grad_depth"])
+    ref_dist = oracle.rel_l1(r32["grad_depth"][fin], ref["grad_depth"][fin])
+    report("degenerate_depth[sweep]", grad_rel_l1=oracle.rel_l1(grad[fin], ref["grad_depth"][fin]), ref_fp32_grad_rel_l1=ref_dist)
+    assert oracle.rel_l1(grad[fin], ref["grad_depth"][fin]) < grad_tol(ref_dist)
+
+
+def test_sweep_is_bit_reproducible(torch_cuda):
+    """Integer LDS accumulation: two runs of the row sweep give the same bits (no overflow-list traffic on consistent scenes)."""
+    from consistent_depth_amd import _native, synthetic
+    lib = _native.lib()
+    batch = synthetic.make_scene_batch(6, 384, 224, seed=8)
+    try:
+        assert lib.cd_debug_set_loss_variant(4) == 0
+        a = _run(torch_cuda, batch, 1.0, 0.1, mode=1)
+        b = _run(torch_cuda, batch, 1.0, 0.1, mode=1)
+    finally:
+        lib.cd_debug_set_loss_variant(0)
+    assert a[0] == b[0]
+    np.testing.assert_array_equal(a[3], b[3])
 
 
 def test_cached_tile_windows_bitwise(torch_cuda):

@@ -1,0 +1,141 @@
+"""CPU checks of the row-sweep loss kernel (consistent_depth_amd/csrc/loss_sweep_core.h) without a GPU:
+
+* the per-pair PLAN (schedule of row groups and ring windows): invariants the kernel relies on, for consistent, unrelated,
+  wild and degenerate flows;
+* the phase functions themselves, executed sequentially on the host by tests/emul (the same header hipcc compiles into the
+  kernel): loss and gradient against the reference-run goldens and the fp64 oracle, through the fast path, the forced
+  slow path, tiny rings (overflow list) and every pixels-per-thread setting.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_loss_cases, load_loss_case
+from emul import build as E
+
+
+def _check_plan(g, items, lo, hi):
+    G, R, H, NG, SMAX = g["G"], g["R"], g["H"], g["NG"], g["SMAX"]
+    assert len(items) <= g["max_items"]
+    done = [[], []]
+    w_prev = [0, 0]
+    outside = 0
+    for p0, p1, w0, w1 in items.tolist():
+        w, p = [w0, w1], [p0, p1]
+        for f in range(2):
+            assert w[f] >= w_prev[f] and w[f] - w_prev[f] <= SMAX, "windows slide forward by at most SMAX rows per item"
+            if p[f] >= 0:
+                assert p[f] % G == 0
+                # rows entering during an item are not used by it: the usable part of a ring ends at the PREVIOUS window's top
+                assert w[f] <= p[f] and p[f] + G <= w_prev[f] + R, "a group's own rows live in its frame's ring"
+                gi = p[f] // G
+                done[f].append(gi)
+                if hi[f, gi] >= 0 and not (lo[f, gi] >= w[1 - f] and hi[f, gi] < w_prev[1 - f] + R):
+                    outside += 1
+        w_prev = w
+    for f in range(2):
+        assert done[f] == list(range(NG)), "every row group exactly once, in order"
+        assert w_prev[f] >= H, "all gradient rows have left the rings"
+    return outside
+
+
+@pytest.mark.parametrize("gen,kw,max_outside", [("scene", {}, 0), ("scene", {"frame_gap": 12}, 0), ("pair", {}, None),
+                                                ("pair", {"noise_px": 40.0}, None)])
+@pytest.mark.parametrize("H,W,pxt", [(384, 224, 2), (384, 224, 4), (384, 224, 1), (224, 384, 2), (96, 128, 2)])
+def test_plan_invariants(gen, kw, max_outside, H, W, pxt):
+    from consistent_depth_amd import synthetic
+    g = E.geo(H, W, pxt)
+    assert g is not None
+    batch = (synthetic.make_scene_batch if gen == "scene" else synthetic.make_pair_batch)(3, H, W, seed=5, **kw)
+    for b in range(3):
+        items, lo, hi = E.plan(g, batch["flows"][0][b], batch["flows"][1][b], batch["masks"][0][b], batch["masks"][1][b])
+        outside = _check_plan(g, items, lo, hi)
+        if max_outside is not None and g["R"] >= 24:
+            # consistent scenes: the schedule keeps every valid tap inside the rings (nothing for the overflow list)
+            assert outside <= max_outside, (outside, len(items))
+        if gen == "scene" and g["R"] >= 24:
+            assert len(items) <= 1.4 * g["NG"] + 12, "lock-step: about one item per row group"
+
+
+def test_plan_degenerate_flows():
+    """Empty masks, constant-target flows, pure vertical shifts beyond the ring."""
+    H, W = 96, 64
+    g = E.geo(H, W, 2)
+    z, one = np.zeros((2, H, W), np.float32), np.ones((1, H, W), np.float32)
+    yy = np.arange(H, dtype=np.float32)[:, None].repeat(W, 1)
+    cases = [(z, z, 0 * one, 0 * one), (z, z, one, one)]
+    up = z.copy(); up[1] = -yy                      # every source of frame 0 samples row 0 of frame 1
+    down = z.copy(); down[1] = (H - 1) - yy         # ... and row H-1 the other way
+    cases.append((up, down, one, one))
+    shift = z.copy(); shift[1] = 60.0               # a shift larger than the ring, not mirrored by the backward flow
+    cases.append((shift, shift, one, one))
+    for ff, fb, mf, mb in cases:
+        items, lo, hi = E.plan(g, ff, fb, mf, mb)
+        _check_plan(g, items, lo, hi)
+
+
+def _dist(oracle, e, ref64):
+    return (abs(e["total"][0] - ref64["total"][0]) / abs(ref64["total"][0]), oracle.rel_l1(e["grad_depth"], ref64["grad_depth"]))
+
+
+@pytest.mark.parametrize("name", [n for n in golden_loss_cases() if not n.startswith("nodisp")])
+@pytest.mark.parametrize("cfg", [dict(pxt=2), dict(pxt=1), dict(pxt=4), dict(pxt=2, force_slow=True), dict(pxt=2, ring_rows=14),
+                                 dict(pxt=2, order=1), dict(pxt=2, ring_rows=14, order=1)],
+                         ids=["pxt2", "pxt1", "pxt4", "slow", "ring14", "sources_last", "ring14_sources_last"])
+def test_emulated_sweep_matches_reference_goldens(oracle, name, cfg):
+    batch, lr, lb, ref64, ref32 = load_loss_case(name)
+    e = E.loss(batch, lr, lb, **cfg)
+    loss_rel, grad = _dist(oracle, e, ref64)
+    assert loss_rel < 1e-6
+    assert grad < max(4 * oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]), 2e-6)
+    np.testing.assert_allclose(e["reprojection"], ref64["reprojection"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(e["disparity"], ref64["disparity"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("gen,kw", [("scene", {}), ("pair", {}), ("pair", {"noise_px": 40.0})], ids=["scene", "unrelated", "wild"])
+@pytest.mark.parametrize("H,W", [(384, 224), (224, 384)])
+def test_emulated_sweep_full_size_vs_oracle(oracle, gen, kw, H, W):
+    from consistent_depth_amd import synthetic
+    batch = (synthetic.make_scene_batch if gen == "scene" else synthetic.make_pair_batch)(2, H, W, seed=11, **kw)
+    args = (batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], 1.0, 0.1)
+    ref = oracle.consistency_loss(*args, dtype=np.float64)
+    r32 = oracle.consistency_loss(*args, dtype=np.float32)
+    e = E.loss(batch, 1.0, 0.1, pxt=2)
+    loss_rel, grad = _dist(oracle, e, ref)
+    assert loss_rel < 1e-6
+    assert grad < max(4 * oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]), 2e-6)
+    e2 = E.loss(batch, 1.0, 0.1, pxt=2, order=1)      # rows entering / leaving an item are independent of its sources
+    np.testing.assert_array_equal(e["grad_depth"], e2["grad_depth"])
+    if gen == "scene" and W == 224:
+        assert e["overflow_entries"] == 0 and e["slow_lanes"] < 0.01 * 2 * 2 * H * W
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_emulated_sweep_fused_heads_and_scales(oracle, mode):
+    """exp / reciprocal heads, MiDaS' lambda (1e-4) and a large batch-size divisor: the accumulator counts in O(1) units
+    whatever the scale of the gradient is."""
+    from consistent_depth_amd import synthetic
+    batch = synthetic.make_scene_batch(2, 96, 128, seed=3)
+    depth = batch["depth"].astype(np.float64)
+    x = np.log(depth) if mode == 1 else 1.0 / depth
+    jac = depth if mode == 1 else -depth * depth
+    for lr, lb in ((1.0, 0.1), (1.0, 1e-4), (0.0, 1.0)):
+        ref = oracle.consistency_loss(depth, batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], lr, lb)
+        r32 = oracle.consistency_loss(depth, batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], lr, lb,
+                                      dtype=np.float32)
+        e = E.loss(dict(batch, depth=x.astype(np.float32)), lr, lb, mode=mode, pxt=2)
+        assert abs(e["total"][0] - ref["total"][0]) / abs(ref["total"][0]) < 1e-6
+        assert oracle.rel_l1(e["grad_depth"], ref["grad_depth"] * jac) < max(4 * oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]), 2e-6)
+
+
+def test_emulated_sweep_nan_and_range_go_through_the_overflow_list(oracle):
+    """Values beyond the fixed-point range and NaN are not saturated: they take the overflow list and reach the gradient."""
+    from consistent_depth_amd import synthetic
+    batch = synthetic.make_scene_batch(1, 64, 64, seed=2)
+    batch["depth"][0, 1, 20:24, 20:24] = 1e-4      # 1/zs^2 ~ 1e8: far outside 2^17 units
+    ref = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], 1.0, 0.1)
+    e = E.loss(batch, 1.0, 0.1, pxt=2)
+    assert e["overflow_entries"] > 0
+    assert oracle.rel_l1(e["grad_depth"], ref["grad_depth"]) < 1e-5
+    batch["depth"][0, 0, 5, 5] = np.nan
+    e = E.loss(batch, 1.0, 0.1, pxt=2)
+    assert np.isnan(e["total"][0]) and np.isnan(e["grad_depth"][0, 0, 5, 5])

@@ -26,7 +26,8 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--mode", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=0, help="pairs per source+gather launch pair (0 = default)")
-    ap.add_argument("--variant", type=int, default=3, help="3 = evaluate-once + slab reduce, 2 = owner-computes")
+    ap.add_argument("--variant", type=int, default=0, help="0 = default dispatch, 4 = row sweep, 3 = evaluate-once + slab reduce, 2 = owner-computes")
+    ap.add_argument("--pxt", type=int, default=0, help="row sweep: pixels per thread (0 = default rule)")
     ap.add_argument("--noise-px", type=float, default=0.25)
     ap.add_argument("--inconsistent", action="store_true", help="adversarial generator: unrelated depth per frame")
     args = ap.parse_args()
@@ -35,6 +36,7 @@ def main():
     lib = _native.lib()
     assert lib.cd_debug_set_loss_variant(args.variant) == 0
     assert lib.cd_debug_set_loss_chunk(args.chunk) == 0
+    assert lib.cd_debug_set_loss_sweep(args.pxt) == 0
     dev = torch.device("cuda", 0)
     H, W = args.height, args.width
     gen = synthetic.make_pair_batch if args.inconsistent else synthetic.make_scene_batch
@@ -65,7 +67,7 @@ def main():
         ms = np.array(ms[:n.value])
         per_pair = (8 if args.fwd_only else 10) * H * W * 4
         gbs = per_pair * B / (ms * 1e-3) / 1e9
-        res.append({"pairs": B, "avg_ms": float(ms.mean()), "min_ms": float(ms.min()),
+        res.append({"variant": args.variant, "pxt": args.pxt, "pairs": B, "avg_ms": float(ms.mean()), "min_ms": float(ms.min()),
                     "GBps_avg": float(per_pair * B / (ms.mean() * 1e-3) / 1e9), "GBps_best": float(gbs.max()),
                     "frac_of_8TBps": float(per_pair * B / (ms.mean() * 1e-3) / 1e9 / 8000.0)})
         print(json.dumps(res[-1]), flush=True)
