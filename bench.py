@@ -2,11 +2,14 @@
 """Benchmark of the fine-tuning hot path on MI355X (contract: task prompt section 4).
 
 A "step" = one optimisation step of depth_fine_tuning.py's loop body on one batch of BS=4
-synthetic 384x224 frame pairs per GPU: hourglass forward (train-mode BN, 8 images), fused HIP
-geometric-consistency loss (+ analytic backward), CNN backward, [RCCL all-reduce], HIP Adam.
-Inputs are resident in HBM before the timed region.  value = frame pairs / second over all ranks.
+frame pairs per GPU of a synthetic 384x224 clip: batch gather from the HBM-resident pair store (one HIP launch),
+hourglass forward (train-mode BN, 8 images), fused HIP geometric-consistency loss (+ analytic backward), CNN backward,
+[RCCL all-reduce], HIP Adam.  The clip (BASELINE configs[2]: 244 frames, hierarchical pair sampling -> 715 pairs) is
+uploaded once before the timed region; every step takes the next batch of the epoch's shared-seed permutation, sharded
+over the ranks exactly like the training driver does (parallel.shard_indices).  value = frame pairs / second over all ranks.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 ...            (re-launches itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
 
 Extra objects in the JSON line:
@@ -31,10 +34,11 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x2 (fp32), SURVEY.md 8d
-# HBM traffic of the gradient path per pair at 384x224 from rocprofv3 PMC (profiles/rocprofv3_loss_slab_b256_r01.txt:
-# FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE, source + gather pass; raw counters: 5.60e6).  Only valid
-# for the size it was measured at; null otherwise.
-LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = 8.96e6
+# HBM traffic of the row-sweep gradient kernel per pair at 384x224 from rocprofv3 PMC (profiles/rocprofv3_loss_sweep_b256_r02.txt,
+# separate passes): FETCH_SIZE 344.77 MB x 2 (the guide's gfx950 correction) + WRITE_SIZE 172.04 MB per 256-pair launch
+# = 3.366 MB per pair = 0.98x the algorithmic 3.441 MB (every input read once, every gradient byte written once).  Only
+# valid for the size and the kernel it was measured on; null otherwise.
+LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = (2 * 344.7666e6 + 172.040e6) / 256
 
 
 _T0 = time.perf_counter()
@@ -68,7 +72,8 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("CD_AMD_MC_BACKEND", "hip"), choices=["torch", "hip"],
                     help="convolutions: hip = hand-written gfx950 engine (BASELINE configs[2]); "
                          "torch = PyTorch-ROCm/MIOpen (configs[1], ~2 min of MIOpen start-up)")
-    ap.add_argument("--pool", type=int, default=6, help="distinct synthetic batches cycled through")
+    ap.add_argument("--frames", type=int, default=244, help="frames of the synthetic clip (BASELINE configs[2]: 244 -> 715 pairs; configs[3]: 1000 -> 2979)")
+    ap.add_argument("--max-pairs", type=int, default=0, help="keep only the first N pairs of the clip (quick runs)")
     ap.add_argument("--loss-batch", type=int, default=256, help="pairs per launch of the roofline micro-benchmark")
     ap.add_argument("--loss-iters", type=int, default=20)
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CD_AMD_STEP_GRAPH", "1")),
@@ -82,23 +87,37 @@ def parse():
     return ap.parse_args()
 
 
-def make_pool(n, B, H, W, seed, device):
-    from consistent_depth_amd import synthetic
-    pool = []
-    for i in range(n):
-        b = synthetic.make_scene_batch(B, H, W, seed=seed * 1000 + i)
-        rng = np.random.default_rng(seed * 1000 + i)
-        images = rng.random((B, 2, 3, H, W), dtype=np.float32)
-        t = lambda a: torch.tensor(a, device=device)  # noqa: E731
-        meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
-                "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
-        # dataset constants, cached per pair exactly like loaders/pair_store.py does
-        from consistent_depth_amd.loss.consistency_loss import mask_sums, tile_windows
-        geom = meta["geometry_consistency"]
-        geom["mask_sums"] = mask_sums(*geom["masks"])
-        geom["tile_windows"] = tile_windows(geom["flows"], geom["masks"])
-        pool.append((t(images), meta, b, images))
-    return pool
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks on port {port}")
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
+class EpochPlans:
+    """The training driver's batch schedule (depth_fine_tuning.py): per epoch a shared-seed permutation of the pair list cut
+    into global batches, this rank's slice of each, uploaded once per epoch."""
+
+    def __init__(self, n_pairs, rank, world, batch_size, device, seed=0):
+        self.n, self.rank, self.world, self.bs, self.device, self.seed = n_pairs, rank, world, batch_size, device, seed
+        self.epoch, self.pos, self.plan = -1, 0, []
+
+    def next(self):
+        from consistent_depth_amd import parallel
+        while self.pos >= len(self.plan):
+            self.epoch += 1
+            plan = parallel.shard_indices(self.n, self.epoch, self.seed, self.rank, self.world, self.bs)
+            plan = [ids for ids in plan if len(ids) == self.bs]      # full batches only: one graph signature
+            self.plan, self.pos = parallel.plan_to_device(plan, self.device), 0
+        ids = self.plan[self.pos]
+        self.pos += 1
+        return ids
 
 
 def profile_collect(lib, cap):
@@ -144,6 +163,8 @@ def main():
     from consistent_depth_amd.monodepth.depth_model_registry import get_depth_model
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank, local_rank, world = parallel.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
@@ -163,18 +184,20 @@ def main():
     model.train()
     eager_step = FineTuneStep(model, params, world=world)
     step = GraphedFineTuneStep(eager_step, eager_steps=max(1, min(2, args.warmup - 1))) if args.graph else eager_step
-    pool = make_pool(args.pool, B, H, W, seed=rank + 1, device=device)
+    # the clip, resident in HBM on every rank (replicated like the reference's dataset on every DataLoader worker)
+    from consistent_depth_amd.loaders.pair_store import PairStore
+    store = PairStore.synthetic(args.frames, H, W, seed=0, device=device, max_pairs=args.max_pairs or None)
+    plans = EpochPlans(len(store), rank, world, B, device, seed=0)
+    log(f"pair store: {args.frames} frames, {len(store)} pairs, {store.nbytes / 1e9:.2f} GB resident")
 
-    def run(n, offset=0):
+    def run(n):
         last = None
-        for i in range(n):
-            images, meta, _, _ = pool[(offset + i) % len(pool)]
-            last, _ = step(images, meta)
+        for _ in range(n):
+            last, _, _ = step.step_from_store(store, plans.next())
         return last
 
-    log("pool ready; warm-up")
     for i in range(args.warmup):
-        run(1, offset=i)
+        run(1)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     if world > 1:
@@ -183,7 +206,7 @@ def main():
     if args.graph and getattr(step, "graphed", None) is None:
         # fewer warm-up steps than the capture needs (eager steps + 1): finish the one-time capture outside the timed region
         for i in range(4):
-            run(1, offset=args.warmup + i)
+            run(1)
             torch.cuda.synchronize()
             if step.graphed is not None:
                 break
@@ -194,7 +217,7 @@ def main():
     if not graphed:   # event records of the in-step loss profiler are not captured into graphs: eager only
         assert lib.cd_profile_begin(args.steps + 8) == 0
     t0 = time.perf_counter()
-    last_loss = run(args.steps, offset=args.warmup)
+    last_loss = run(args.steps)
     t_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (no sync inside the loop)
     torch.cuda.synchronize()
     if world > 1:
@@ -212,8 +235,7 @@ def main():
         if graphed:       # (an eager rank has had the profiler on since before the timed region)
             assert lib.cd_profile_begin(16) == 0
         for i in range(3):
-            images, meta, _, _ = pool[i % len(pool)]
-            eager_step(images, meta)
+            eager_step.step_from_store(store, plans.next())
         torch.cuda.synchronize()
     ms_step, _ = profile_collect(lib, 16 if graphed else args.steps + 8)
     if world > 1:
@@ -229,8 +251,9 @@ def main():
         "value": round(pairs_per_s, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"mc hourglass (random init, seed 0) test-time fine-tuning step, {H}x{W}, "
-                               f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{2 if args.backend == 'hip' else 1}]: "
+        "config": {"workload": f"mc hourglass (random init, seed 0) test-time fine-tuning steps over a synthetic {args.frames}-frame "
+                               f"{H}x{W} clip ({len(store)} pairs, hierarchical sampling, HBM-resident pair store, shared-seed shards), "
+                               f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{(3 if world > 1 else 2) if args.backend == 'hip' else 1}]: "
                                + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"),
                    "conv_backend": args.backend, "global_batch": B * world, "parallelism": f"dp{world}",
                    "hip_graph": graphed, "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),
@@ -256,10 +279,13 @@ def main():
         if not args.no_loss_microbench and len(ms):
             avg = float(np.mean(ms))
             ach = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch / (avg * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "loss_source_kernel + loss_gather4_kernel (one gradient launch)", "bound": "hbm", "achieved": round(ach, 1),
+            sweep = (H, W) == (384, 224) and args.loss_batch >= 96     # the default dispatch of cd_consistency_loss_fwd_bwd
+            out["roofline"] = {"kernel": "loss_sweep_kernel (row sweep: one workgroup per pair, one gradient launch)" if sweep else
+                                         "loss_source_kernel + loss_gather4_kernel (one gradient launch)",
+                               "bound": "hbm", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": (LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 * args.loss_batch if (H, W) == (384, 224) else None),
-                               "traffic_source": "profiles/rocprofv3_loss_slab_b256_r01.txt (PMC, separate passes; FETCH_SIZE x2 + WRITE_SIZE)",
+                               "traffic": (LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 * args.loss_batch if sweep else None),
+                               "traffic_source": "profiles/rocprofv3_loss_sweep_b256_r02.txt (PMC, separate passes; FETCH_SIZE x2 + WRITE_SIZE)",
                                "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
         if world == 1 and not args.no_cpu_baseline:
@@ -270,7 +296,12 @@ def main():
             import subprocess
             import tempfile
             cores = usable_cores()
-            _, _, b_np, images_np = pool[0]
+            ids0 = EpochPlans(len(store), 0, 1, B, device, seed=0).next()
+            im0, meta0 = store.batch(ids0)
+            g0 = meta0["geometry_consistency"]
+            images_np = im0.cpu().numpy()
+            b_np = {"flows": [f.cpu().numpy() for f in g0["flows"]], "masks": [m.cpu().numpy() for m in g0["masks"]],
+                    "intrinsics": meta0["intrinsics"].cpu().numpy(), "extrinsics": meta0["extrinsics"].cpu().numpy()}
             with tempfile.TemporaryDirectory() as td:
                 blob = os.path.join(td, "in.pkl")
                 with open(blob, "wb") as f:
@@ -285,8 +316,9 @@ def main():
                     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
                     sec = float([ln for ln in r.stdout.splitlines() if ln.startswith("SEC")][-1].split()[1])
                     out["cpu_baseline"] = {"value": round(B / sec, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                                           "sample": f"{args.cpu_steps} full steps (+1 warm-up) of the same BS{B} {H}x{W} workload: torch CPU fp32 "
-                                                     f"hourglass fwd+bwd (train-mode BN) + C-oracle loss + torch Adam, {sec:.2f} s/step, {cores} threads"}
+                                           "sample": f"{args.cpu_steps} full steps (+1 warm-up; per-step time extrapolated to pairs/s) on the first "
+                                                     f"BS{B} batch of the same clip: torch CPU fp32 hourglass fwd+bwd (train-mode BN) + "
+                                                     f"C-oracle loss + torch Adam, {sec:.2f} s/step, {cores} threads"}
                 except (subprocess.TimeoutExpired, IndexError, ValueError) as e:
                     out["cpu_baseline"] = {"value": None, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                            "sample": f"not completed within {args.cpu_timeout}s ({type(e).__name__})"}

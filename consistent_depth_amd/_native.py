@@ -35,6 +35,7 @@ SIGNATURES = {
     "cd_consistency_loss_fwd": (c_i, [c_p] * 8 + [c_f, c_f, c_i, c_i, c_i, c_i] + [c_p] * 3 + [c_p, c_sz, c_p]),
     "cd_profile_begin": (c_i, [c_i]),
     "cd_profile_end": (c_i, [c_p, c_p, c_i, c_p]),
+    "cd_gather_pairs": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "cd_sample_bilinear_border": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "cd_flow_consistency_masks": (c_i, [c_p, c_p, c_p, c_p, c_i, ctypes.c_double, ctypes.c_double, c_i, c_i, c_i, c_p, c_p, c_p]),
     "cd_warp_image": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),

@@ -140,9 +140,9 @@ class DepthFineTuner:
         for epoch in range(p.num_epochs):
             t0 = time.perf_counter()
             plan = parallel.shard_indices(len(store), epoch, self.seed, self.rank, self.world, p.batch_size)
+            plan_dev = parallel.plan_to_device(plan, store.device)   # the epoch's index lists: uploaded once
             for it, ids in enumerate(plan):
-                images, metadata = store.batch(ids)
-                loss, loss_meta = step(images, metadata)
+                loss, loss_meta, metadata = step.step_from_store(store, plan_dev[it])
                 total_iters += len(ids) * self.world
                 if p.print_freq > 0 and (it % max(1, p.print_freq) == 0) and self.rank == 0:
                     pairs = metadata["geometry_consistency"]["indices"].tolist()

@@ -50,6 +50,13 @@ class FineTuneStep:
         self.opt.step(grad_scale=1.0 / self.world, guard_loss=guard)
         return loss.detach(), parts
 
+    def step_from_store(self, store, pair_ids: torch.Tensor):
+        """One step on the pairs `pair_ids` (int64 device tensor) of a device-resident PairStore: the batch is gathered by
+        one HIP launch (cd_gather_pairs).  Returns (loss, parts, metadata)."""
+        images, metadata = store.batch(pair_ids)
+        loss, parts = self(images, metadata)
+        return loss, parts, metadata
+
     # -- the step split at the data-parallel exchange (GraphedFineTuneStep captures the two halves)
     def _grads(self, images, metadata):
         raw = self.model.estimate_raw(images)
@@ -117,7 +124,7 @@ class GraphedFineTuneStep:
 
     def __init__(self, step: FineTuneStep, eager_steps: int = 2):
         self.step, self.eager_steps = step, eager_steps
-        self._seen, self._graphs = {}, {}
+        self._seen, self._graphs, self._store_sig = {}, {}, {}
         self.graphed = None      # None: nothing captured yet; True / False after the first attempt
         self.capture_error = None
 
@@ -163,6 +170,24 @@ class GraphedFineTuneStep:
         if self.step.world > 1:
             self.step._update(g["guard"])
         return g["guard"].clone(), {k: v.clone() for k, v in g["parts"].items()}
+
+    def step_from_store(self, store, pair_ids: torch.Tensor):
+        """Like FineTuneStep.step_from_store; once the graph of this batch shape exists the pairs are gathered STRAIGHT into
+        its static input buffers (no intermediate batch, no copies) and the graph is replayed."""
+        skey = (id(store), int(pair_ids.numel()))
+        key = self._store_sig.get(skey)
+        g = self._graphs.get(key) if key is not None else None
+        if g is None:
+            images, metadata = store.batch(pair_ids)
+            self._store_sig[skey] = self._signature(images, metadata)
+            loss, parts = self(images, metadata)
+            return loss, parts, metadata
+        self._seen[key] = self._seen.get(key, 0) + 1
+        store.gather_into(pair_ids, g["images"], g["meta"])
+        g["graph"].replay()
+        if self.step.world > 1:
+            self.step._update(g["guard"])
+        return g["guard"].clone(), {k: v.clone() for k, v in g["parts"].items()}, g["meta"]
 
     def evaluate(self, images, metadata):
         return self.step.evaluate(images, metadata)

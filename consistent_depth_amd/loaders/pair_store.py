@@ -7,17 +7,37 @@ loader is the bottleneck, and 288 GB of HBM holds any realistic clip outright (2
 7.2 GB).  So the whole dataset is uploaded ONCE and mini-batches are gathered on the GPU:
 
     colour  (F,3,H,W) fp32      flows (P,2,2,H,W) fp32 [pair, direction, (dx,dy)]
-    masks   (P,2,1,H,W) fp32    mask_sums (P,2) fp32 (dataset constants, cached normalisers)
+    masks   (P,2,1,H,W) uint8   one byte per pixel like the reference's mask PNGs (video_dataset.py:71-77: `> 0` -> float);
+                                widened to the loss kernels' fp32 {0,1} by the gather: 34 H W bytes per pair resident
+                                instead of 40
+    mask_sums (P,2) fp32, tile_windows (P, bytes) uint8   dataset constants of the loss kernels (normalisers, source windows
+                                and row-sweep plans), computed once
     intrinsics (F,4), extrinsics (F,3,4), pair_frames (P,2) int64 (indices into F)
 
-`batch(pair_ids)` returns exactly what default_collate + to_device hand the reference's loop.
+`batch(pair_ids)` returns exactly what default_collate + to_device hand the reference's loop -- ONE HIP launch
+(cd_gather_pairs, csrc/store.hip) instead of file reads, numpy conversions and H2D copies; `gather_into` writes straight
+into the static input buffers of a captured step graph.
 """
 from __future__ import annotations
+
+import ctypes
 
 import numpy as np
 import torch
 
+from .. import _native
 from ..loss.consistency_loss import mask_sums as _mask_sums, tile_windows as _tile_windows
+
+
+class _StoreDesc(ctypes.Structure):     # cd_pair_store of include/consistent_depth_amd.h
+    _fields_ = [(n, ctypes.c_void_p) for n in ("color", "flows", "masks", "intrinsics", "extrinsics", "pair_frames", "frame_ids",
+                                               "mask_sums", "plans")] + \
+               [("plan_bytes", ctypes.c_int64)] + [(n, ctypes.c_int32) for n in ("F", "P", "H", "W", "mask_u8", "reserved")]
+
+
+class _BatchDesc(ctypes.Structure):     # cd_pair_batch
+    _fields_ = [(n, ctypes.c_void_p) for n in ("images", "flow_fwd", "flow_bwd", "mask_fwd", "mask_bwd", "intrinsics", "extrinsics",
+                                               "indices", "mask_sums", "plans")]
 
 
 class PairStore:
@@ -27,12 +47,13 @@ class PairStore:
         self.device = dev
         self.color = f32(color)
         self.flows = f32(flows)
-        self.masks = f32(masks)
+        self.masks = (torch.as_tensor(np.ascontiguousarray(masks)) > 0).to(torch.uint8).to(dev).contiguous()
         self.intrinsics = f32(intrinsics)
         self.extrinsics = f32(extrinsics)
         self.pair_frames = torch.as_tensor(np.asarray(pair_frames), dtype=torch.int64).to(dev)
         # original frame numbers (for file names / logs); row r of colour is frame frame_ids[r]
         self.frame_ids = list(frame_ids) if frame_ids is not None else list(range(self.color.shape[0]))
+        self._frame_ids_dev = torch.as_tensor(self.frame_ids, dtype=torch.int64).to(dev)
         P = self.flows.shape[0]
         assert self.masks.shape[0] == P and self.pair_frames.shape == (P, 2)
         self._refresh_constants()
@@ -44,10 +65,11 @@ class PairStore:
         wins = []
         for s in range(0, P, 256):
             fl = [self.flows[s:s + 256, 0].contiguous(), self.flows[s:s + 256, 1].contiguous()]
-            mk = [self.masks[s:s + 256, 0].contiguous(), self.masks[s:s + 256, 1].contiguous()]
+            mk = [self.masks[s:s + 256, 0].float().contiguous(), self.masks[s:s + 256, 1].float().contiguous()]
             self.mask_sums[s:s + 256] = _mask_sums(mk[0], mk[1])
             wins.append(_tile_windows(fl, mk))
-        self.tile_windows = torch.cat(wins, 0)  # (P, bytes_per_pair) uint8
+        self.tile_windows = torch.cat(wins, 0).contiguous()  # (P, bytes_per_pair) uint8
+        self._desc = None
 
     def rebuild_masks(self, flow_thresh: float = 1.0, color_thresh: float = 1.0):
         """Recompute the flow-consistency masks of every pair ON THE DEVICE from the resident flows and colours -- the
@@ -60,8 +82,8 @@ class PairStore:
             m0, m1 = consistency.consistent_flow_masks_batch(
                 self.flows[s:s + 256, 0].contiguous(), self.flows[s:s + 256, 1].contiguous(),
                 self.color[pf[:, 0]], self.color[pf[:, 1]], flow_thresh, color_thresh)
-            self.masks[s:s + 256, 0] = m0
-            self.masks[s:s + 256, 1] = m1
+            self.masks[s:s + 256, 0] = (m0 > 0).to(torch.uint8)
+            self.masks[s:s + 256, 1] = (m1 > 0).to(torch.uint8)
         self._refresh_constants()
         return self
 
@@ -77,25 +99,59 @@ class PairStore:
         pf = self.pair_frames.cpu().numpy()
         return [[self.frame_ids[a], self.frame_ids[b]] for a, b in pf]
 
-    def batch(self, pair_ids):
-        ids = torch.as_tensor(pair_ids, dtype=torch.int64, device=self.device)
-        fr = self.pair_frames[ids]                       # (B,2)
-        images = self.color[fr]                          # (B,2,3,H,W)
-        fl = self.flows[ids]                             # (B,2,2,H,W)
-        mk = self.masks[ids]                             # (B,2,1,H,W)
-        fid = torch.as_tensor(self.frame_ids, dtype=torch.int64, device=self.device)
+    def _store_desc(self):
+        if self._desc is None:
+            F, _, H, W = self.color.shape
+            d = _StoreDesc(self.color.data_ptr(), self.flows.data_ptr(), self.masks.data_ptr(), self.intrinsics.data_ptr(),
+                           self.extrinsics.data_ptr(), self.pair_frames.data_ptr(), self._frame_ids_dev.data_ptr(),
+                           self.mask_sums.data_ptr(), self.tile_windows.data_ptr(), self.tile_windows.shape[1], F, len(self), H, W, 1, 0)
+            self._desc = d
+        return self._desc
+
+    def new_batch_buffers(self, B: int):
+        """(images, metadata) tensors of a batch of B pairs, in the layout `batch` returns (contents undefined)."""
+        _, _, H, W = self.color.shape
+        dev = self.device
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        images = f(B, 2, 3, H, W)
         metadata = {
-            "extrinsics": self.extrinsics[fr],
-            "intrinsics": self.intrinsics[fr],
+            "extrinsics": f(B, 2, 3, 4),
+            "intrinsics": f(B, 2, 4),
             "geometry_consistency": {
-                "indices": fid[fr],
-                "flows": [fl[:, 0].contiguous(), fl[:, 1].contiguous()],
-                "masks": [mk[:, 0].contiguous(), mk[:, 1].contiguous()],
-                "mask_sums": self.mask_sums[ids],
-                "tile_windows": self.tile_windows[ids].contiguous(),
+                "indices": torch.empty(B, 2, dtype=torch.int64, device=dev),
+                "flows": [f(B, 2, H, W), f(B, 2, H, W)],
+                "masks": [f(B, 1, H, W), f(B, 1, H, W)],
+                "mask_sums": f(B, 2),
+                "tile_windows": torch.empty(B, self.tile_windows.shape[1], dtype=torch.uint8, device=dev),
             },
         }
         return images, metadata
+
+    def gather_into(self, pair_ids: torch.Tensor, images: torch.Tensor, metadata: dict):
+        """Fill existing batch buffers (e.g. the static inputs of a captured step graph) with the pairs `pair_ids`
+        (int64 tensor on the device) -- one launch, no host synchronisation."""
+        if pair_ids.dtype != torch.int64 or not pair_ids.is_cuda or not pair_ids.is_contiguous():
+            raise ValueError("pair_ids must be a contiguous int64 tensor on the HIP device")
+        B = pair_ids.numel()
+        geom = metadata["geometry_consistency"]
+        tensors = [images, geom["flows"][0], geom["flows"][1], geom["masks"][0], geom["masks"][1], metadata["intrinsics"],
+                   metadata["extrinsics"], geom["indices"], geom["mask_sums"], geom["tile_windows"]]
+        _, _, H, W = self.color.shape
+        shapes = [(B, 2, 3, H, W), (B, 2, H, W), (B, 2, H, W), (B, 1, H, W), (B, 1, H, W), (B, 2, 4), (B, 2, 3, 4), (B, 2), (B, 2),
+                  (B, self.tile_windows.shape[1])]
+        for t, shp in zip(tensors, shapes):
+            if tuple(t.shape) != shp or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"batch buffer of shape {tuple(t.shape)}: expected contiguous {shp} on {self.device}")
+        out = _BatchDesc(*[t.data_ptr() for t in tensors])
+        rc = _native.lib().cd_gather_pairs(ctypes.byref(self._store_desc()), pair_ids.data_ptr(), B, ctypes.byref(out),
+                                           _native.stream_ptr(self.device))
+        _native.check(rc, "cd_gather_pairs")
+        return images, metadata
+
+    def batch(self, pair_ids):
+        ids = torch.as_tensor(pair_ids, dtype=torch.int64, device=self.device).contiguous()
+        images, metadata = self.new_batch_buffers(ids.numel())
+        return self.gather_into(ids, images, metadata)
 
     @classmethod
     def from_directory(cls, path: str, meta_file: str, device=None):

@@ -67,6 +67,19 @@ def broadcast_(tensors, src: int = 0):
             dist.broadcast(t, src)
 
 
+def plan_to_device(plan, device):
+    """The per-step index lists of an epoch as int64 device tensors (ONE upload; slices of a padded matrix)."""
+    if not plan:
+        return []
+    import numpy as np
+    width = max(len(ids) for ids in plan)
+    mat = np.zeros((len(plan), width), np.int64)
+    for r, ids in enumerate(plan):
+        mat[r, :len(ids)] = ids
+    dev = torch.as_tensor(mat).to(device)
+    return [dev[r, :len(ids)].contiguous() for r, ids in enumerate(plan)]
+
+
 def shard_indices(n_items: int, epoch: int, seed: int, rank: int, world: int, batch_size: int, shuffle: bool = True):
     """Pair indices this rank trains on in `epoch`.
 

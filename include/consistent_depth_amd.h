@@ -139,6 +139,39 @@ int cd_debug_set_loss_sweep(int pixels_per_thread);
  * to stay resident in the Infinity Cache).  Changes cd_consistency_loss_workspace_bytes(); set it before the query. */
 int cd_debug_set_loss_chunk(int pairs);
 
+/* ------------------------------------------------------------------------------------
+ * Device-resident frame-pair store: mini-batch gather  (reference: loaders/video_dataset.py:131-207
+ * __getitem__ + default collate + utils/torch_helpers.py:10-23 to_device -- file reads and H2D copies per step;
+ * here the dataset is uploaded once and a batch is ONE launch copying 12 H W floats per pair)
+ * ---------------------------------------------------------------------------------- */
+typedef struct cd_pair_store {
+    const float* color;          /* [F][3][H][W] RGB in [0,1]                                   */
+    const float* flows;          /* [P][2][2][H][W] (pair, direction fwd/bwd, (dx, dy)) pixels   */
+    const void* masks;           /* [P][2][H][W] uint8 (mask_u8 = 1; nonzero = valid, as in the reference's PNGs) or fp32 {0,1} */
+    const float* intrinsics;     /* [F][4] fx, fy, cx, cy                                        */
+    const float* extrinsics;     /* [F][3][4] [R|t] camera-to-world                              */
+    const int64_t* pair_frames;  /* [P][2] rows of the two frames of each pair                   */
+    const int64_t* frame_ids;    /* [F] original frame numbers for metadata "indices", or NULL   */
+    const float* mask_sums;      /* [P][2] cd_mask_sums per pair, or NULL                        */
+    const uint8_t* plans;        /* [P][plan_bytes] cd_tile_windows per pair (B = 1 records), or NULL */
+    int64_t plan_bytes;
+    int32_t F, P, H, W, mask_u8, reserved;
+} cd_pair_store;
+typedef struct cd_pair_batch {   /* destinations, laid out like the reference's collated batch   */
+    float* images;               /* [B][2][3][H][W]                                              */
+    float* flow_fwd;             /* [B][2][H][W]   metadata["geometry_consistency"]["flows"][0]  */
+    float* flow_bwd;             /* [B][2][H][W]                                  ["flows"][1]   */
+    float* mask_fwd;             /* [B][1][H][W]   fp32 {0,1}                     ["masks"][0]   */
+    float* mask_bwd;             /* [B][1][H][W]                                  ["masks"][1]   */
+    float* intrinsics;           /* [B][2][4]                                                    */
+    float* extrinsics;           /* [B][2][3][4]                                                 */
+    int64_t* indices;            /* [B][2] or NULL                                               */
+    float* mask_sums;            /* [B][2] or NULL                                               */
+    uint8_t* plans;              /* [B][plan_bytes] or NULL                                      */
+} cd_pair_batch;
+/* pair_ids: B int64 rows of the store ON THE DEVICE (an epoch's index lists are uploaded once). */
+int cd_gather_pairs(const cd_pair_store* store, const int64_t* pair_ids, int B, const cd_pair_batch* batch, void* stream);
+
 /* utils/geometry.py:201-208 `sample`: bilinear, border padding, align_corners=False on an
  * align_corners=True style normalisation.  data [B,C,H,W], uv [B,2,H,W] px -> out [B,C,H,W]. */
 int cd_sample_bilinear_border(const float* data, const float* uv, int B, int C, int H, int W,

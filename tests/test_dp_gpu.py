@@ -62,3 +62,53 @@ def test_two_ranks_share_one_gpu_and_stay_in_sync(tmp_path, graph):
         assert res["graphed"] is True, res["capture_error"]
     assert res["same_weights"], "ranks diverged: the gradient all-reduce / guarded Adam are not in lock-step"
     assert all(l == l for l in res["losses"])
+
+
+NCCL_WORKER = r"""
+import argparse, json, os, sys, torch
+sys.path.insert(0, %(repo)r)
+import torch.distributed as dist
+from consistent_depth_amd import parallel, synthetic
+from consistent_depth_amd.engine import FineTuneStep, GraphedFineTuneStep
+from consistent_depth_amd.monodepth.depth_model_registry import get_depth_model
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # the branch parallel.init takes on a multi-GPU node
+params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0, learning_rate=4e-4, optimizer="Adam")
+model = get_depth_model("mc")(seed=0); model.train()
+eager = FineTuneStep(model, params, world=1)
+step = GraphedFineTuneStep(eager, eager_steps=1)
+t = lambda a: torch.tensor(a, device=dev)
+b = synthetic.make_scene_batch(2, 64, 48, seed=1)
+imgs = torch.rand(2, 2, 3, 64, 48, device=dev)
+meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
+        "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
+# the data-parallel exchange on the REAL buffer: [flat grads | loss slot], one RCCL call, in place
+guard, _ = eager._grads(imgs, meta)
+eager.opt.loss_slot.copy_(guard.reshape(1))
+before = eager.opt.reduce_buffer.clone()
+dist.all_reduce(eager.opt.reduce_buffer, op=dist.ReduceOp.SUM)
+torch.cuda.synchronize()
+same = torch.equal(before, eager.opt.reduce_buffer)       # world 1: the sum is the buffer itself
+eager._update(eager.opt.loss_slot)
+losses = [step(imgs, meta)[0].item() for _ in range(4)]   # graph capture with RCCL's watchdog thread alive
+print("RESULT " + json.dumps({"backend": dist.get_backend(), "allreduce_identity": same, "losses": losses,
+                              "graphed": step.graphed, "capture_error": step.capture_error, "bytes": eager.opt.reduce_buffer.numel() * 4}))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_rccl_one_rank_smoke(tmp_path):
+    """RCCL itself (torch.distributed backend "nccl" on ROCm) on this box's single GPU: process-group init with device_id, the
+    flat gradient all-reduce on the optimiser's real buffer, then eager + graph-replayed steps with the communicator alive.
+    (Two ranks cannot share a device under RCCL; the 2-rank logic above runs over gloo.)"""
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER % {"repo": REPO})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert lines, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads(lines[-1][len("RESULT "):])
+    assert res["backend"] == "nccl" and res["allreduce_identity"] and res["bytes"] > 20e6
+    assert res["graphed"] is True, res["capture_error"]
+    assert all(l == l for l in res["losses"])

@@ -67,4 +67,4 @@ def test_pair_store_rebuilds_its_masks_on_the_device():
         ref, _ = masks_oracle.consistent_flow_masks(flows, colors, 1.0, 1.0)
         for k in range(2):
             np.testing.assert_array_equal(store.masks[p, k, 0].cpu().numpy() > 0.5, ref[k])
-    torch.testing.assert_close(store.mask_sums, store.masks.sum((2, 3, 4)))
+    torch.testing.assert_close(store.mask_sums, store.masks.float().sum((2, 3, 4)))
