@@ -12,7 +12,7 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 
 _lib = None
@@ -52,7 +52,7 @@ SIGNATURES = {
     "cd_debug_set_wgrad_mode": (c_i, [c_i]),
     "cd_conv2d_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),
     "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
-    "cd_conv2d_wgrad_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
+    "cd_conv2d_wgrad_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
     "cd_conv2d_wgrad_unpack_table": (c_i, [c_p, c_i, c_p]),
     "cd_bn_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "cd_bn_finalize": (c_i, [c_p, c_i, c_i, c_i, ctypes.c_double, c_f, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),

@@ -12,9 +12,11 @@
 // A block stages a TY x 32 pixel tile of dY (CO_T*16 channels) and of the input (CI_T*16 channels,
 // + halo) in LDS; its 4 waves partition the accumulator set (taps for k >= 5, co x ci tiles for k <= 3 -- never
 // the pixels) and keep one accumulator tile per owned (tap, co tile, ci tile) in registers while the block walks all the
-// image tiles assigned to it (grid-stride over (image, tile)); partial sums are flushed ONCE per block
-// with fp32 atomics into a zeroed packed buffer [co grp][ci grp][tap][co][ci] (64-byte contiguous per
-// (tap, co)), which unpack_wgrad_kernel transposes into the [Cout][Cin][k][k] gradient.
+// image tiles assigned to it (grid-stride over (image, tile)); every block ("split" s of its channel group) stores its
+// partial sums ONCE, with plain stores, into ITS OWN slice of the workspace [split][co grp][ci grp][tap][co][ci]; the unpack
+// kernels add the slices in split order (fp64 accumulator) while transposing into the [Cout][Cin][k][k] gradient.
+// No atomics, no zero-initialised workspace, and the sum has ONE fixed order: the weight gradient is bit-reproducible
+// (round 1 flushed with fp32 atomics -- memory-side on MI355X, ~4x the cost of a store, and order-dependent).
 #include "cd_common.h"
 
 namespace cd {
@@ -261,9 +263,10 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
         }
     }
 
-    // ---- flush: packed [cog][cig][tap][COB][CIB]
+    // ---- flush: this block's slice, packed [split][cog][cig][tap][COB][CIB]
     if (dbg & 1) return;   // measurement hook (cd_debug_set_wgrad_mode): skip the flush
-    const size_t base = ((size_t)cog * gridDim.y + cig) * TAPS * COB * CIB;
+    const size_t slice = (size_t)gridDim.z * gridDim.y * TAPS * COB * CIB;
+    const size_t base = (size_t)blockIdx.x * slice + ((size_t)cog * gridDim.y + cig) * TAPS * COB * CIB;
     const int ci_l = lane & 15, co4 = (lane >> 4) * 4;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -275,25 +278,47 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(
                 for (int c = 0; c < CPW; ++c) {
                     float* dst = dw_packed + base + ((size_t)tap * COB + (a * NW_A + wa) * 16 + co4) * CIB + (c * NW_C + wc) * 16 + ci_l;
                     const f32x4 v = acc[t][a][c];
-                    atomic_add_f32(dst, v.x);
-                    atomic_add_f32(dst + CIB, v.y);
-                    atomic_add_f32(dst + 2 * CIB, v.z);
-                    atomic_add_f32(dst + 3 * CIB, v.w);
+                    dst[0] = v.x; dst[CIB] = v.y; dst[2 * CIB] = v.z; dst[3 * CIB] = v.w;
                 }
         }
     }
 }
 
-// packed [cog][cig][tap][COB][CIB] -> dW[Cout][Cin][KS][KS]  (accumulate = 0: overwrite, 1: add)
-__global__ void unpack_wgrad_kernel(const float* __restrict__ packed, int Cout, int Cin, int KS, int COB, int CIB,
-                                    int ci_groups, float* __restrict__ dw, int accumulate) {
-    const int total = Cout * Cin * KS * KS, taps = KS * KS;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int tap = i % taps, ci = (i / taps) % Cin, co = i / (taps * Cin);
-        const int cog = co / COB, cig = ci / CIB;
-        const float v = packed[(((size_t)cog * ci_groups + cig) * taps + tap) * COB * CIB + (size_t)(co - cog * COB) * CIB + (ci - cig * CIB)];
-        dw[i] = accumulate ? dw[i] + v : v;
+// the slices of one packed element, added in ONE fixed order (4 interleaved fp64 chains over the splits, combined at the
+// end: the loads of a chain do not wait for each other)
+__device__ __forceinline__ float sum_splits(const float* __restrict__ p, int splits, size_t stride) {
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+        const float a = p[(size_t)s * stride], b = p[(size_t)(s + 1) * stride], c = p[(size_t)(s + 2) * stride], d = p[(size_t)(s + 3) * stride];
+        v0 += (double)a; v1 += (double)b; v2 += (double)c; v3 += (double)d;
     }
+    for (; s < splits; ++s) v0 += (double)p[(size_t)s * stride];
+    return (float)((v0 + v1) + (v2 + v3));
+}
+
+// One gradient tensor dw[rows][Cin][KS][KS] from the output-channel rows [row0, row0 + rows) of a packed buffer.  Threads
+// walk the PACKED order (input channel fastest: 64-byte runs of every slice are read by neighbouring lanes); the transposed
+// write into dw happens once per element, the reads `splits` times.
+__device__ __forceinline__ void unpack_rows(const float* __restrict__ packed, float* __restrict__ dw, int Cin, int ks, int cob,
+                                            int cib, int ci_groups, int row0, int rows, int accumulate, int splits,
+                                            size_t split_stride, int first, int step) {
+    const int taps = ks * ks, total = rows * Cin * taps;
+    for (int j = first; j < total; j += step) {
+        const int ci = j % Cin, r = (j / Cin) % rows, tap = j / (Cin * rows);
+        const int co = row0 + r, cog = co / cob, cig = ci / cib;
+        const float v = sum_splits(packed + (((size_t)cog * ci_groups + cig) * taps + tap) * cob * cib + (size_t)(co - cog * cob) * cib + (ci - cig * cib),
+                                   splits, split_stride);
+        float* d = dw + ((size_t)r * Cin + ci) * taps + tap;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+// packed [split][cog][cig][tap][COB][CIB] -> dW[Cout][Cin][KS][KS]  (accumulate = 0: overwrite, 1: add)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ packed, int Cout, int Cin, int KS, int COB, int CIB,
+                                    int ci_groups, int splits, size_t split_stride, float* __restrict__ dw, int accumulate) {
+    unpack_rows(packed, dw, Cin, KS, COB, CIB, ci_groups, 0, Cout, accumulate, splits, split_stride,
+                blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ---------------------------------------------------------------- few input channels (the RGB stem)
@@ -388,19 +413,25 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_fewcin_kernel(
             }
         }
     }
-    if (!q_live) return;   // (after the last barrier) padding columns carry garbage by construction
-    const size_t base = (size_t)cog * TAPS * COB * CIB;
+    if (!q_live) return;   // (after the last barrier) padding columns carry garbage by construction; the unpack never reads them
+    const size_t base = (size_t)blockIdx.x * ((size_t)gridDim.z * TAPS * COB * CIB) + (size_t)cog * TAPS * COB * CIB;
     const int co4 = wa * 16 + (lane >> 4) * 4;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
         float* dst = dw_packed + base + ((size_t)(ky * KS + q_kx) * COB + co4) * CIB + q_ci;
         const f32x4 v = acc[ky];
-        atomic_add_f32(dst, v.x);
-        atomic_add_f32(dst + CIB, v.y);
-        atomic_add_f32(dst + 2 * CIB, v.z);
-        atomic_add_f32(dst + 3 * CIB, v.w);
+        dst[0] = v.x; dst[CIB] = v.y; dst[2 * CIB] = v.z; dst[3 * CIB] = v.w;
     }
 }
+
+// Blocks ("splits") per channel group: enough to fill the chip -- ~2 per CU where the LDS tiles allow 2 resident blocks, 1 for
+// the wide 1x1 shapes.  ONE definition: the launchers, the workspace size and cd_conv2d_wgrad_plan must agree.
+static inline int wgrad_splits(int groups, int per_cu, int items) {
+    int splits = (256 * per_cu + groups - 1) / groups;
+    if (splits > items) splits = items;
+    return splits < 1 ? 1 : splits;
+}
+static inline int wgrad_items(int N, int H, int W, int ty) { return N * ((W + WG_TX - 1) / WG_TX) * ((H + ty - 1) / ty); }
 
 template <int KS>
 static int launch_wgrad_fewcin(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift,
@@ -408,8 +439,7 @@ static int launch_wgrad_fewcin(const float* x, int x_ctot, int x_coff, int Cin, 
                                int W, hipStream_t s) {
     const int tiles_x = (W + WG_TX - 1) / WG_TX, tiles_y = (H + 7) / 8;
     const int cogs = (Cout + 31) / 32, items = N * tiles_x * tiles_y;
-    int splits = (256 * 3 + cogs - 1) / cogs;
-    if (splits > items) splits = items;
+    const int splits = wgrad_splits(cogs, 3, items);
     hipLaunchKernelGGL((conv_wgrad_fewcin_kernel<KS>), dim3(splits, 1, cogs), dim3(kBlock), 0, s, x, x_ctot, x_coff, Cin, in_scale,
                        in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
@@ -425,19 +455,14 @@ static int g_wgrad_dbg = 0;   // measurement hook: bit 0 skip the atomic flush, 
 // nn.Conv2d weights).
 struct UnpackDesc {
     const float* packed; float* dw;
-    int Cin, ks, cob, cib, ci_groups, row0, rows, accumulate;
+    int Cin, ks, cob, cib, ci_groups, row0, rows, accumulate, splits, split_stride;   // split_stride in floats
 };
-static_assert(sizeof(UnpackDesc) == 48, "cd_unpack_desc layout");
+static_assert(sizeof(UnpackDesc) == 56, "cd_unpack_desc layout");
 
 __global__ void unpack_wgrad_table_kernel(const UnpackDesc* __restrict__ table) {
     const UnpackDesc d = table[blockIdx.y];
-    const int taps = d.ks * d.ks, total = d.rows * d.Cin * taps;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int tap = i % taps, ci = (i / taps) % d.Cin, co = d.row0 + i / (taps * d.Cin);
-        const int cog = co / d.cob, cig = ci / d.cib;
-        const float v = d.packed[(((size_t)cog * d.ci_groups + cig) * taps + tap) * d.cob * d.cib + (size_t)(co - cog * d.cob) * d.cib + (ci - cig * d.cib)];
-        d.dw[i] = d.accumulate ? d.dw[i] + v : v;
-    }
+    unpack_rows(d.packed, d.dw, d.Cin, d.ks, d.cob, d.cib, d.ci_groups, d.row0, d.rows, d.accumulate, d.splits, (size_t)d.split_stride,
+                blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 struct WgPlan { int co_t, ci_t; };
@@ -485,9 +510,7 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
     // enough blocks to fill the chip (~2 per CU: the LDS tiles allow 2 resident blocks; 1 for the wide 1x1 shapes), few
     // enough that the atomic flush of the partial sums (one per block, all splits hit the same addresses) stays small
     constexpr int per_cu = (CO_T + CI_T > 16) ? 1 : 2;
-    int splits = (256 * per_cu + cogs * cigs - 1) / (cogs * cigs);
-    if (splits > items) splits = items;
-    if (splits < 1) splits = 1;
+    const int splits = wgrad_splits(cogs * cigs, per_cu, items);
     const size_t lds = sizeof(float) * ((size_t)COB * Cfg::PS_DY + (size_t)CIB * Cfg::PS_IN);
     static bool attr_set = false;
     if (!attr_set) {
@@ -498,6 +521,24 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
     hipLaunchKernelGGL((conv_wgrad_kernel<KS, CO_T, CI_T>), dim3(splits, cigs, cogs), dim3(kBlock), lds, s, x, x_ctot, x_coff,
                        Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y, g_wgrad_dbg);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+// Packed layout and launch shape of one weight gradient -- ONE definition for the launchers, the workspace size,
+// cd_conv2d_wgrad_plan and the unpack descriptors.
+struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide; size_t slice; };
+static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W) {
+    WgLayout L;
+    WgPlan p = wgrad_plan(ks, Cout, Cin);
+    L.wide = (N > 0 && g_wgrad_wide && wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p)) ? 1 : 0;
+    L.fewcin = (ks == 7 && Cin <= 4 && p.co_t == 2 && !(g_wgrad_dbg & 8)) ? 1 : 0;
+    L.cob = p.co_t * 16; L.cib = p.ci_t * 16;
+    L.cogs = (Cout + L.cob - 1) / L.cob; L.cigs = L.fewcin ? 1 : (Cin + L.cib - 1) / L.cib;
+    L.slice = (size_t)L.cogs * L.cigs * ks * ks * L.cob * L.cib;
+    const int per_cu = L.fewcin ? 3 : ((p.co_t + p.ci_t > 16) ? 1 : 2);
+    const int ty = (ks == 1) ? ((p.co_t + p.ci_t > 16) ? 2 : 4) : 8;
+    L.max_splits = wgrad_splits(L.cogs * L.cigs, per_cu, 1 << 30);
+    L.splits = N > 0 ? wgrad_splits(L.cogs * L.cigs, per_cu, wgrad_items(N, H, W, ty)) : L.max_splits;
+    return L;
 }
 
 }  // namespace cd
@@ -512,30 +553,32 @@ int cd_debug_set_wgrad_mode(int bits) {
 
 size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
-    const cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
-    const int cob = p.co_t * 16, cib = p.ci_t * 16;
-    size_t n = (size_t)((Cout + cob - 1) / cob) * ((Cin + cib - 1) / cib) * ks * ks * cob * cib;
+    // every block owns a slice: the largest number of blocks per channel group the launcher can choose, for either 1x1 layout
+    const cd::WgLayout a = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0);
+    size_t n = a.slice * (size_t)a.max_splits;
     cd::WgPlan w;
     if (cd::wgrad_wide_plan(ks, Cout, Cin, 1 << 20, 2, 32, &w)) {   // the wide 1x1 layout (chosen per launch by the image size)
         const int wob = w.co_t * 16, wib = w.ci_t * 16;
-        const size_t m = (size_t)((Cout + wob - 1) / wob) * ((Cin + wib - 1) / wib) * wob * wib;
+        const size_t groups = (size_t)((Cout + wob - 1) / wob) * ((Cin + wib - 1) / wib);
+        const size_t m = groups * wob * wib * (size_t)cd::wgrad_splits((int)groups, (w.co_t + w.ci_t > 16) ? 1 : 2, 1 << 30);
         if (m > n) n = m;
     }
     return n;
 }
 
-int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib) {
-    if (!cob || !cib || cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) == 0 || N <= 0 || H <= 0 || W <= 0) return CD_ERR_INVALID_ARG;
-    cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
-    if (cd::g_wgrad_wide) (void)cd::wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p);
-    *cob = p.co_t * 16;
-    *cib = p.ci_t * 16;
+int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib, int* splits) {
+    if (!cob || !cib || !splits || cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) == 0 || N <= 0 || H <= 0 || W <= 0) return CD_ERR_INVALID_ARG;
+    const cd::WgLayout L = cd::wgrad_layout(Cout, Cin, ks, N, H, W);
+    *cob = L.cob;
+    *cib = L.cib;
+    *splits = L.splits;
     return CD_OK;
 }
 
 int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream) {
     if (!table_dev || n <= 0 || n > 65535) return CD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(cd::unpack_wgrad_table_kernel, dim3(8, n), dim3(256), 0, (hipStream_t)stream, (const cd::UnpackDesc*)table_dev);
+    // 48 workgroups per gradient tensor: the reads of the per-workgroup slices (2 GB per hourglass step) need the whole chip
+    hipLaunchKernelGGL(cd::unpack_wgrad_table_kernel, dim3(48, n), dim3(256), 0, (hipStream_t)stream, (const cd::UnpackDesc*)table_dev);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -548,10 +591,10 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     const size_t wsf = cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks);
     if (wsf == 0) return CD_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    // accumulate bit 1 (value 2): the caller has already zeroed `workspace` (one memset over an arena of many)
-    if (!(accumulate & 2) && hipMemsetAsync(workspace, 0, wsf * sizeof(float), s) != hipSuccess) return CD_ERR_LAUNCH;
+    // (the workspace needs no initialisation: every block writes its whole slice; bit 1 of `accumulate` is accepted and ignored)
     cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
     const bool wide = cd::g_wgrad_wide && cd::wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p);
+    const cd::WgLayout L = cd::wgrad_layout(Cout, Cin, ks, N, H, W);
     int rc = CD_ERR_UNSUPPORTED;
 #define CD_WG(K, A, C) rc = cd::launch_wgrad_t<K, A, C>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, s)
     if (ks == 11) CD_WG(11, 1, 1);
@@ -587,7 +630,7 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     const int cob = p.co_t * 16, cib = p.ci_t * 16;
     const int total = Cout * Cin * ks * ks;
     hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
-                       workspace, Cout, Cin, ks, cob, cib, (Cin + cib - 1) / cib, dw, accumulate & 1);
+                       workspace, Cout, Cin, ks, cob, cib, L.cigs, L.splits, L.slice, dw, accumulate & 1);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -318,20 +318,27 @@ __global__ __launch_bounds__(kBlock) void add_slice_kernel(const float* __restri
     }
 }
 
-// out[c] (+)= sum over n, y, x of src[n][coff+c]   (bias gradient of a conv that is NOT followed by BatchNorm).
-// grid (chunks, C): block partials are combined with fp32 atomics into out (zeroed first unless accumulating).
+// out[c] (+)= sum over n, y, x of src[n][coff+c]   (bias gradient of a conv that is NOT followed by BatchNorm: in the
+// hourglass only the 1-channel head).  ONE workgroup per channel, fixed summation order (per-thread strided sums in 4
+// independent fp32 chains, then a fp64 tree): bit-reproducible, unlike the fp32-atomic combination of round 1.
 __global__ __launch_bounds__(kBlock) void channel_sum_kernel(const float* __restrict__ src, int ctot, int coff, int N,
-                                                             int HW, float* __restrict__ out) {
-    __shared__ float lds[kBlock / kWave];
+                                                             int HW, float* __restrict__ out, int accumulate) {
+    __shared__ double lds[kBlock];
     const int c = blockIdx.y;
-    float acc = 0.f;
-    const long long total = (long long)N * HW;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
-        const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
-        acc += src[((size_t)n * ctot + coff + c) * HW + p];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* pl = src + ((size_t)n * ctot + coff + c) * HW;
+        int p = threadIdx.x;
+        for (; p + 3 * kBlock < HW; p += 4 * kBlock) { a0 += pl[p]; a1 += pl[p + kBlock]; a2 += pl[p + 2 * kBlock]; a3 += pl[p + 3 * kBlock]; }
+        for (; p < HW; p += kBlock) a0 += pl[p];
     }
-    acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) atomic_add_f32(&out[c], acc);
+    lds[threadIdx.x] = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)lds[0] : (float)lds[0];
 }
 
 static inline dim3 plane_grid(int HW, int C, int N, int per_thread) {
@@ -440,11 +447,8 @@ int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_cto
 int cd_channel_sum(const float* src, int ctot, int coff, int C, int N, int H, int W, float* out, int accumulate,
                    void* stream) {
     CD_ARGCHK(src && out && C > 0 && coff + C <= ctot);
-    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream) != hipSuccess) return CD_ERR_LAUNCH;
-    long long chunks = ((long long)N * H * W + cd::kBlock * 16 - 1) / (cd::kBlock * 16);
-    if (chunks > 256) chunks = 256;
-    hipLaunchKernelGGL(cd::channel_sum_kernel, dim3((unsigned)chunks, C), dim3(cd::kBlock), 0, (hipStream_t)stream, src, ctot,
-                       coff, N, H * W, out);
+    hipLaunchKernelGGL(cd::channel_sum_kernel, dim3(1, C), dim3(cd::kBlock), 0, (hipStream_t)stream, src, ctot,
+                       coff, N, H * W, out, accumulate);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -436,8 +436,8 @@ class HourglassEngine:
         return plan
 
     def _carve_arenas(self, plan):
-        """One arena for all wgrad workspaces and one for all BN-backward sums: two memsets per backward
-        instead of two per convolution."""
+        """One arena for all wgrad workspaces (per-workgroup partial sums, written whole by every launch: never zeroed) and
+        one for all BN-backward sums (one memset per backward)."""
         units = plan["convs"]
         sizes = [(C.wgrad_workspace_floats(u.cout, u.cin, u.ks) + 63) // 64 * 64 for u in units]
         plan["wgrad_arena"] = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
@@ -461,7 +461,7 @@ class HourglassEngine:
             layout = C.wgrad_plan(u.cout, u.cin, u.ks, N, h, w)
             if isinstance(u, PointwiseGroup):   # the fused gradient's rows belong to the members' weights
                 for m in u.members:
-                    unpack.add(u.wgrad_ws, (lambda m=m: _grad_of(m.conv.weight)), u.cin, 1, layout, row0=m.coff)
+                    unpack.add(u.wgrad_ws, (lambda m=m: _grad_of(m.conv.weight)), u.cin, 1, layout, row0=m.coff, cout_total=u.cout)
             else:
                 unpack.add(u.wgrad_ws, (lambda u=u: _grad_of(u.conv.weight)), u.cin, u.ks, layout)
 
@@ -538,7 +538,6 @@ class HourglassEngine:
     def _backward(self, dpred: torch.Tensor):
         plan = self._last
         plan["dpred"].copy_(dpred.reshape(plan["dpred"].shape))
-        plan["wgrad_arena"].zero_()
         plan["sums_arena"].zero_()
         for a in plan["acts"]:  # first gradient contribution overwrites, later ones accumulate
             a.grad_written = False

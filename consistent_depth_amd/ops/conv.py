@@ -163,12 +163,13 @@ def conv2d_wgrad(x, dy, Cin, Cout, ks, dw, workspace, x_coff=0, dy_coff=0, in_sc
 
 
 def wgrad_plan(Cout, Cin, ks, N, H, W):
-    """(cob, cib): channel block sizes of the packed layout cd_conv2d_wgrad uses for these arguments."""
+    """(cob, cib, splits): channel block sizes and number of per-workgroup slices of the packed layout cd_conv2d_wgrad
+    uses for these arguments."""
     import ctypes
-    cob, cib = ctypes.c_int(0), ctypes.c_int(0)
-    _native.check(_native.lib().cd_conv2d_wgrad_plan(Cout, Cin, ks, N, H, W, ctypes.byref(cob), ctypes.byref(cib)),
+    cob, cib, splits = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _native.check(_native.lib().cd_conv2d_wgrad_plan(Cout, Cin, ks, N, H, W, ctypes.byref(cob), ctypes.byref(cib), ctypes.byref(splits)),
                   "cd_conv2d_wgrad_plan")
-    return cob.value, cib.value
+    return cob.value, cib.value, splits.value
 
 
 class UnpackTable:
@@ -182,22 +183,28 @@ class UnpackTable:
     clears them once per step."""
 
     _DT = [("packed", "<u8"), ("dw", "<u8"), ("Cin", "<i4"), ("ks", "<i4"), ("cob", "<i4"), ("cib", "<i4"), ("cig", "<i4"),
-           ("row0", "<i4"), ("rows", "<i4"), ("acc", "<i4")]
+           ("row0", "<i4"), ("rows", "<i4"), ("acc", "<i4"), ("splits", "<i4"), ("split_stride", "<i4")]
 
     def __init__(self, device):
         self.device, self._entries, self._table, self._ptrs = device, [], None, None
 
-    def add(self, workspace, grad_of, Cin, ks, plan, row0=0):
-        """grad_of: callable returning the CURRENT gradient tensor (evaluated at every run)."""
-        self._entries.append((workspace, grad_of, Cin, ks, plan, row0))
+    def add(self, workspace, grad_of, Cin, ks, plan, row0=0, cout_total=None):
+        """grad_of: callable returning the CURRENT gradient tensor (evaluated at every run); plan = wgrad_plan(...) of the
+        convolution that filled `workspace`, cout_total its output channels (default: the destination's rows)."""
+        self._entries.append((workspace, grad_of, Cin, ks, plan, row0, cout_total))
 
     def _refresh(self, grads):
         import numpy as np
         tab = np.zeros(len(self._entries), np.dtype(self._DT))
-        for j, ((ws, _, Cin, ks, (cob, cib), row0), g) in enumerate(zip(self._entries, grads)):
+        for j, ((ws, _, Cin, ks, (cob, cib, splits), row0, cout_total), g) in enumerate(zip(self._entries, grads)):
             if not (g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda and g.shape[1] == Cin and g.shape[2] == ks):
                 raise RuntimeError("weight gradients must be contiguous fp32 (rows, Cin, k, k) on the HIP device")
-            tab[j] = (ws.data_ptr(), g.data_ptr(), Cin, ks, cob, cib, (Cin + cib - 1) // cib, row0, g.shape[0], 1)
+            cout = cout_total if cout_total is not None else g.shape[0]
+            cig = (Cin + cib - 1) // cib
+            stride = ((cout + cob - 1) // cob) * cig * ks * ks * cob * cib      # one workgroup slice of the packed buffer
+            if stride * splits > ws.numel():
+                raise RuntimeError("wgrad workspace smaller than its plan")
+            tab[j] = (ws.data_ptr(), g.data_ptr(), Cin, ks, cob, cib, cig, row0, g.shape[0], 1, splits, stride)
         self._ptrs = [g.data_ptr() for g in grads]
         self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
 

@@ -256,7 +256,7 @@ int cd_debug_force_conv_tile_rows(int ty);
  * cd_conv2d_packed_co_tiles; 0 = heuristic), and switch the register-prefetch software pipeline (default on). */
 int cd_debug_force_conv_co_tiles(int co_tiles);
 int cd_debug_set_conv_pipeline(int on);
-/* Measurement hook for cd_conv2d_wgrad: bit 0 skips the flush of the partial sums, bit 1 the matrix instructions
+/* Measurement hook for cd_conv2d_wgrad: bit 0 skips the store of the partial sums, bit 1 the matrix instructions
  * (the result is then wrong); bit 2 switches the wide 1x1 plan off, bit 3 the few-input-channel (stem) kernel (correct
  * results, for A/B timing and tests);
  * 0 restores normal operation. */
@@ -264,24 +264,26 @@ int cd_debug_set_wgrad_mode(int bits);
 
 /* Weight gradient dw[Cout][Cin][ks][ks] (=, or += when accumulate) of the same convolution:
  * sum over n,y,x of dy[n][co][y][x] * act(x)[n][ci][y+ky-P][x+kx-P]  (act as in cd_conv2d_fwd).
- * workspace: cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) floats, zeroed inside unless bit 1 of
- * `accumulate` (value 2) says the caller already zeroed it (one memset over an arena of many). */
+ * workspace: cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks) floats, no initialisation needed: every workgroup stores its
+ * partial sums into its own slice and the unpack step adds the slices in a fixed order (fp64 accumulator) -- no atomics,
+ * the result is bit-reproducible.  (Bit 1 of `accumulate`, "workspace already zeroed" in ABI 3, is accepted and ignored.) */
 size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks);
 int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale,
                     const float* in_shift, int in_relu, const float* dy, int dy_ctot, int dy_coff,
                     int Cout, float* dw, int accumulate, float* workspace, int N, int H, int W, int ks,
                     void* stream);
 /* Deferred form: with bit 2 of `accumulate` (value 4) cd_conv2d_wgrad leaves the result in `workspace` in the packed
- * layout [co group][ci group][tap][cob][cib] that cd_conv2d_wgrad_plan reports for the same arguments (dw may be NULL),
- * and ONE cd_conv2d_wgrad_unpack_table launch later writes any number of gradients -- one descriptor per destination
- * tensor dw[rows][Cin][ks][ks] taking the output-channel rows [row0, row0+rows) of a packed buffer (a fused
- * convolution's rows belong to several nn.Conv2d weights).  Device-resident table of cd_unpack_desc (48 bytes each). */
+ * layout [split][co group][ci group][tap][cob][cib] that cd_conv2d_wgrad_plan reports for the same arguments (dw may be
+ * NULL; `splits` slices of split_stride = (co groups * ci groups * ks*ks * cob * cib) floats), and ONE
+ * cd_conv2d_wgrad_unpack_table launch later writes any number of gradients -- one descriptor per destination tensor
+ * dw[rows][Cin][ks][ks] taking the output-channel rows [row0, row0+rows) of a packed buffer (a fused convolution's rows
+ * belong to several nn.Conv2d weights).  Device-resident table of cd_unpack_desc (56 bytes each). */
 typedef struct cd_unpack_desc {
     const float* packed;
     float* dw;
-    int Cin, ks, cob, cib, ci_groups, row0, rows, accumulate;
+    int Cin, ks, cob, cib, ci_groups, row0, rows, accumulate, splits, split_stride;
 } cd_unpack_desc;
-int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib);
+int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib, int* splits);
 int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream);
 
 /* BatchNorm2d in training mode, forward.  stats[CD_BN_STAT_SLOTS][ctot][2] = per-channel (sum, sum of squares) of the raw

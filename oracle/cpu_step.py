@@ -25,6 +25,19 @@ class CpuFineTuner:
         self.opt = torch.optim.Adam([self.state[k] for k in self.param_keys], lr, betas=(0.9, 0.999))
         self.lambda_r, self.lambda_b = lambda_r, lambda_b
 
+    def set_adam_state(self, exp_avg, exp_avg_sq, step):
+        """Continue from a warm optimiser: per-parameter first / second moments (dicts keyed like the state dict; a missing
+        key = zeros) and the number of steps already taken -- exactly torch.optim.Adam's own state layout."""
+        for k in self.param_keys:
+            p = self.state[k]
+            m = exp_avg.get(k)
+            v = exp_avg_sq.get(k)
+            self.opt.state[p] = {
+                "step": torch.tensor(float(step)),
+                "exp_avg": (torch.zeros_like(p) if m is None else m.detach().to("cpu", self.dtype).reshape(p.shape).clone()),
+                "exp_avg_sq": (torch.zeros_like(p) if v is None else v.detach().to("cpu", self.dtype).reshape(p.shape).clone()),
+            }
+
     def step(self, images, batch):
         """images (B,2,3,H,W) numpy/tensor; batch: dict with flows/masks/intrinsics/extrinsics (numpy)."""
         np_dtype = np.float64 if self.dtype == torch.float64 else np.float32

@@ -140,3 +140,29 @@ def test_autotuner_returns_a_valid_cached_launch_shape():
     assert cfg is not None and cfg[0] in (4, 8, 16) and cfg[1] in (1, 2, 4)
     assert conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True) is cfg or \
         conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True) == cfg
+
+
+@pytest.mark.parametrize("ks,Cin,Cout,N,H,W", [(3, 32, 64, 8, 96, 56), (1, 256, 208, 8, 96, 56), (7, 3, 128, 4, 96, 64), (11, 64, 16, 4, 96, 56)])
+def test_weight_gradient_is_bit_reproducible(ks, Cin, Cout, N, H, W):
+    """Every workgroup stores its partial sums into its own slice and the slices are added in split order: no atomics, one
+    summation order -- two launches give the same bits (generic, wide-1x1 and few-input-channel plans), also through the
+    deferred unpack table."""
+    import torch
+    from consistent_depth_amd.ops import conv
+    torch.manual_seed(3)
+    x, dy = torch.randn(N, Cin, H, W, device="cuda"), torch.randn(N, Cout, H, W, device="cuda")
+    ws = conv.wgrad_workspace(Cout, Cin, ks, "cuda")
+    ws.fill_(float("nan"))        # the workspace needs no initialisation: every slice is written whole
+    a = conv.conv2d_wgrad(x, dy, Cin, Cout, ks, torch.empty(Cout, Cin, ks, ks, device="cuda"), ws)
+    ws2 = conv.wgrad_workspace(Cout, Cin, ks, "cuda")
+    ws2.fill_(7.0)
+    b = conv.conv2d_wgrad(x, dy, Cin, Cout, ks, torch.empty(Cout, Cin, ks, ks, device="cuda"), ws2)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (Cout, Cin, ks, ks), dy.double().cpu(), padding=ks // 2)
+    assert ((a.double().cpu() - ref).abs().sum() / ref.abs().sum()).item() < 2e-6
+    g = torch.zeros(Cout, Cin, ks, ks, device="cuda")
+    tab = conv.UnpackTable("cuda")
+    conv.conv2d_wgrad(x, dy, Cin, Cout, ks, None, ws)
+    tab.add(ws, lambda: g, Cin, ks, conv.wgrad_plan(Cout, Cin, ks, N, H, W))
+    tab.run()
+    assert torch.equal(g, a)

@@ -99,23 +99,95 @@ def test_short_finetune_matches_cpu_reference(backend):
     assert d_gpu < 3 * d_ref32 + 1e-3 and l_gpu < 5 * l_ref32 + 1e-3
 
 
-def test_hip_graph_replay_follows_the_eager_trajectory():
-    """GraphedFineTuneStep (1 eager step, then capture + replay of the whole step: CNN forward, loss, CNN backward, Adam
-    with its device-side step counter and NaN guard) must train like the eager step.  Not bit-identical: the weight
-    gradients are reduced with fp32 atomics in both, and the network amplifies that (parity)."""
+def test_eager_runs_are_reproducible_and_graph_replay_follows():
+    """The engine reproduces itself: weight gradients are reduced in ONE fixed order (per-workgroup slices summed in split
+    order, csrc/conv_wgrad.hip), the loss gradient is integer-accumulated, Adam is elementwise -- two eager runs on the same
+    batches give the same losses and the same final depth (the fp64 atomics of the BatchNorm statistics are the only
+    order-dependent sums left: ~1e-16 relative before the cast to fp32).  GraphedFineTuneStep (1 eager step, then capture +
+    replay of the whole step) runs the same kernels on the same data, so it must land on the same trajectory."""
     batches = _batches()
     _, loss_e, depth_e = _gpu_run("hip", batches)
     _, loss_e2, depth_e2 = _gpu_run("hip", batches)
     _, loss_g, depth_g = _gpu_run("hip", batches, graph=True)
     run_to_run = _rel_l1(depth_e2, depth_e)
-    print(f"\nlosses eager {loss_e}\nlosses graph {loss_g}\ndepth rel-L1 graph vs eager {_rel_l1(depth_g, depth_e):.2e}  "
-          f"eager vs eager {run_to_run:.2e}")
-    assert loss_g[0] == pytest.approx(loss_e[0], rel=1e-5)          # first step: same eager code
-    # Step 2 sees the weights after ONE update: only the atomics' round-off separates the runs (observed 2e-7).  Later
-    # steps diverge chaotically (sign-like Adam on noise-level gradients, observed up to 7e-4 in the loss and 4e-2 in the
-    # depth between two EAGER runs), so they get loose bounds -- a replay bug (stale inputs, missing update) moves the
-    # losses by >10 % because the batches differ (12.6, 12.3, 9.0, 6.3).
-    assert loss_g[1] == pytest.approx(loss_e[1], rel=1e-3)
-    np.testing.assert_allclose(loss_g[2:], loss_e[2:], rtol=5e-2)
+    print(f"\nlosses eager {loss_e}\nlosses eager again {loss_e2}\nlosses graph {loss_g}\n"
+          f"depth rel-L1 eager vs eager {run_to_run:.2e}  graph vs eager {_rel_l1(depth_g, depth_e):.2e}")
+    np.testing.assert_allclose(loss_e2, loss_e, rtol=1e-6)
+    assert run_to_run < 1e-5
+    np.testing.assert_allclose(loss_g, loss_e, rtol=1e-4)
+    assert _rel_l1(depth_g, depth_e) < 1e-3
     assert loss_g[-1] < loss_g[0]
-    assert _rel_l1(depth_g, depth_e) < 3 * run_to_run + 5e-2
+
+
+def test_run_level_parity_after_burn_in():
+    """BASELINE.json's acceptance criterion -- depth maps and per-step losses within 1e-3 relative L1 of the reference's CPU
+    path -- in a regime where it is a property of the ARITHMETIC and not of chaos: the comparison starts from the weights,
+    BatchNorm statistics and Adam moments after a burn-in (Adam's first steps are sign-like, m/sqrt(v) = +-1: every weight
+    whose gradient is at fp32 noise level moves by a full +-lr in a random direction -- the random-init start of the test
+    above measures that, not the kernels).  From that state the GPU engine and the CPU restatement of the reference step
+    (oracle/cpu_step.py, fp64) run the same T steps at the BASELINE size (4 pairs of 384x224); the reference's own fp32 run
+    is the yardstick printed next to it."""
+    import argparse
+    import torch
+    from consistent_depth_amd import synthetic
+    from consistent_depth_amd.engine import FineTuneStep
+    from consistent_depth_amd.monodepth.mannequin_challenge_model import MannequinChallengeModel
+    from oracle import cpu_step, hourglass_ref
+    BURN, T, PB, PH, PW = 24, 4, 4, 384, 224
+    params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0, learning_rate=4e-4,
+                                optimizer="Adam")
+    model = MannequinChallengeModel(backend="hip", seed=0)
+    model.train()
+    step = FineTuneStep(model, params, world=1)
+    t = lambda a: torch.tensor(a, device="cuda")  # noqa: E731
+
+    def batch(i):
+        b = synthetic.make_scene_batch(PB, PH, PW, seed=500 + i)
+        return np.random.default_rng(700 + i).random((PB, 2, 3, PH, PW), dtype=np.float32), b
+
+    def meta_of(b):
+        return {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
+                "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
+
+    for i in range(BURN):
+        images, b = batch(i % 6)
+        step(t(images), meta_of(b))
+    torch.cuda.synchronize()
+    opt = step.opt
+    state = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+    names = {id(p): n for n, p in model.netG.named_parameters()}
+    m1, m2 = {}, {}
+    for p, o in zip(opt._params, opt._offsets):
+        m1[names[id(p)]] = opt.exp_avg[o:o + p.numel()].detach().cpu().clone()
+        m2[names[id(p)]] = opt.exp_avg_sq[o:o + p.numel()].detach().cpu().clone()
+    k0 = int(opt.step_dev.item())
+    assert k0 == BURN
+    run = [batch(100 + i) for i in range(T)]
+    probe_images, _ = batch(999)
+    losses_gpu = []
+    for images, b in run:
+        loss, _ = step(t(images), meta_of(b))
+        losses_gpu.append(loss.item())
+    with torch.no_grad():
+        model.train()      # probe with batch statistics, like the reference's validation sweep
+        depth_gpu = model.forward(t(probe_images)).double().cpu().numpy()
+
+    def cpu(dtype):
+        ft = cpu_step.CpuFineTuner(state, lr=4e-4, lambda_r=1.0, lambda_b=0.1, dtype=dtype)
+        ft.set_adam_state(m1, m2, k0)
+        losses = [float(ft.step(images, b)[0]["total"][0]) for images, b in run]
+        x = torch.as_tensor(probe_images, dtype=dtype).reshape(-1, 3, PH, PW)
+        with torch.no_grad():
+            pred, _ = hourglass_ref.forward(ft.state, x, training=True, update_running_stats=False)
+        return np.array(losses), torch.exp(pred).reshape(PB, 2, PH, PW).double().numpy()
+
+    loss64, depth64 = cpu(torch.float64)
+    loss32, depth32 = cpu(torch.float32)
+    d_gpu, d_ref = _rel_l1(depth_gpu, depth64), _rel_l1(depth32, depth64)
+    l_gpu, l_ref = _rel_l1(np.array(losses_gpu), loss64), _rel_l1(loss32, loss64)
+    per_step = np.abs(np.array(losses_gpu) - loss64) / np.abs(loss64)
+    from gpu_util import report
+    report("run_level[burn_in24,4x384x224,4steps]", depth_rel_l1=d_gpu, ref_fp32_depth_rel_l1=d_ref, loss_rel_l1=l_gpu,
+           ref_fp32_loss_rel_l1=l_ref, worst_step_loss_rel=float(per_step.max()))
+    print(f"\nlosses gpu {losses_gpu}\nlosses cpu fp64 {loss64}\nlosses cpu fp32 {loss32}")
+    assert d_gpu <= 1e-3 and l_gpu <= 1e-3 and per_step.max() <= 1e-3

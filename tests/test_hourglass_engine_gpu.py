@@ -12,9 +12,15 @@ def _rel(a, b):
     return (a.double() - b.double()).abs().sum().item() / max(1e-30, b.double().abs().sum().item())
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (2, 32, 48)])
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (2, 32, 48), (8, 384, 224)], ids=["2x64x96", "2x32x48", "baseline_8x384x224"])
 def test_engine_matches_autograd(N, H, W):
+    """The third case is the BASELINE shape (BS4 = 8 images of 384x224): the XCD-aware tile mapping, the level streams, the
+    timed launch shapes and the wide-1x1 / few-input-channel weight-gradient plans only exist at this size."""
     import torch
+    if N * H * W > 100000:
+        import psutil
+        if psutil.virtual_memory().available < 48e9:     # fp64 autograd of 8 images keeps ~25 GB of activations
+            pytest.skip("not enough host memory for the fp64 reference at the BASELINE shape")
     from consistent_depth_amd.monodepth.hourglass import HourglassModel
     from consistent_depth_amd.monodepth.hourglass_engine import HourglassEngine
     torch.manual_seed(0)
@@ -38,12 +44,15 @@ def test_engine_matches_autograd(N, H, W):
     torch.cuda.synchronize()
     gref = dict(ref.named_parameters())
     # fp32 noise floor of autograd itself on this (deep, BatchNorm-heavy) network: same net in fp32 on the CPU
-    ref32 = HourglassModel()
-    ref32.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items() if "running" not in k and "num_batches" not in k}, strict=False)
-    ref32.train()
-    p32, _ = ref32(x.float())
-    p32.backward(dpred.float())
-    g32 = dict(ref32.named_parameters())
+    big = N * H * W > 100000
+    g32 = None
+    if not big:    # (at the BASELINE shape a second CPU pass costs minutes: its measured distances are the constants below)
+        ref32 = HourglassModel()
+        ref32.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items() if "running" not in k and "num_batches" not in k}, strict=False)
+        ref32.train()
+        p32, _ = ref32(x.float())
+        p32.backward(dpred.float())
+        g32 = dict(ref32.named_parameters())
     errs = []
     for name, p in net.named_parameters():
         g = gref[name].grad
@@ -54,7 +63,8 @@ def test_engine_matches_autograd(N, H, W):
             # mathematically zero; autograd produces round-off noise, the engine exact zeros
             assert p.grad.abs().max().item() == 0.0
             continue
-        errs.append((_rel(p.grad.cpu(), g), _rel(g32[name].grad, g), name))
+        # torch-fp32 autograd at 8x384x224, measured once (profiles/parity_engine_r02.txt): median 1.07e-2, worst 1.25e-2
+        errs.append((_rel(p.grad.cpu(), g), _rel(g32[name].grad, g) if g32 is not None else 1.07e-2, name))
     errs.sort(reverse=True)
     for e, e32, name in errs[:8]:
         print(f"  {name:45s} engine {e:.2e}   torch-fp32 {e32:.2e}")
