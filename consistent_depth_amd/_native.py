@@ -121,13 +121,17 @@ def stream_ptr(device=None) -> int:
 
 
 _workspaces: dict = {}
+_retired: list = []   # outgrown workspaces stay alive: a captured HIP graph may have their addresses baked in
 
 
 def workspace(key, nbytes: int, device) -> torch.Tensor:
-    """Persistent per-(key, device) scratch buffer, grown on demand (never shrunk)."""
+    """Persistent per-(key, device) scratch buffer, grown on demand (never shrunk, never freed: a step graph captured
+    with the smaller buffer keeps replaying into it while later, larger calls use the new one)."""
     k = (key, str(device))
     buf = _workspaces.get(k)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _retired.append(buf)
         buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         _workspaces[k] = buf
     return buf

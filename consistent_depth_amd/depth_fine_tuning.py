@@ -110,9 +110,15 @@ class DepthFineTuner:
             ds = VideoFrameDataset(pjoin(self.base_dir, "color_down", "frame_{:06d}.raw"), frames)
             lookup = {f: i for i, f in enumerate(frames)}
             get = lambda f: ds[lookup[f]][0][None]  # noqa: E731
-        for f in frames:
-            depth = self.model.forward(get(f)).detach().float().cpu().numpy().squeeze()
-            image_io.save_raw_float32_image(pjoin(depth_dir, f"frame_{f:06d}.raw"), 1.0 / depth)
+        # batched eval-mode forward; inverse depth stays on the device, file writes run on a background thread
+        bs = max(1, 2 * self.params.batch_size)
+        with image_io.AsyncRawWriter(device=self.store.device if self.store is not None else None) as writer:
+            for s0 in range(0, len(frames), bs):
+                chunk = frames[s0:s0 + bs]
+                images = torch.cat([get(f) for f in chunk], 0).to("cuda", non_blocking=True)
+                inv = self.model.forward(images).detach().float().reciprocal()
+                for i, f in enumerate(chunk):
+                    writer.submit(pjoin(depth_dir, f"frame_{f:06d}.raw"), inv[i].reshape(inv.shape[-2:]))
 
     # ------------------------------------------------------------------ training (:201-310)
     def fine_tune(self, writer=None):
@@ -120,6 +126,8 @@ class DepthFineTuner:
         if self.store is None:
             self.store = PairStore.from_directory(self.base_dir, pjoin(self.range_dir, "metadata_scaled.npz"))
         store = self.store
+        if self.world > 1:   # identical replicas by construction, not by seed: rank 0's parameters and buffers everywhere
+            parallel.broadcast_([q.data for q in self.model.parameters()] + [b for b in self.model.buffers() if b.is_floating_point()])
         step = FineTuneStep(self.model, p, world=self.world)
         if os.environ.get("CD_AMD_STEP_GRAPH", "1") != "0":   # replay the step from a HIP graph after 2 eager steps
             step = GraphedFineTuneStep(step)
@@ -172,20 +180,24 @@ class DepthFineTuner:
         reference (model.train() is set once, :241).  Ranks shard the unshuffled list; per-pair
         losses are gathered on rank 0, which writes the files."""
         store, p = self.store, self.params
-        plan = parallel.shard_indices(len(store), 0, 0, self.rank, self.world, p.batch_size, shuffle=False)
-        names, rows, saved = None, [], {}
-        for ids in plan:
-            images, metadata = store.batch(ids)
+        plan = parallel.eval_shard(len(store), self.rank, self.world, p.batch_size)   # every pair, like the reference's sweep
+        names, rows, saved = None, [], set()
+        plan_dev = parallel.plan_to_device(plan, store.device)
+        frames_of = store.pair_indices()    # host copy of the pair list: no device sync to learn which frames a batch holds
+        writer = image_io.AsyncRawWriter(device=store.device)
+        for ids, ids_dev in zip(plan, plan_dev):
+            images, metadata = store.batch(ids_dev)
             raw, _, parts = step.evaluate(images, metadata)
             if names is None:
                 names = [n for n in parts if parts[n].numel() == len(ids)]
             idx = metadata["geometry_consistency"]["indices"]
             rows.append(torch.cat([idx.float()] + [parts[n].reshape(-1, 1).float() for n in names], 1))
-            depth = self._depth_from_raw(raw)
-            for b, pair in enumerate(idx.tolist()):
-                for k, f in enumerate(pair):
-                    if f not in saved:
-                        saved[f] = (1.0 / depth[b, k]).cpu().numpy()
+            inv = self._depth_from_raw(raw).reciprocal()
+            for b, pid in enumerate(ids):
+                for k, f in enumerate(frames_of[pid]):
+                    if f not in saved:   # first sighting of a frame on this rank (the reference keeps the first, :343-360)
+                        saved.add(f)
+                        writer.submit(pjoin(self.out_dir, "eval", f"depth_{f:06d}{suf}.raw"), inv[b, k])
         table = torch.cat(rows, 0) if rows else torch.zeros(0, 2 + len(names or []), device=store.device)
         if self.world > 1:
             import torch.distributed as dist
@@ -199,8 +211,7 @@ class DepthFineTuner:
             dist.all_gather(gathered, pad)
             table = torch.cat([g[:int(n.item())] for g, n in zip(gathered, n_all)], 0)
         table = table.cpu().numpy()
-        for f, inv in saved.items():  # every rank writes the frames it saw first (disjoint enough; idempotent)
-            image_io.save_raw_float32_image(pjoin(self.out_dir, "eval", f"depth_{f:06d}{suf}.raw"), inv)
+        writer.close()   # the files of this sweep are on disk when it returns
         loss_dict = {n: {} for n in (names or [])}
         for row in table:
             key = str([int(row[0]), int(row[1])])

@@ -158,10 +158,11 @@ class PointwiseGroup:
                                     y_ctot=src.buf.shape[1])
 
     def _fused_bias(self):
-        v = tuple((m.conv.bias.data_ptr(), m.conv.bias._version) for m in self.members)
-        if v != self._bias_versions:
-            torch.cat([m.conv.bias.detach() for m in self.members], out=self._bias)
-            self._bias_versions = v
+        # Rebuilt on EVERY forward (one tiny concatenation, captured into the step graph): FlatAdam updates the member biases
+        # through raw pointers, which tensor version counters never see, so a cached copy would go stale -- harmless under a
+        # train-mode BatchNorm (which cancels the bias) but wrong in eval mode and as soon as the biases get a gradient
+        # (lambda_parameter > 0).
+        torch.cat([m.conv.bias.detach() for m in self.members], out=self._bias)
         return self._bias
 
     def forward(self, training):

@@ -67,6 +67,18 @@ def broadcast_(tensors, src: int = 0):
             dist.broadcast(t, src)
 
 
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def eval_shard(n_items: int, rank: int, world: int, batch_size: int):
+    """Validation shards: EVERY item exactly once (rank r takes items r, r + world, ...; the last batches may be short and
+    ranks may run different numbers of batches -- there is no collective inside the validation loop)."""
+    mine = list(range(rank, n_items, world))
+    return [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
+
+
 def plan_to_device(plan, device):
     """The per-step index lists of an epoch as int64 device tensors (ONE upload; slices of a padded matrix)."""
     if not plan:

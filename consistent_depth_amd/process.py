@@ -10,6 +10,7 @@ from __future__ import annotations
 import os
 from os.path import join as pjoin
 
+from . import parallel
 from .depth_fine_tuning import DepthFineTuner
 from .loaders.video_dataset import read_pair_list
 
@@ -41,5 +42,9 @@ class DatasetProcessor:
         print(f"Output directory: {self.out_dir}")
         ft = DepthFineTuner(self.out_dir, frames, params)
         ft.fine_tune(writer=self.writer)
-        ft.save_depth(ft.out_dir, frames)
+        # one writer: rank 0 holds the checkpointed weights AND running statistics the exported depth must come from
+        # (BatchNorm running statistics are rank-local during training, like nn.DataParallel's replica 0)
+        if ft.rank == 0:
+            ft.save_depth(ft.out_dir, frames)
+        parallel.barrier()
         return None, ft.out_dir, frames

@@ -58,3 +58,62 @@ def load_mask_png(file_name: str) -> np.ndarray:
 def save_mask_png(file_name: str, mask: np.ndarray) -> None:
     from PIL import Image
     Image.fromarray((np.asarray(mask) > 0).astype(np.uint8) * 255).save(file_name)
+
+
+class AsyncRawWriter:
+    """Writes device tensors as `.raw` float32 images OFF the critical path: `submit` enqueues a device-to-pinned-host copy on
+    a side stream (ordered after the producing stream by an event) and returns at once; a background thread waits for each
+    copy and writes the file.  `close()` (or leaving the `with` block) drains the queue and re-raises a writer error.
+    Replaces the reference's blocking per-frame `.cpu().numpy()` + write (depth_fine_tuning.py:185-199)."""
+
+    def __init__(self, device=None, max_pending: int = 64):
+        import queue
+        import threading
+        import torch
+        self._torch = torch
+        self._stream = torch.cuda.Stream(device=device)
+        self._q = queue.Queue(maxsize=max_pending)
+        self._err = None
+        self._thread = threading.Thread(target=self._run, name="cd-raw-writer", daemon=True)
+        self._thread.start()
+
+    def submit(self, file_name: str, image) -> None:
+        torch = self._torch
+        if self._err is not None:
+            raise self._err
+        src = image.detach()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(src.device))
+        host = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(ready)
+            host.copy_(src, non_blocking=True)
+            src.record_stream(self._stream)      # keep the device tensor alive until the copy has run
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        self._q.put((file_name, host, done))
+
+    def _run(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            try:
+                file_name, host, done = item
+                done.synchronize()
+                save_raw_float32_image(file_name, host.numpy())
+            except Exception as e:   # noqa: BLE001 -- surfaced by submit / close
+                self._err = e
+
+    def close(self):
+        self._q.put(None)
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

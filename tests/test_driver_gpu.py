@@ -115,3 +115,64 @@ def test_gather_into_graph_buffers_and_step_from_store():
         assert md["geometry_consistency"]["indices"].tolist() == [store.pair_indices()[i] for i in pid.tolist()]
     assert step.graphed is True, step.capture_error
     assert all(l == l for l in losses) and not torch.equal(w0, step.step.opt.flat_param)
+
+
+def test_validation_sweep_values_match_cpu_reference(tmp_path):
+    """eval_and_save (depth_fine_tuning.py:312-406 of the reference): the VALUES of eval/loss*.json (per pair and mean) and of
+    the inverse-depth .raw files against the reference step restated on the CPU in fp64 (oracle/cpu_step pieces) on the same
+    weights and the same batches (train-mode BatchNorm under no_grad, first sighting of a frame wins), written through the
+    asynchronous writer."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_dataset as msd
+    import torch
+    from consistent_depth_amd import parallel
+    from consistent_depth_amd.depth_fine_tuning import DepthFineTuner
+    from consistent_depth_amd.engine import FineTuneStep
+    from consistent_depth_amd.loaders.pair_store import PairStore
+    from consistent_depth_amd.params import Video3dParamsParser
+    from consistent_depth_amd.utils import image_io
+    from oracle import hourglass_ref, oracle
+    oracle.build()
+    path = str(tmp_path / "clip")
+    range_dir, pairs = msd.write_dataset(path, n_frames=5, H=64, W=48, seed=6)
+    params = Video3dParamsParser().parse(["--path", path, "--batch_size", "3"])
+    ft = DepthFineTuner(range_dir, list(range(5)), params)
+    ft.store = PairStore.from_directory(path, os.path.join(range_dir, "metadata_scaled.npz"))
+    os.makedirs(os.path.join(ft.out_dir, "eval"), exist_ok=True)
+    state = {k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu() for k, v in ft.model.netG.state_dict().items()}
+    ft.model.train()
+    step = FineTuneStep(ft.model, params, world=1)
+    ft.eval_and_save(step, "_t")
+    with open(os.path.join(ft.out_dir, "eval", "loss_t.json")) as f:
+        got = json.load(f)
+    want, first = {"reprojection": {}, "disparity": {}}, {}
+    for ids in parallel.eval_shard(len(ft.store), 0, 1, 3):
+        images, meta = ft.store.batch(ids)
+        x = images.cpu().double().reshape(-1, 3, 64, 48)
+        with torch.no_grad():
+            pred, _ = hourglass_ref.forward(state, x, training=True, update_running_stats=False)
+        depth = torch.exp(pred).reshape(len(ids), 2, 64, 48).numpy()
+        g = meta["geometry_consistency"]
+        out = oracle.consistency_loss(depth, [f.cpu().numpy() for f in g["flows"]], [m.cpu().numpy() for m in g["masks"]],
+                                      meta["intrinsics"].cpu().numpy(), meta["extrinsics"].cpu().numpy(), 1.0, 0.1, want_grad=False)
+        for b, pair in enumerate(g["indices"].tolist()):
+            want["reprojection"][str(pair)] = out["reprojection"][b]
+            want["disparity"][str(pair)] = out["disparity"][b]
+            for k, fr in enumerate(pair):
+                first.setdefault(fr, 1.0 / depth[b, k])
+    assert set(got["reprojection"]) == set(want["reprojection"]) == {str(list(p)) for p in pairs}
+    for name in ("reprojection", "disparity"):
+        for key, v in want[name].items():
+            assert got[name][key] == pytest.approx(v, rel=2e-3), (name, key)     # fp32 CNN forward at random init: ~2e-4 in depth
+        assert got["mean"][name] == pytest.approx(np.mean(list(want[name].values())), rel=1e-3)
+    for fr, inv in first.items():
+        raw = image_io.load_raw_float32_image(os.path.join(ft.out_dir, "eval", f"depth_{fr:06d}_t.raw"))
+        assert np.abs(raw - inv).sum() / np.abs(inv).sum() < 1e-3
+    # save_depth: eval-mode BatchNorm, batched forward, same files as one frame at a time
+    ft.save_depth(ft.out_dir, list(range(5)))
+    ft.model.eval()
+    with torch.no_grad():
+        for fr in range(5):
+            ref = 1.0 / ft.model.forward(ft.store.color[fr][None]).float().cpu().numpy().squeeze()
+            raw = image_io.load_raw_float32_image(os.path.join(ft.out_dir, "depth", f"frame_{fr:06d}.raw"))
+            np.testing.assert_allclose(raw, ref, rtol=1e-5)

@@ -191,3 +191,39 @@ def test_run_level_parity_after_burn_in():
            ref_fp32_loss_rel_l1=l_ref, worst_step_loss_rel=float(per_step.max()))
     print(f"\nlosses gpu {losses_gpu}\nlosses cpu fp64 {loss64}\nlosses cpu fp32 {loss32}")
     assert d_gpu <= 1e-3 and l_gpu <= 1e-3 and per_step.max() <= 1e-3
+
+
+def test_parameter_regulariser_reaches_the_update():
+    """lambda_parameter > 0 (ParameterLoss, the L1 pull towards the initial weights): its gradient lambda * sign(p - p0) is put
+    into p.grad by autograd BEFORE the engine's backward runs; the engine ACCUMULATES its weight / bias / BatchNorm-affine
+    gradients, so the sum reaches Adam (round 1 overwrote it: the loss value contained the term, the update did not)."""
+    import argparse
+    import torch
+    from consistent_depth_amd import synthetic
+    from consistent_depth_amd.engine import FineTuneStep
+    from consistent_depth_amd.monodepth.mannequin_challenge_model import MannequinChallengeModel
+    t = lambda a: torch.tensor(a, device="cuda")  # noqa: E731
+    b = synthetic.make_scene_batch(2, 64, 48, seed=5)
+    images = torch.rand(2, 2, 3, 64, 48, device="cuda")
+    meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
+            "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
+    grads, losses = {}, {}
+    for lam in (0.0, 0.5):
+        params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=lam, learning_rate=4e-4,
+                                    optimizer="Adam")
+        model = MannequinChallengeModel(backend="hip", seed=0)
+        model.train()
+        step = FineTuneStep(model, params, world=1)      # p0 = the initial weights
+        with torch.no_grad():                            # move away from p0 deterministically, same in both runs
+            gen = torch.Generator(device="cuda").manual_seed(1)
+            step.opt.flat_param.add_(1e-3 * torch.randn(step.opt.flat_param.shape, device="cuda", generator=gen))
+        guard, _ = step._grads(images, meta)
+        grads[lam], losses[lam] = step.opt.flat_grad.clone(), guard.item()
+        if lam > 0:
+            sign = torch.zeros_like(step.opt.flat_param)
+            for p, p0, o in zip(step.opt._params, step.criterion.parameter_loss.parameters_init, step.opt._offsets):
+                sign[o:o + p.numel()] = torch.sign(p.detach() - p0).reshape(-1)
+    extra = grads[0.5] - grads[0.0]
+    assert losses[0.5] > losses[0.0]
+    assert (extra - 0.5 * sign).abs().max().item() < 1e-5, "the regulariser's gradient did not survive the engine's backward"
+    assert (extra != 0).float().mean().item() > 0.9

@@ -88,3 +88,23 @@ def test_two_rank_gloo_gradient_allreduce_matches_single_process():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_eval_shards_cover_every_pair_exactly_once():
+    """Validation evaluates EVERY pair (the reference's sweep does): 11 pairs on 2 ranks with batch 4 used to lose pair 10,
+    7 pairs on 8 ranks used to evaluate nothing."""
+    for n, world, bs in ((11, 2, 4), (7, 8, 4), (715, 8, 4), (1, 3, 4), (0, 2, 4)):
+        seen = []
+        for r in range(world):
+            for ids in parallel.eval_shard(n, r, world, bs):
+                assert 0 < len(ids) <= bs
+                seen += ids
+        assert sorted(seen) == list(range(n))
+
+
+def test_plan_to_device_roundtrip():
+    import torch
+    plan = [[3, 1, 2, 0], [5, 4]]
+    dev = parallel.plan_to_device(plan, torch.device("cpu"))
+    assert [d.tolist() for d in dev] == plan and all(d.dtype == torch.int64 and d.is_contiguous() for d in dev)
+    assert parallel.plan_to_device([], torch.device("cpu")) == []
