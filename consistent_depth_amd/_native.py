@@ -54,6 +54,20 @@ SIGNATURES = {
     "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_conv2d_wgrad_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
     "cd_conv2d_wgrad_unpack_table": (c_i, [c_p, c_i, c_p]),
+    "cd_hourglass_create": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_p)]),
+    "cd_hourglass_destroy": (c_i, [c_p]),
+    "cd_hourglass_param_floats": (c_sz, [c_p]),
+    "cd_hourglass_bn_floats": (c_sz, [c_p]),
+    "cd_hourglass_param_count": (c_i, [c_p]),
+    "cd_hourglass_param_info": (c_i, [c_p, c_i, ctypes.POINTER(c_sz), ctypes.POINTER(c_i)]),
+    "cd_hourglass_params": (c_p, [c_p]),
+    "cd_hourglass_grads": (c_p, [c_p]),
+    "cd_hourglass_load_state": (c_i, [c_p, c_p, c_p, c_p]),
+    "cd_hourglass_save_state": (c_i, [c_p, c_p, c_p, c_p]),
+    "cd_hourglass_zero_grad": (c_i, [c_p, c_p]),
+    "cd_copy_f32": (c_i, [c_p, c_p, c_sz, c_p]),
+    "cd_hourglass_forward": (c_i, [c_p, c_p, c_p, c_i, c_p]),
+    "cd_hourglass_backward": (c_i, [c_p, c_p, c_p]),
     "cd_bn_normalize": (c_i, [c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "cd_bn_finalize": (c_i, [c_p, c_i, c_i, c_i, ctypes.c_double, c_f, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     "cd_bn_relu_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -321,9 +321,11 @@ __global__ __launch_bounds__(kBlock) void add_slice_kernel(const float* __restri
 // out[c] (+)= sum over n, y, x of src[n][coff+c]   (bias gradient of a conv that is NOT followed by BatchNorm: in the
 // hourglass only the 1-channel head).  ONE workgroup per channel, fixed summation order (per-thread strided sums in 4
 // independent fp32 chains, then a fp64 tree): bit-reproducible, unlike the fp32-atomic combination of round 1.
-__global__ __launch_bounds__(kBlock) void channel_sum_kernel(const float* __restrict__ src, int ctot, int coff, int N,
-                                                             int HW, float* __restrict__ out, int accumulate) {
-    __shared__ double lds[kBlock];
+constexpr int kSumBlock = 1024;
+__global__ __launch_bounds__(kSumBlock) void channel_sum_kernel(const float* __restrict__ src, int ctot, int coff, int N,
+                                                                int HW, float* __restrict__ out, int accumulate) {
+    __shared__ double lds[kSumBlock];
+    constexpr int kBlock = kSumBlock;
     const int c = blockIdx.y;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int n = 0; n < N; ++n) {
@@ -447,7 +449,7 @@ int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_cto
 int cd_channel_sum(const float* src, int ctot, int coff, int C, int N, int H, int W, float* out, int accumulate,
                    void* stream) {
     CD_ARGCHK(src && out && C > 0 && coff + C <= ctot);
-    hipLaunchKernelGGL(cd::channel_sum_kernel, dim3(1, C), dim3(cd::kBlock), 0, (hipStream_t)stream, src, ctot,
+    hipLaunchKernelGGL(cd::channel_sum_kernel, dim3(1, C), dim3(cd::kSumBlock), 0, (hipStream_t)stream, src, ctot,
                        coff, N, H * W, out, accumulate);
     CD_CHECK_LAUNCH();
     return CD_OK;

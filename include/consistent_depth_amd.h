@@ -286,6 +286,41 @@ typedef struct cd_unpack_desc {
 int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib, int* splits);
 int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * The hourglass as ONE object: plan, buffers, forward and explicit backward behind a handle, for hosts without Python
+ * (reference call site: monodepth/mannequin_challenge_model.py:52-69 netG.forward + autograd, depth_fine_tuning.py:282).
+ * A whole fine-tuning step through this header:
+ *     cd_hourglass_zero_grad; cd_hourglass_forward(images -> pred);
+ *     cd_consistency_loss_fwd_bwd(depth = pred, CD_DEPTH_EXP -> grad);  cd_hourglass_backward(grad);
+ *     [all-reduce cd_hourglass_grads()];  cd_adam_step_flat(cd_hourglass_params(), cd_hourglass_grads(), m, v, ...).
+ * Parameters: ONE flat fp32 buffer, the tensors of the PyTorch module's named_parameters() in order (seq.0.weight,
+ * seq.0.bias, seq.1.weight, ..., uncertainty_layer.0.*, pred_layer.*), each starting on a 64-float boundary -- the layout
+ * consistent_depth_amd.optimizer.FlatAdam uses; cd_hourglass_param_info reports offset and shape of tensor `index`.
+ * BatchNorm running statistics: bn_flat = for every BatchNorm2d in module order [running_mean(C), running_var(C)].
+ * cd_hourglass_create allocates the engine's device memory (activations, gradients, packed filters, workspaces:
+ * ~10 GB for 8 x 384 x 224); all other calls only enqueue work on `stream`.  One input shape per handle.
+ * ---------------------------------------------------------------------------------- */
+typedef struct cd_hourglass cd_hourglass;
+int cd_hourglass_create(int N, int H, int W, cd_hourglass** out);   /* H, W multiples of 16 */
+int cd_hourglass_destroy(cd_hourglass* h);
+size_t cd_hourglass_param_floats(const cd_hourglass* h);
+size_t cd_hourglass_bn_floats(const cd_hourglass* h);
+int cd_hourglass_param_count(const cd_hourglass* h);
+int cd_hourglass_param_info(const cd_hourglass* h, int index, size_t* offset, int* shape4);
+float* cd_hourglass_params(cd_hourglass* h);   /* device pointers owned by the handle */
+float* cd_hourglass_grads(cd_hourglass* h);
+/* params_flat / bn_flat: host or device memory (hipMemcpyDefault); bn_flat may be NULL (keep / skip the statistics). */
+int cd_hourglass_load_state(cd_hourglass* h, const float* params_flat, const float* bn_flat, void* stream);
+int cd_hourglass_save_state(cd_hourglass* h, float* params_flat, float* bn_flat, void* stream);
+int cd_hourglass_zero_grad(cd_hourglass* h, void* stream);
+/* n floats between any two host / device buffers, stream ordered (reads the handle-owned buffers from a binding). */
+int cd_copy_f32(const float* src, float* dst, size_t n, void* stream);
+/* images [N][3][H][W] RGB in [0,1] -> pred [N][1][H][W] (log depth).  training != 0: batch statistics, running statistics
+ * updated (nn.BatchNorm2d semantics, momentum 0.1); 0: running statistics. */
+int cd_hourglass_forward(cd_hourglass* h, const float* images, float* pred, int training, void* stream);
+/* dpred = d loss / d pred of the LAST training forward; every parameter gradient is ADDED into cd_hourglass_grads(). */
+int cd_hourglass_backward(cd_hourglass* h, const float* dpred, void* stream);
+
 /* BatchNorm2d in training mode, forward.  stats[CD_BN_STAT_SLOTS][ctot][2] = per-channel (sum, sum of squares) of the raw
  * tensor over N*H*W (what cd_conv2d_fwd accumulates).  In place: x <- (x - mean) * rsqrt(var + eps)
  * (x_hat, PRE-ReLU: consumers apply relu / the affine part while loading); writes

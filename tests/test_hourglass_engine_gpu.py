@@ -109,3 +109,54 @@ def test_engine_eval_mode_and_no_grad():
         pred = eng.forward(x.float().cuda())
     assert not pred.requires_grad
     assert _rel(pred.cpu(), ref(x)[0].detach()) < 2e-4
+
+
+def test_c_handle_engine_matches_python_engine():
+    """cd_hourglass_* (csrc/hourglass.hip): the plan in C++ behind one handle.  Same kernels, same buffers layout, same
+    fixed summation orders as the Python orchestration -> pred, every parameter gradient and the running statistics agree
+    to the last bit or nearly (launch shapes differ: results do not depend on them); parameter layout = FlatAdam's."""
+    import torch
+    from consistent_depth_amd.monodepth.hourglass import HourglassModel
+    from consistent_depth_amd.monodepth.hourglass_c import CHourglass
+    from consistent_depth_amd.monodepth.hourglass_engine import HourglassEngine
+    from consistent_depth_amd.optimizer import FlatAdam
+    torch.manual_seed(0)
+    N, H, W = 2, 64, 96
+    net = HourglassModel().cuda().train()
+    for m in net.modules():   # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    ce = CHourglass(N, H, W)
+    ce.load_module(net)
+    opt = FlatAdam(list(net.parameters()), lr=4e-4)          # re-homes the parameters: the layout the C engine mirrors
+    layout = ce.param_layout()
+    assert [o for o, _ in layout] == opt._offsets and ce.n_param == opt.flat_param.numel()
+    x = torch.rand(N, 3, H, W, device="cuda")
+    dpred = torch.randn(N, 1, H, W, device="cuda")
+    eng = HourglassEngine(net)
+    opt.zero_grad()
+    pred_py = eng.forward(x)
+    pred_py.backward(dpred)
+    ce.zero_grad()
+    pred_c = ce.forward(x, training=True)
+    ce.backward(dpred)
+    torch.cuda.synchronize()
+    assert _rel(pred_c, pred_py.detach()) < 1e-6
+    g_c, g_py = ce.grads(), opt.flat_grad
+    assert _rel(g_c, g_py) < 1e-5, _rel(g_c, g_py)
+    worst = max(_rel(g_c[o:o + int(torch.tensor(s).prod())], g_py[o:o + int(torch.tensor(s).prod())])
+                for (o, s) in layout if g_py[o:o + int(torch.tensor(s).prod())].abs().sum() > 0)
+    print(f"  C engine vs Python engine: pred rel {_rel(pred_c, pred_py.detach()):.2e}, grads rel {_rel(g_c, g_py):.2e}, worst tensor {worst:.2e}")
+    assert worst < 1e-4
+    # running statistics after one training forward, and eval mode
+    _, bn_c = ce.state()
+    bn_py = torch.cat([torch.cat([m.running_mean.detach().float().cpu(), m.running_var.detach().float().cpu()])
+                       for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)])
+    assert _rel(bn_c, bn_py) < 1e-6
+    net.eval()
+    with torch.no_grad():
+        e_py = eng.forward(x)
+    e_c = ce.forward(x, training=False)
+    assert _rel(e_c, e_py) < 1e-6
+    ce.close()
