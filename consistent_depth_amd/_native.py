@@ -54,6 +54,8 @@ SIGNATURES = {
     "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_conv2d_wgrad_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
     "cd_conv2d_wgrad_unpack_table": (c_i, [c_p, c_i, c_p]),
+    "cd_rccl_available": (c_i, []),
+    "cd_allreduce_mean_f32": (c_i, [c_p, c_sz, c_p, c_i, c_p]),
     "cd_hourglass_create": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_p)]),
     "cd_hourglass_destroy": (c_i, [c_p]),
     "cd_hourglass_param_floats": (c_sz, [c_p]),

@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", SO, *objs]
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", SO, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

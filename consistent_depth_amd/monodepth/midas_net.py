@@ -11,14 +11,22 @@ Output: inverse depth (N, H, W).  State-dict keys follow upstream (`pretrained.l
 `scratch.refinenet4.resConfUnit1.conv1.weight`, `scratch.output_conv.0.weight`): a real checkpoint loads by
 key.  "Parity unpinned" (no source, no weights, no golden vectors in /root/reference); ~105 M parameters.
 
-Convolutions of this backbone run through PyTorch-ROCm (grouped 3x3 convs and strided stems are outside the
-stride-1 MFMA engine built for the hourglass); loss, optimiser and data parallelism are the HIP/RCCL path.
+Convolutions: `backend="hip"` (default) builds the network from ops.conv_layer.HipConv2d -- every convolution (grouped
+32 x 8d 3x3, strided stem / down-samples, decoder) forward, input gradient and weight gradient on the hand-written gfx950
+MFMA kernels; `backend="torch"` keeps nn.Conv2d (PyTorch-ROCm / MIOpen).  BatchNorm, ReLU, max-pool and the bilinear
+up-sampling are ATen ops in both; loss, optimiser and data parallelism are the HIP/RCCL path.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+_CONV = [nn.Conv2d]   # the convolution class the constructors below use (set by MidasNet for the duration of __init__)
+
+
+def Conv2d(*a, **kw):
+    return _CONV[0](*a, **kw)
 
 
 class Bottleneck(nn.Module):
@@ -27,11 +35,11 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None, groups=32, base_width=8):
         super().__init__()
         width = int(planes * (base_width / 64.0)) * groups
-        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.conv1 = Conv2d(inplanes, width, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(width)
-        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, groups=groups, bias=False)
+        self.conv2 = Conv2d(width, width, 3, stride, 1, groups=groups, bias=False)
         self.bn2 = nn.BatchNorm2d(width)
-        self.conv3 = nn.Conv2d(width, planes * self.expansion, 1, bias=False)
+        self.conv3 = Conv2d(width, planes * self.expansion, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -47,7 +55,7 @@ class Bottleneck(nn.Module):
 def _stage(inplanes, planes, blocks, stride):
     down = None
     if stride != 1 or inplanes != planes * 4:
-        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+        down = nn.Sequential(Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
     layers = [Bottleneck(inplanes, planes, stride, down)]
     layers += [Bottleneck(planes * 4, planes) for _ in range(1, blocks)]
     return nn.Sequential(*layers)
@@ -58,7 +66,7 @@ class _Encoder(nn.Module):
 
     def __init__(self):
         super().__init__()
-        stem = [nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)]
+        stem = [Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)]
         self.layer1 = nn.Sequential(*stem, _stage(64, 64, 3, 1))
         self.layer2 = _stage(256, 128, 4, 2)
         self.layer3 = _stage(512, 256, 23, 2)
@@ -68,8 +76,8 @@ class _Encoder(nn.Module):
 class ResidualConvUnit(nn.Module):
     def __init__(self, features):
         super().__init__()
-        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
-        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+        self.conv1 = Conv2d(features, features, 3, 1, 1, bias=True)
+        self.conv2 = Conv2d(features, features, 3, 1, 1, bias=True)
 
     def forward(self, x):
         out = self.conv1(F.relu(x))
@@ -97,19 +105,31 @@ class _Interpolate(nn.Module):
 
 
 class MidasNet(nn.Module):
-    def __init__(self, path=None, features=256, non_negative=True):
+    def __init__(self, path=None, features=256, non_negative=True, backend="torch"):
         super().__init__()
+        if backend == "hip":
+            from ..ops.conv_layer import HipConv2d
+            _CONV[0] = HipConv2d
+        elif backend != "torch":
+            raise ValueError(f"MidasNet backend {backend!r}")
+        try:
+            self._init(features, non_negative)
+        finally:
+            _CONV[0] = nn.Conv2d
+        self.backend = backend
+        if path:
+            self.load_state_dict(torch.load(path, map_location="cpu"))
+
+    def _init(self, features, non_negative):
         self.pretrained = _Encoder()
         self.scratch = nn.Module()
         for i, c in enumerate((256, 512, 1024, 2048), start=1):
-            setattr(self.scratch, f"layer{i}_rn", nn.Conv2d(c, features, 3, 1, 1, bias=False))
+            setattr(self.scratch, f"layer{i}_rn", Conv2d(c, features, 3, 1, 1, bias=False))
         for i in (4, 3, 2, 1):
             setattr(self.scratch, f"refinenet{i}", FeatureFusionBlock(features))
         self.scratch.output_conv = nn.Sequential(
-            nn.Conv2d(features, 128, 3, 1, 1), _Interpolate(), nn.Conv2d(128, 32, 3, 1, 1), nn.ReLU(True),
-            nn.Conv2d(32, 1, 1, 1, 0), nn.ReLU(True) if non_negative else nn.Identity())
-        if path:
-            self.load_state_dict(torch.load(path, map_location="cpu"))
+            Conv2d(features, 128, 3, 1, 1), _Interpolate(), Conv2d(128, 32, 3, 1, 1), nn.ReLU(True),
+            Conv2d(32, 1, 1, 1, 0), nn.ReLU(True) if non_negative else nn.Identity())
 
     def forward(self, x):
         l1 = self.pretrained.layer1(x)

@@ -22,7 +22,7 @@ class MidasV2Model(DepthModel):
     lambda_view_baseline = 0.0001
     depth_mode = DEPTH_RECIPROCAL  # depth = 1 / disparity, :67
 
-    def __init__(self, support_cpu: bool = False, pretrained: bool = False, seed: int = 0):
+    def __init__(self, support_cpu: bool = False, pretrained: bool = False, seed: int = 0, backend: str = None):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError("MidasV2Model needs the HIP device (no CPU path in consistent_depth_amd)")
@@ -30,7 +30,9 @@ class MidasV2Model(DepthModel):
         self.device = torch.device("cuda", torch.cuda.current_device())
         st = torch.random.get_rng_state()
         torch.manual_seed(seed)
-        self.model = MidasNet(non_negative=True)
+        # convolutions: "hip" = hand-written gfx950 MFMA kernels (ops/conv_layer.py), "torch" = PyTorch-ROCm / MIOpen
+        self.backend = backend or os.environ.get("CD_AMD_MIDAS_BACKEND", "hip")
+        self.model = MidasNet(non_negative=True, backend=self.backend)
         torch.random.set_rng_state(st)
         weights = os.environ.get("CD_AMD_MIDAS_WEIGHTS", os.path.join("checkpoints", "midas_v2.pt"))
         self.pretrained = os.path.isfile(weights)

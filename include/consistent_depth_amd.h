@@ -287,6 +287,16 @@ int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* co
 int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (reference: nn.DataParallel, monodepth/midas_v2_model.py:41-43 and the batch scaling of
+ * depth_fine_tuning.py:155-159): buf <- sum over ranks / world, in place, ONE ncclAllReduce(sum, fp32) on the caller's RCCL
+ * communicator (ncclComm_t passed as void*) + one scale launch, both on `stream`.  librccl is resolved at run time
+ * (the copy already loaded into the process, else dlopen): cd_rccl_available() says whether it was found.
+ * world = 1 with a communicator still runs the collective (smoke tests); world = 1 without one is a no-op.
+ * ---------------------------------------------------------------------------------- */
+int cd_rccl_available(void);
+int cd_allreduce_mean_f32(float* buf, size_t n, void* nccl_comm, int world, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * The hourglass as ONE object: plan, buffers, forward and explicit backward behind a handle, for hosts without Python
  * (reference call site: monodepth/mannequin_challenge_model.py:52-69 netG.forward + autograd, depth_fine_tuning.py:282).
  * A whole fine-tuning step through this header:

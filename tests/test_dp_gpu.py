@@ -112,3 +112,39 @@ def test_rccl_one_rank_smoke(tmp_path):
     assert res["backend"] == "nccl" and res["allreduce_identity"] and res["bytes"] > 20e6
     assert res["graphed"] is True, res["capture_error"]
     assert all(l == l for l in res["losses"])
+
+
+def test_c_abi_allreduce_on_a_raw_rccl_communicator():
+    """cd_allreduce_mean_f32: the collective of the data-parallel step straight from the C ABI, on a communicator created
+    with RCCL's own C API (ncclGetUniqueId / ncclCommInitRank, world = 1 on this box) -- no torch.distributed involved."""
+    import ctypes
+    import torch
+    from consistent_depth_amd import _native
+    lib = _native.lib()
+    assert lib.cd_rccl_available() == 1
+    rccl = None
+    for name in ("librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    assert rccl is not None
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    torch.cuda.set_device(0)
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    buf = torch.randn(5_357_731, device="cuda")          # the hourglass gradient + the loss slot
+    want = buf.clone()
+    assert lib.cd_allreduce_mean_f32(buf.data_ptr(), buf.numel(), comm, 1, _native.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)                        # world 1: sum / 1
+    # the scale path (what world = 4 would do to the summed buffer), without a communicator
+    assert lib.cd_allreduce_mean_f32(buf.data_ptr(), buf.numel(), None, 1, _native.stream_ptr()) == 0
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)

@@ -1,3 +1,5 @@
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_hourglass_engine_gpu.py -m gpu -q -x -s -k "c_handle or eval_mode" 2>&1 | tail -30 > gpurun_out/tests_r02j.txt
-cat gpurun_out/tests_r02j.txt
+set -x
+cd $GRAFT_REPO_ROOT
+export CD_AMD_REPORT=1
+timeout 900 python -m pytest tests/test_midas_gpu.py tests/test_dp_gpu.py -x -q 2>&1 | tail -30
+cp gpurun_out/parity_log.txt gpurun_out/parity_midas.txt 2>/dev/null
