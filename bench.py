@@ -35,10 +35,10 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x2 (fp32), SURVEY.md 8d
 # HBM traffic of the row-sweep gradient kernel per pair at 384x224 from rocprofv3 PMC (profiles/rocprofv3_loss_sweep_b256_r02.txt,
-# separate passes): FETCH_SIZE 344.77 MB x 2 (the guide's gfx950 correction) + WRITE_SIZE 172.04 MB per 256-pair launch
-# = 3.366 MB per pair = 0.98x the algorithmic 3.441 MB (every input read once, every gradient byte written once).  Only
+# separate passes): FETCH_SIZE 346.80 MB x 2 (the guide's gfx950 correction) + WRITE_SIZE 172.04 MB per 256-pair launch
+# = 3.381 MB per pair = 0.98x the algorithmic 3.441 MB (every input read once, every gradient byte written once).  Only
 # valid for the size and the kernel it was measured on; null otherwise.
-LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = (2 * 344.7666e6 + 172.040e6) / 256
+LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = (2 * 346.8037e6 + 172.040e6) / 256
 
 
 _T0 = time.perf_counter()
