@@ -12,7 +12,7 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 
 _lib = None
@@ -46,6 +46,8 @@ SIGNATURES = {
     "cd_conv2d_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_conv2d_fwd_cfg": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_conv2d_packed_co_tiles": (c_i, [c_i, c_i]),
+    "cd_set_conv_arith": (c_i, [c_i]),
+    "cd_get_conv_arith": (c_i, []),
     "cd_debug_force_conv_tile_rows": (c_i, [c_i]),
     "cd_debug_force_conv_co_tiles": (c_i, [c_i]),
     "cd_debug_set_conv_pipeline": (c_i, [c_i]),

@@ -23,7 +23,11 @@
 // The input-gradient convolution (dgrad) is the same kernel on flipped/transposed packed weights.
 // Launch shape (tile rows x channel slices per block) is a run-time choice with bit-identical results;
 // staging is 16-byte wide (aligned superset rows) and software-pipelined through registers where it fits.
+#include <stdlib.h>
+#include <string.h>
+
 #include "cd_common.h"
+#include "conv_split.h"
 
 namespace cd {
 
@@ -47,8 +51,6 @@ template <int KS, int TY_> struct ConvCfg {
     // plane stride == 16 (mod 32): the 4 channels of an A fragment hit disjoint bank halves
     static constexpr int PS = PLANE_RAW + ((16 - (PLANE_RAW % 32)) + 32) % 32;
 };
-
-__host__ __device__ constexpr int co_stride_padded(int cob) { return (cob % 32 == 0) ? cob + 16 : cob; }
 
 // ---------------------------------------------------------------- weight packing
 // w [Cout][Cin][KS][KS] -> packed [co_group][ci_chunk][tap][ci_in_chunk][COBP]  (zero padded)
@@ -414,14 +416,7 @@ static int launch_conv_t(const float* x, int x_ctot, int x_coff, int Cin, const 
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
-// number of 16-wide output-channel tiles a block handles for a given (k, Cout)
-__host__ __device__ static inline int pick_co_tiles(int ks, int cout) {
-    const int need = (cout + 15) / 16;
-    int cap = (ks >= 11) ? 1 : 4;  // LDS: 121 taps x CI x COBP floats must leave room for >= 2 blocks per CU
-    int t = need < cap ? need : cap;
-    if (t == 3) t = 4;
-    return t < 1 ? 1 : t;
-}
+// (pick_co_tiles: 16-wide output-channel tiles per packed group, conv_split.h)
 
 // (tile rows, co tiles per block) for one launch when the caller does not say (cd_conv2d_fwd_cfg lets a caller that
 // has timed the candidates choose -- the hourglass engine does, once per distinct shape).  Rules read off
@@ -458,13 +453,6 @@ static inline void pick_conv_tile(int ks, int pack_cot, int Cout, int N, int H, 
 // of its destination.  Several descriptors may target ONE packed filter (a fused convolution whose output --
 // or, for the transposed/dgrad form, input -- channels are the concatenation of several nn.Conv2d weights):
 // each writes only the (oc, ic) range it owns; padding elements are zeroed once when the arena is allocated.
-struct PackDesc {
-    const float* w; float* packed;
-    int Cout, Cin, ks, transposed;   // the source tensor w[Cout][Cin][ks][ks] and which form to pack
-    int OC, IC, oc_off, ic_off;      // logical channels of the (fused) packed conv and this source's offset in it
-};
-static_assert(sizeof(PackDesc) == 48, "cd_pack_desc layout");
-
 __global__ void pack_weights_table_kernel(const PackDesc* __restrict__ table) {
     const PackDesc d = table[blockIdx.y];
     const int KS = d.ks, OC = d.OC, IC = d.IC;
@@ -491,7 +479,17 @@ __global__ void pack_weights_table_kernel(const PackDesc* __restrict__ table) {
 
 }  // namespace cd
 
-namespace cd { static int g_force_conv_ty = 0, g_force_conv_cot = 0, g_conv_pipe = 1; }
+namespace cd {
+static int g_force_conv_ty = 0, g_force_conv_cot = 0, g_conv_pipe = 1;
+// arithmetic of the k >= 5 convolutions: 1 = split-bf16 (conv_split.hip), 0 = the fp32 matrix instruction.
+// Start-up value from CD_AMD_CONV_ARITH ("fp32" / "split"), default split.
+static int initial_conv_arith() {
+    const char* e = getenv("CD_AMD_CONV_ARITH");
+    if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) return 0;
+    return 1;
+}
+static int g_conv_arith = initial_conv_arith();
+}
 
 extern "C" {
 
@@ -512,19 +510,26 @@ int cd_debug_set_conv_pipeline(int on) {
     return CD_OK;
 }
 
+int cd_set_conv_arith(int mode) {
+    if (!(mode == 0 || mode == 1)) return CD_ERR_INVALID_ARG;
+    cd::g_conv_arith = mode;
+    return CD_OK;
+}
+
+int cd_get_conv_arith(void) { return cd::g_conv_arith; }
+
+// fp32 layout, followed (k = 5, 7, 11) by the split-bf16 layout: both are always packed, the launch picks one
 size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed) {
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
     const int OC = transposed ? Cin : Cout, IC = transposed ? Cout : Cin;
-    const int cot = cd::pick_co_tiles(ks, OC), cob = cot * 16, cobp = cd::co_stride_padded(cob);
-    const int ci_chunk = ks >= 7 ? 4 : (ks == 1 ? 32 : 8);
-    const int groups = (OC + cob - 1) / cob, chunks = (IC + ci_chunk - 1) / ci_chunk;
-    return (size_t)groups * chunks * ks * ks * ci_chunk * cobp;
+    return cd::fp32_packed_floats(OC, IC, ks) + cd::split_packed_floats(OC, IC, ks);
 }
 
 int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transposed, float* packed, void* stream) {
-    const size_t total = cd_conv2d_packed_weight_floats(Cout, Cin, ks, transposed);
+    if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return CD_ERR_INVALID_ARG;
+    const int OC = transposed ? Cin : Cout, IC = transposed ? Cout : Cin;
+    const size_t total = cd::fp32_packed_floats(OC, IC, ks);
     if (!w || !packed || total == 0) return CD_ERR_INVALID_ARG;
-    const int OC = transposed ? Cin : Cout;
     const int cot = cd::pick_co_tiles(ks, OC), cob = cot * 16, cobp = cd::co_stride_padded(cob);
     const int ci_chunk = ks >= 7 ? 4 : (ks == 1 ? 32 : 8);
     size_t blocks = (total + 255) / 256;
@@ -532,6 +537,11 @@ int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transp
     hipLaunchKernelGGL(cd::pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ks,
                        ci_chunk, cob, cobp, transposed, packed, total);
     CD_CHECK_LAUNCH();
+    if (cd::split_supported(ks)) {   // the split layout's padding must be zero: the one-filter form clears it itself
+        const size_t nsplit = cd::split_packed_floats(OC, IC, ks);
+        if (hipMemsetAsync(packed + total, 0, nsplit * sizeof(float), (hipStream_t)stream) != hipSuccess) return CD_ERR_LAUNCH;
+        return cd::launch_pack_split(w, Cout, Cin, ks, transposed, packed + total, (hipStream_t)stream);
+    }
     return CD_OK;
 }
 
@@ -539,7 +549,7 @@ int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream) {
     if (!table_dev || n <= 0 || n > 65535) return CD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(cd::pack_weights_table_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const cd::PackDesc*)table_dev);
     CD_CHECK_LAUNCH();
-    return CD_OK;
+    return cd::launch_pack_split_table(table_dev, n, (hipStream_t)stream);
 }
 
 int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w, const float* bias,
@@ -566,6 +576,9 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     // back wrong (tests/test_conv_gpu.py::test_launch_shapes_are_bit_identical catches it; every other
     // instantiation is bit-identical across launch shapes).  8-row tiles are within a few % on the shapes concerned.
     if (ks == 7 && cot == 1 && ty == 16) ty = 8;
+    if (cd::g_conv_arith == 1 && cd::split_supported(ks) && Cin >= 8)   // (the 3-channel stem would pad K 8/3-fold: fp32 kernel)
+        return cd::launch_conv_split(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift,
+                                     in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, ks, ty, cot, s);
     const int pipe = cd::g_conv_pipe;
 #define CD_CONV(K, T, Y) return cd::launch_conv_t<K, T, Y>(x, x_ctot, x_coff, Cin, packed_w, pack_cot, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, pipe, s)
 #define CD_CONV_T(K, T)                     \

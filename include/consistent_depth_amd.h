@@ -246,6 +246,14 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
                       const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                       float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                       int N, int H, int W, int ks, int tile_rows, int co_tiles, void* stream);
+/* Arithmetic of the k = 5, 7, 11 convolutions (forward and input gradient), process-wide:
+ *   1 (default; start-up value from CD_AMD_CONV_ARITH = "split" | "fp32"): every fp32 operand is split exactly into three
+ *     bf16 terms and the six significant cross products run on the BF16 matrix cores with fp32 accumulation --
+ *     as close to fp64 as the fp32 instruction (profiles/mfma_split_exp_r02.txt), ~2x faster; not bitwise the fmaf chain;
+ *   0: the fp32 matrix instruction (bitwise a k-ordered fmaf chain).
+ * The packed filter holds both layouts, so the mode may change between launches without re-packing. */
+int cd_set_conv_arith(int mode);
+int cd_get_conv_arith(void);
 /* The upper bound of co_tiles for (Cout, ks). */
 int cd_conv2d_packed_co_tiles(int Cout, int ks);
 

@@ -4,7 +4,21 @@ K-long dot product)."""
 import numpy as np
 import pytest
 
+from tests.gpu_util import report
+
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["split", "fp32"])
+def arith(request):
+    """Every test runs under both arithmetic modes of the k >= 5 convolutions (cd_set_conv_arith): the split-bf16 kernel
+    (default) and the fp32 matrix instruction."""
+    from consistent_depth_amd import _native
+    lib = _native.lib()
+    before = lib.cd_get_conv_arith()
+    assert lib.cd_set_conv_arith(1 if request.param == "split" else 0) == 0
+    yield request.param
+    lib.cd_set_conv_arith(before)
 
 CASES = [
     # N, Cin, Cout, H, W, ks
@@ -46,6 +60,33 @@ def test_conv_fwd_matches_torch(N, Cin, Cout, H, W, ks, ty):
         _native.lib().cd_debug_force_conv_tile_rows(0)
     err = (y.cpu().double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [(2, 64, 16, 40, 64, 11), (2, 16, 64, 40, 64, 11), (2, 64, 32, 32, 64, 7), (2, 32, 64, 24, 32, 5),
+                                               (1, 64, 64, 96, 56, 11)])
+def test_split_arithmetic_is_as_close_to_fp64_as_the_fp32_instruction(N, Cin, Cout, H, W, ks, arith):
+    """The licence for the split-bf16 kernel: on the same inputs its distance to the fp64 result is not larger than that of
+    the fp32 matrix instruction (both printed).  Inputs with a non-zero mean (post-ReLU activations) make the sums long."""
+    if arith != "split":
+        pytest.skip("one comparison covers both modes")
+    import torch
+    from consistent_depth_amd import _native
+    from consistent_depth_amd.ops import conv
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(ks * 31 + Cin)
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g) + 0.5)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks)
+    ref = _ref(x, w, None, ks)
+    pk = conv.pack_weights(w.cuda())
+    err = {}
+    for name, mode in (("split", 1), ("fp32", 0)):
+        lib.cd_set_conv_arith(mode)
+        y = conv.conv2d(x.cuda(), pk, Cin, Cout, ks)
+        d = (y.cpu().double() - ref).abs()
+        err[name] = (d.max().item() / ref.abs().max().item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
+    report("conv_split_vs_fp32", shape=f"{N}x{Cin}->{Cout}x{H}x{W}k{ks}", split_max=f"{err['split'][0]:.2e}", fp32_max=f"{err['fp32'][0]:.2e}",
+           split_rms=f"{err['split'][1]:.2e}", fp32_rms=f"{err['fp32'][1]:.2e}")
+    assert err["split"][0] <= 1.5 * err["fp32"][0] + 1e-8 and err["split"][1] <= 1.25 * err["fp32"][1] + 1e-9
 
 
 def test_conv_channel_slices_fused_input_and_stats():

@@ -29,8 +29,14 @@ def main():
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--dgrad", action="store_true", help="bench the dgrad-shaped convolutions instead")
     ap.add_argument("--wgrad", action="store_true", help="bench the weight-gradient kernel on the forward shapes")
+    ap.add_argument("--arith", choices=["split", "fp32"], default=None, help="arithmetic of the k >= 5 convolutions (default: library default)")
+    ap.add_argument("--cfgs", default="", help="launch shapes to time, e.g. '16x1,8x1,16x2' (tile rows x co tiles); default: the heuristic")
     args = ap.parse_args()
+    from consistent_depth_amd import _native
     from consistent_depth_amd.ops import conv
+    if args.arith:
+        _native.lib().cd_set_conv_arith(1 if args.arith == "split" else 0)
+    cfgs = [tuple(int(v) for v in c.split("x")) for c in args.cfgs.split(",") if c] or [None]
     N = 8
     for i, (H, W, ks, Cin, Cout, share) in enumerate(DGRAD_SHAPES if args.dgrad else SHAPES):
         if args.only >= 0 and i != args.only:
@@ -60,8 +66,11 @@ def main():
             ws = conv.wgrad_workspace(Cout, Cin, ks, "cuda")
             ms = timeit(lambda: conv.conv2d_wgrad(x, dy, Cin, Cout, ks, dw, ws, in_relu=True))
         else:
-            ms = timeit(lambda: conv.conv2d(x, pk, Cin, Cout, ks, bias=b, out=out))
+            per_cfg = {("heuristic" if c is None else "%dx%d" % c): timeit(lambda: conv.conv2d(x, pk, Cin, Cout, ks, bias=b, out=out, cfg=c)) for c in cfgs}
+            ms = min(per_cfg.values())
         rec = {"shape": [H, W, ks, Cin, Cout], "share_pct": share, "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1)}
+        if not args.wgrad and len(cfgs) > 1:
+            rec["cfgs_ms"] = {k: round(v, 4) for k, v in per_cfg.items()}
         if args.torch:
             ms_t = timeit(lambda: torch.nn.functional.conv2d(x, w, b, padding=(ks - 1) // 2))
             rec["torch_ms"] = round(ms_t, 4)

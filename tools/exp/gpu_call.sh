@@ -1,8 +1,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
-timeout 120 tools/exp/mfma_split_exp > gpurun_out/mfma_split_exp.txt 2>&1
-cat gpurun_out/mfma_split_exp.txt
-timeout 600 bash tools/prof_loss.sh r02final --batches 256 --iters 10 > gpurun_out/prof_loss_r02final.log 2>&1
-tail -5 gpurun_out/prof_loss_r02final.log
-timeout 600 python bench.py > gpurun_out/bench_r02_n1.json 2> gpurun_out/bench_r02_n1.err
-cat gpurun_out/bench_r02_n1.json
+export CD_AMD_REPORT=1
+timeout 900 python -m pytest tests/test_conv_gpu.py -x -q 2>&1 | tail -25
+cp gpurun_out/parity_log.txt gpurun_out/parity_conv_split.txt 2>/dev/null
+for a in fp32 split; do
+for i in 0 1 2 3 5 7; do timeout 120 python tools/conv_bench.py --arith $a --only $i --cfgs 16x1,8x1,4x1,16x2,8x2 ; done
+for i in 0 1 3; do timeout 120 python tools/conv_bench.py --dgrad --arith $a --only $i --cfgs 16x1,8x1,16x2,8x2 ; done
+done > gpurun_out/conv_split_bench.txt 2>&1
+cat gpurun_out/conv_split_bench.txt
