@@ -562,6 +562,15 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     const int pack_cot = cd::pick_co_tiles(ks, Cout);
     if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16)) return CD_ERR_INVALID_ARG;
     if (!(co_tiles == 0 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4 || co_tiles == 8 || co_tiles == 16)) return CD_ERR_INVALID_ARG;
+    if (cd::g_conv_arith == 1 && cd::split_supported(ks) && Cin >= 8) {   // (the 3-channel stem would pad K 8/3-fold: fp32 kernel)
+        // launch-shape hints: tile_rows <= 4 -> 4 M-tiles per block, else 8; co_tiles >= 2 -> two 32-column tiles per block (then 4
+        // M-tiles).  Unhinted: 4 M-tiles, two column tiles when the filter has them and the image is large (conv_split_bench)
+        int sty = cd::g_force_conv_ty ? cd::g_force_conv_ty : tile_rows, scot = cd::g_force_conv_cot ? cd::g_force_conv_cot : co_tiles;
+        if (sty == 0) sty = 4;
+        if (scot == 0) scot = ((long long)N * H * W > 8LL * 96 * 56) ? 2 : 1;
+        return cd::launch_conv_split(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift,
+                                     in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, ks, sty, scot, s);
+    }
     int ty, cot;
     cd::pick_conv_tile(ks, pack_cot, Cout, N, H, W, &ty, &cot);
     const int max_cot = cd::max_co_tiles(ks, Cout);
@@ -576,9 +585,6 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     // back wrong (tests/test_conv_gpu.py::test_launch_shapes_are_bit_identical catches it; every other
     // instantiation is bit-identical across launch shapes).  8-row tiles are within a few % on the shapes concerned.
     if (ks == 7 && cot == 1 && ty == 16) ty = 8;
-    if (cd::g_conv_arith == 1 && cd::split_supported(ks) && Cin >= 8)   // (the 3-channel stem would pad K 8/3-fold: fp32 kernel)
-        return cd::launch_conv_split(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift,
-                                     in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, ks, ty, cot, s);
     const int pipe = cd::g_conv_pipe;
 #define CD_CONV(K, T, Y) return cd::launch_conv_t<K, T, Y>(x, x_ctot, x_coff, Cin, packed_w, pack_cot, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, pipe, s)
 #define CD_CONV_T(K, T)                     \
@@ -610,6 +616,9 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                              accumulate, N, H, W, ks, 0, 0, stream);
 }
 
-int cd_conv2d_packed_co_tiles(int Cout, int ks) { return cd::max_co_tiles(ks, Cout); }
+int cd_conv2d_packed_co_tiles(int Cout, int ks) {
+    if (cd::g_conv_arith == 1 && cd::split_supported(ks)) return cd::split_column_tiles(Cout) >= 2 ? 2 : 1;
+    return cd::max_co_tiles(ks, Cout);
+}
 
 }  // extern "C"

@@ -37,6 +37,9 @@ __host__ __device__ inline size_t fp32_packed_floats(int OC, int IC, int ks) {
 // floats appended to the fp32 packed filter of the logical convolution IC -> OC (0 when unsupported)
 size_t split_packed_floats(int OC, int IC, int ks);
 
+// 32-wide column tiles of the split layout for OC output channels (1 when OC <= 16: 16 channels x 2 output rows)
+int split_column_tiles(int OC);
+
 int launch_pack_split_table(const void* table_dev, int n, hipStream_t s);
 int launch_pack_split(const float* w, int Cout, int Cin, int ks, int transposed, float* packed_split, hipStream_t s);
 

@@ -1,7 +1,8 @@
 // Direct 2-D convolution at fp32 accuracy on the gfx950 BF16 matrix cores (forward and input gradient, k in {5, 7, 11}).
 //
 // CDNA4 has no TF32/xf32 and its fp32 matrix instruction runs at the vector rate (157 TFLOP/s); the bf16 instruction
-// v_mfma_f32_16x16x32_bf16 is ~10-15x faster per multiply-add.  Every fp32 operand is split EXACTLY into three bf16 terms
+// v_mfma_f32_32x32x16_bf16 is ~14x faster per multiply-add (2.1 PFLOP/s measured, profiles/mfma_rate_exp_r02.txt).  Every
+// fp32 operand is split EXACTLY into three bf16 terms
 //     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (RNE; 3 x 8 = 24 mantissa bits)
 // and a product is evaluated as the six cross terms of weight  >= 2^-16:  hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi
 // (each bf16 x bf16 product is exact in fp32; the dropped mid*lo, lo*mid, lo*lo terms are < 2^-25 |x*y|, below half an fp32
@@ -10,18 +11,23 @@
 // identical with all nine terms), so no precision is traded; what IS different: the result is not bitwise the fmaf chain
 // of conv_mfma.hip (cd_set_conv_arith(0) selects that kernel), and an infinite input gives NaN instead of +-inf.
 //
-// Mapping (implicit GEMM, no im2col buffer): M = 16 consecutive output pixels of one row, N = 16 output channels,
-// K = 32 = 8 input channels x 4 consecutive filter taps (taps flattened ky * KS + kx, padded to a multiple of 4 with zero
-// weights: 121 -> 124, 49 -> 52, 25 -> 28).
-//   A[i = lane&15][8 * (lane>>4) + e] = act(in)[ci0 + e][y + ky][x0 + i + kx],  (ky, kx) = tap 4*step + (lane>>4)
+// Mapping (implicit GEMM, no im2col buffer): M = the 32 output pixels of one tile row, N = 32 output columns,
+// K = 16 = 8 input channels x 2 consecutive filter taps (taps flattened ky * KS + kx).
+//   A[i = lane&31][8 * (lane>>5) + e] = act(in)[ci0 + e][y + ky][x0 + i + kx],  (ky, kx) = tap 2*step + (lane>>5)
 //        one ds_read_b128 per split: the LDS tile is channels-last, 8 bf16 channels = 16 bytes per pixel, three planes
-//   B[8 * (lane>>4) + e][j = lane&15] = w[co0 + j][ci0 + e][tap]
+//   B[8 * (lane>>5) + e][n = lane&31] = w[column n][ci0 + e][tap]
 //        pre-packed in exactly this fragment order (3 x 1 KB per step), read straight from global/L2 one step ahead
-//   D: lane holds channel co0 + (lane&15), pixels x0 + 4*(lane>>4) + {0..3}  (same as the fp32 kernel: same epilogue).
-// A block (4 waves) owns a TY x 32 output tile for CO_T*16 output channels; input channels stream through LDS 8 at a time
-// (global fp32 -> producer's BN-apply + ReLU -> split -> LDS).  Per step a wave reads 3 KB of LDS per pixel tile and issues
-// 6 MFMAs per (pixel tile, channel tile): with one channel tile (Cout = 16) the kernel is LDS-bandwidth bound, with two
-// or more MFMA bound.  Fusions (input affine/ReLU, bias, accumulate, BatchNorm statistics) are those of conv_mfma.hip.
+//   D: lane holds column lane&31, pixels 8*q + 4*(lane>>5) + {0..3}, q = 0..3  -> four 16-byte stores.
+// Columns: 32 output channels -- or, when the convolution has at most 16 of them (the 64->16 branches of the finest level,
+// the largest share of the network's multiply-adds), 16 channels x 2 OUTPUT ROWS: column (co, dy) of the M-tile of row y is
+// output row y + dy, with the filter shifted down by dy (taps over KS + 1 rows, zero weights where the shift leaves the
+// filter), so an M-tile exists only for every other row.  That keeps all 32 columns busy at (KS+1)/KS of the multiply-adds
+// and halves the LDS bytes per multiply-add (a pixel fragment feeds 32 columns either way).
+// A block (4 waves) owns a TY x 32 output tile for NT*32 columns; input channels stream through LDS 8 at a time
+// (global fp32 -> producer's BN-apply + ReLU -> split -> LDS).  Per step a wave reads 3 KB of LDS per M-tile and issues
+// 6 MFMAs (32 cycles each) per (M-tile, column tile): LDS <= 50% busy.  The six products of one accumulator are issued
+// round-robin over the wave's accumulators (a dependent MFMA right behind its producer stalls the pipe).
+// Fusions (input affine/ReLU, bias, accumulate, BatchNorm statistics) are those of conv_mfma.hip.
 #include "cd_common.h"
 #include "conv_split.h"
 
@@ -50,9 +56,17 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
     l = cvt_pk_bf16(ra - bf16_lo(m), rb - bf16_hi(m));
 }
 
-template <int KS, int TY_> struct SplitCfg {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// DY = output rows per M-tile (2 when the convolution has <= 16 output channels)
+__host__ __device__ constexpr int split_dy(int OC) { return OC <= 16 ? 2 : 1; }
+__host__ __device__ constexpr int split_taps(int ks, int dy) { return (ks + dy - 1) * ks; }      // flattened (ky', kx), ky' over KS + DY - 1 rows
+__host__ __device__ constexpr int split_steps(int ks, int dy) { return (split_taps(ks, dy) + 1) / 2; }
+__host__ __device__ constexpr int split_ntiles(int OC) { return split_dy(OC) == 2 ? 1 : (OC + 31) / 32; }
+
+template <int KS, int TY_, int DY> struct SplitCfg {
     static constexpr int TY = TY_;
-    static constexpr int TAPS = KS * KS, KSTEPS = (TAPS + 3) / 4;
+    static constexpr int TAPS = split_taps(KS, DY), KSTEPS = split_steps(KS, DY);
     static constexpr int ROWS = TY + KS - 1;
     static constexpr int PADL = (((KS - 1) / 2) + 3) & ~3;          // aligned superset rows, as in conv_mfma.hip
     static constexpr int RSP = SP_TX + 2 * PADL, COFF = PADL - (KS - 1) / 2;
@@ -61,12 +75,14 @@ template <int KS, int TY_> struct SplitCfg {
 };
 
 // ---------------------------------------------------------------- weight packing (split layout)
-// [co tile][ci chunk of 8][step][split][lane][8 bf16]; element e of lane (j, g) = w[tile*16 + j][chunk*8 + e][tap 4*step + g]
+// [column tile][ci chunk of 8][step][split][lane][8 bf16]; element e of lane (n = lane&31, g = lane>>5) is
+// w[column n][chunk*8 + e][tap 2*step + g]; column n = output channel tile*32 + n, or (OC <= 16) channel n&15 of output row
+// dy = n>>4, whose filter row is ky' - dy.
 __device__ __forceinline__ void pack_split_elements(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout_src, int Cin_src,
                                                     int KS, int transposed, int OC, int IC, int oc_off, int ic_off, size_t first,
                                                     size_t stride) {
     const int oc_n = transposed ? Cin_src : Cout_src, ic_n = transposed ? Cout_src : Cin_src;
-    const int taps = KS * KS, ksteps = (taps + 3) / 4, chunks = (IC + 7) / 8, tiles = (OC + 15) / 16;
+    const int dy_n = split_dy(OC), taps = split_taps(KS, dy_n), ksteps = split_steps(KS, dy_n), chunks = (IC + 7) / 8, tiles = split_ntiles(OC);
     const size_t total = (size_t)tiles * chunks * ksteps * 512;
     for (size_t i = first; i < total; i += stride) {
         size_t r = i;
@@ -75,10 +91,11 @@ __device__ __forceinline__ void pack_split_elements(const float* __restrict__ w,
         const int step = (int)(r % ksteps); r /= ksteps;
         const int chunk = (int)(r % chunks); r /= chunks;
         const int tile = (int)r;
-        const int tap = step * 4 + (lane >> 4);
-        const int oc = tile * 16 + (lane & 15) - oc_off, ic = chunk * 8 + e - ic_off;
-        if (tap >= taps || (unsigned)oc >= (unsigned)oc_n || (unsigned)ic >= (unsigned)ic_n) continue;   // padding stays zero
-        const int ky = tap / KS, kx = tap - ky * KS;
+        const int tap = step * 2 + (lane >> 5), n = lane & 31;
+        const int kyp = tap / KS, kx = tap - kyp * KS;
+        const int ky = dy_n == 2 ? kyp - (n >> 4) : kyp;
+        const int oc = (dy_n == 2 ? (n & 15) : tile * 32 + n) - oc_off, ic = chunk * 8 + e - ic_off;
+        if (tap >= taps || (unsigned)ky >= (unsigned)KS || (unsigned)oc >= (unsigned)oc_n || (unsigned)ic >= (unsigned)ic_n) continue;   // stays zero
         const float v = transposed ? w[(((size_t)ic * Cin_src + oc) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)]
                                    : w[(((size_t)oc * Cin_src + ic) * KS + ky) * KS + kx];
         unsigned h, m, l;
@@ -109,20 +126,31 @@ int launch_pack_split_table(const void* table_dev, int n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------- the convolution
-template <int KS, int CO_T, int TYP>
-__global__ __launch_bounds__(kBlock) void conv_fwd_split_kernel(
+// NT = column tiles (32 wide) per block, TYP = output rows per block, DY = output rows per M-tile.
+// Work split inside a block: ALL four waves hold accumulators for ALL MB = TYP / DY M-tiles of the block and divide the
+// reduction dimension -- wave w takes the steps (chunk * KSTEPS + step) % 4 == w -- so a weight fragment is fetched by one
+// wave only (with the M-tiles divided instead, every wave fetched every fragment: 64 B/clk/CU of L1 traffic, the measured
+// bottleneck).  At the end the four partial sums of an M-tile are added in a fixed order through LDS by the wave that
+// stores it.  The order of accumulation depends on nothing but (Cin, KS, DY): every launch shape gives the same bits.
+constexpr size_t SPLIT_REDUCE_LDS = 4 * 3 * 4096;   // one round of the cross-wave reduction: 4 owners x 3 foreign partials x 4 KB
+
+template <int KS, int NT, int TYP, int DY>
+__global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
     const u32x4* __restrict__ wsp, int pack_tiles, const float* __restrict__ bias,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     float* __restrict__ y, int y_ctot, int y_coff, int Cout,
     double* __restrict__ stats, int accumulate, int H, int W, int tiles_x, int tiles_img, int tiles_total, int chunk_tiles,
     int slices) {
-    using Cfg = SplitCfg<KS, TYP>;
+    using Cfg = SplitCfg<KS, TYP, DY>;
     constexpr int TY = Cfg::TY, ROWS = Cfg::ROWS, RSP = Cfg::RSP, COFF = Cfg::COFF, PADL = Cfg::PADL, PLANE = Cfg::PLANE;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, KSTEPS = Cfg::KSTEPS;
-    constexpr int COB = CO_T * 16;
-    constexpr int RPW = TY / 4, MT = RPW * 2;
+    constexpr int MB = TY / DY;                       // M-tiles (tile rows, DY output rows each) per block
+    constexpr int MG = 4;                             // M-tiles whose fragments are in registers at a time
+    constexpr int CPT = DY == 2 ? 16 : 32;            // output channels per column tile
+    constexpr int COB = NT * CPT;
     constexpr int UNITS = ROWS * (RSP / 4);           // staging units: (row, 4-pixel quad) x 8 channels
+    static_assert(MB % 4 == 0 && MB * NT <= 8, "M-tiles are owned round-robin by the 4 waves; 128 accumulator registers");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* s_in = reinterpret_cast<u32x4*>(smem_raw);   // [3][ROWS][RSP] 16-byte slots (8 bf16 channels of one pixel)
@@ -136,43 +164,43 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_split_kernel(
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int X0 = tx * SP_TX, Y0 = ty * TY;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int li = lane & 15, g = lane >> 4;
+    const int li = lane & 31, g = lane >> 5;
     const size_t HW = (size_t)H * W;
     const float* xin = x + ((size_t)n * x_ctot + x_coff) * HW;
     const int n_chunks = (Cin + 7) / 8;
     const bool vec_in = (W & 3) == 0;
 
-    f32x4 acc[MT][CO_T];
+    f32x16 acc[MB][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int t = 0; t < CO_T; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][t][q] = 0.f;
 
-    // the weight stream of channel tile t: [chunk][step][split][lane], linear in (chunk, step)
-    const u32x4* wt[CO_T];
-    bool live[CO_T];
+    // the weight stream of column tile t: [chunk][step][split][lane], linear in (chunk, step).  A column tile beyond the
+    // filter (odd tile count, NT = 2) re-computes tile 0 and is dropped by the epilogue's channel bound.
+    const u32x4* wt[NT];
 #pragma unroll
-    for (int t = 0; t < CO_T; ++t) {
-        const int gt = slice * CO_T + t;
-        live[t] = gt < pack_tiles;   // block-uniform
-        wt[t] = wsp + (size_t)(live[t] ? gt : 0) * n_chunks * KSTEPS * 192 + lane;
+    for (int t = 0; t < NT; ++t) {
+        const int gt = slice * NT + t;
+        wt[t] = wsp + (size_t)(gt < pack_tiles ? gt : 0) * n_chunks * KSTEPS * 192 + lane;
     }
     const int steps_total = n_chunks * KSTEPS;
-    bf16x8 bcur[CO_T][3], bnext[CO_T][3];
-    auto load_b = [&](bf16x8 (&dst)[CO_T][3], int lin) {
+    bf16x8 bcur[NT][3], bnext[NT][3];
+    auto load_b = [&](bf16x8 (&dst)[NT][3], int lin) {
 #pragma unroll
-        for (int t = 0; t < CO_T; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) {
                 const u32x4 v = wt[t][(size_t)lin * 192 + sp * 64];
                 dst[t][sp] = __builtin_bit_cast(bf16x8, v);
             }
     };
-    load_b(bcur, 0);
+    int lin = wid;   // this wave's next step, linear over (chunk, step)
+    if (lin < steps_total) load_b(bcur, lin);
 
-    int arow[MT];   // LDS slot of this lane's pixel for pixel tile m at tap (0, 0)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) arow[m] = (wid * RPW + (m >> 1)) * RSP + (m & 1) * 16 + li + COFF;
+    const int abase = li + COFF;   // LDS slot of this lane's pixel in tile row 0 at tap (0, 0)
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         __syncthreads();   // the previous chunk's fragments are consumed
@@ -222,90 +250,138 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_split_kernel(
         }
         __syncthreads();
 
-        // ---- MFMA over the tap steps of this chunk
-        int ky = 0, kx = g;   // this lane's tap of the current step: 4 * step + g  (g < 4 < KS)
+        // ---- MFMA over this wave's tap steps of the chunk
+        const int lin_end = (chunk + 1) * KSTEPS;
 #pragma unroll 1
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int lin = chunk * KSTEPS + s;
-            if (lin + 1 < steps_total) load_b(bnext, lin + 1);
-            const int toff = (s * 4 + g < TAPS) ? ky * RSP + kx : 0;   // padded taps carry zero weights: any valid slot
+        for (; lin < lin_end; lin += 4) {
+            if (lin + 4 < steps_total) load_b(bnext, lin + 4);
+            const int tap = (lin - chunk * KSTEPS) * 2 + g;
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const int slot0 = abase + ((tap < TAPS) ? ky * RSP + kx : 0);   // a padded tap carries zero weights: any valid slot
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, smallest first
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int slot = arow[m] + toff;
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, s_in[slot]);
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, s_in[PLANE + slot]);
-                const bf16x8 a2 = __builtin_bit_cast(bf16x8, s_in[2 * PLANE + slot]);
+            for (int mg = 0; mg < MB; mg += MG) {
+                bf16x8 a[MG][3];
 #pragma unroll
-                for (int t = 0; t < CO_T; ++t) {
-                    if (!live[t]) continue;
-                    f32x4 c = acc[m][t];   // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bcur[t][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bcur[t][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bcur[t][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bcur[t][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bcur[t][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bcur[t][0], c, 0, 0, 0);
-                    acc[m][t] = c;
+                for (int m = 0; m < MG; ++m) {
+                    const int slot = slot0 + (mg + m) * DY * RSP;
+                    a[m][0] = __builtin_bit_cast(bf16x8, s_in[slot]);
+                    a[m][1] = __builtin_bit_cast(bf16x8, s_in[PLANE + slot]);
+                    a[m][2] = __builtin_bit_cast(bf16x8, s_in[2 * PLANE + slot]);
                 }
-            }
-            kx += 4;
-            if (kx >= KS) { kx -= KS; ++ky; }
 #pragma unroll
-            for (int t = 0; t < CO_T; ++t)
+                for (int p = 0; p < 6; ++p)   // round-robin over the accumulators: a dependent MFMA never follows its producer
+#pragma unroll
+                    for (int m = 0; m < MG; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[mg + m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[p]], bcur[t][PB[p]], acc[mg + m][t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp) bcur[t][sp] = bnext[t][sp];
         }
     }
 
-    // ---- epilogue: bias, store, batch statistics of the raw output (identical to conv_mfma.hip: same D layout)
-    const int co_l = li, px4 = g * 4;
-    const int co_base = slice * COB;
-    float* yout = y + ((size_t)n * y_ctot + y_coff) * HW;
-    double s1[CO_T], s2[CO_T];
+    // ---- cross-wave reduction: M-tile 4j + o belongs to wave o; per round (j, t) the three other waves hand their partial
+    // sums over through LDS and the owner adds (P0 + P1) + (P2 + P3)
+    f32x4* s_red = reinterpret_cast<f32x4*>(smem_raw);   // [owner][foreign slot 0..2][4 register quads][64 lanes]
 #pragma unroll
-    for (int t = 0; t < CO_T; ++t) {
-        const int co = co_base + t * 16 + co_l;
+    for (int j = 0; j < MB / 4; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            __syncthreads();   // the MFMA operands / the previous round are consumed
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o == wid) continue;   // wave-uniform
+                const int fs = wid < o ? wid : wid - 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    s_red[((o * 3 + fs) * 4 + q) * 64 + lane] = f32x4{acc[4 * j + o][t][4 * q], acc[4 * j + o][t][4 * q + 1], acc[4 * j + o][t][4 * q + 2], acc[4 * j + o][t][4 * q + 3]};
+            }
+            __syncthreads();
+            // the owner's own partial sits at position `wid` of the fixed order
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 pw[4];
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    // (selected per wave below: all four acc tiles are compile-time indexed)
+                    pw[w2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    if (o != wid) continue;   // wave-uniform: o is this wave
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        if (w2 == o) pw[w2] = f32x4{acc[4 * j + o][t][4 * q], acc[4 * j + o][t][4 * q + 1], acc[4 * j + o][t][4 * q + 2], acc[4 * j + o][t][4 * q + 3]};
+                        else pw[w2] = s_red[((o * 3 + (w2 < o ? w2 : w2 - 1)) * 4 + q) * 64 + lane];
+                    }
+                    const f32x4 sum = (pw[0] + pw[1]) + (pw[2] + pw[3]);
+                    acc[4 * j + o][t][4 * q] = sum[0]; acc[4 * j + o][t][4 * q + 1] = sum[1]; acc[4 * j + o][t][4 * q + 2] = sum[2]; acc[4 * j + o][t][4 * q + 3] = sum[3];
+                }
+            }
+        }
+
+    // ---- epilogue: bias, store, batch statistics of the raw output.  D: column = lane&31, pixels 8q + 4g + {0..3};
+    // this wave stores the M-tiles 4j + wid
+    const int co_base = slice * COB;
+    const int dy_l = DY == 2 ? (li >> 4) : 0, co_l = DY == 2 ? (li & 15) : li;
+    float* yout = y + ((size_t)n * y_ctot + y_coff) * HW;
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = co_base + t * CPT + co_l;
         const float bv = (bias != nullptr && co < Cout) ? bias[co] : 0.f;
         s1[t] = 0.0; s2[t] = 0.0;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int gy = Y0 + wid * RPW + (m >> 1), gx = X0 + (m & 1) * 16 + px4;
-            f32x4 v = acc[m][t];
-            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-            if (co < Cout && gy < H) {
-                float* dst = yout + (size_t)co * HW + (size_t)gy * W + gx;
-                if (gx + 3 < W && ((W & 3) == 0)) {
-                    if (accumulate) {
-                        const float4 o = *reinterpret_cast<const float4*>(dst);
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    *reinterpret_cast<float4*>(dst) = make_float4(v.x, v.y, v.z, v.w);
-                    if (stats != nullptr) {
-                        const double a = v.x, b = v.y, c = v.z, d = v.w;
-                        s1[t] += (a + b) + (c + d);
-                        s2[t] += (a * a + b * b) + (c * c + d * d);
-                    }
-                } else {
-                    float e[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; j < MB / 4; ++j) {
+            const int gy = Y0 + (4 * j + wid) * DY + dy_l;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (gx + q < W) {
-                            if (accumulate) e[q] += dst[q];
-                            dst[q] = e[q]; s1[t] += (double)e[q]; s2[t] += (double)e[q] * (double)e[q];
+            for (int q = 0; q < 4; ++q) {
+                const int gx = X0 + 8 * q + 4 * g;
+                float e[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o == wid) {   // wave-uniform select of the owned accumulator (compile-time register indices)
+                        e[0] = acc[4 * j + o][t][4 * q] + bv; e[1] = acc[4 * j + o][t][4 * q + 1] + bv;
+                        e[2] = acc[4 * j + o][t][4 * q + 2] + bv; e[3] = acc[4 * j + o][t][4 * q + 3] + bv;
+                    }
+                if (co < Cout && gy < H) {
+                    float* dst = yout + (size_t)co * HW + (size_t)gy * W + gx;
+                    if (gx + 3 < W && ((W & 3) == 0)) {
+                        if (accumulate) {
+                            const float4 o4 = *reinterpret_cast<const float4*>(dst);
+                            e[0] += o4.x; e[1] += o4.y; e[2] += o4.z; e[3] += o4.w;
                         }
+                        *reinterpret_cast<float4*>(dst) = make_float4(e[0], e[1], e[2], e[3]);
+                        if (stats != nullptr) {
+                            const double a = e[0], b = e[1], c = e[2], d = e[3];
+                            s1[t] += (a + b) + (c + d);
+                            s2[t] += (a * a + b * b) + (c * c + d * d);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (gx + k < W) {
+                                if (accumulate) e[k] += dst[k];
+                                dst[k] = e[k]; s1[t] += (double)e[k]; s2[t] += (double)e[k] * (double)e[k];
+                            }
+                    }
                 }
             }
         }
     }
-    if (stats != nullptr) {  // block-uniform; reduction as in conv_mfma.hip
+    if (stats != nullptr) {  // block-uniform; lanes of one channel: +32 (pixel half), and for DY = 2 also +16 (the other row)
         __syncthreads();
         double* red = reinterpret_cast<double*>(smem_raw);   // [4 waves][COB][2]
 #pragma unroll
-        for (int t = 0; t < CO_T; ++t) {
+        for (int t = 0; t < NT; ++t) {
             double a = s1[t], b = s2[t];
-            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
             a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-            if (lane < 16) { red[(wid * COB + t * 16 + co_l) * 2] = a; red[(wid * COB + t * 16 + co_l) * 2 + 1] = b; }
+            if (DY == 2) { a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); }
+            if (lane < CPT) { red[(wid * COB + t * CPT + lane) * 2] = a; red[(wid * COB + t * CPT + lane) * 2 + 1] = b; }
         }
         __syncthreads();
         if (threadIdx.x < COB) {
@@ -322,31 +398,33 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_split_kernel(
     }
 }
 
-template <int KS, int CO_T, int TYP>
+template <int KS, int NT, int TYP, int DY>
 static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                           const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                           int N, int H, int W, hipStream_t s) {
-    using Cfg = SplitCfg<KS, TYP>;
+    using Cfg = SplitCfg<KS, TYP, DY>;
     const int tiles_x = (W + SP_TX - 1) / SP_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
-    const size_t lds = Cfg::LDS;
+    const size_t lds = Cfg::LDS > SPLIT_REDUCE_LDS ? Cfg::LDS : SPLIT_REDUCE_LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_split_kernel<KS, CO_T, TYP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_split_kernel<KS, NT, TYP, DY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
-    const int pack_tiles = (Cout + 15) / 16, slices = (pack_tiles + CO_T - 1) / CO_T;
+    const int pack_tiles = split_ntiles(Cout), slices = (pack_tiles + NT - 1) / NT;
     const int tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * N, chunk_tiles = (tiles_total + 7) / 8;
-    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, CO_T, TYP>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
+    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
                        x_coff, Cin, reinterpret_cast<const u32x4*>(wsplit), pack_tiles, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff,
                        Cout, stats, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk_tiles, slices);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
+int split_column_tiles(int OC) { return split_ntiles(OC); }
+
 size_t split_packed_floats(int OC, int IC, int ks) {
     if (!split_supported(ks)) return 0;
-    const size_t taps = (size_t)ks * ks, ksteps = (taps + 3) / 4, chunks = ((size_t)IC + 7) / 8, tiles = ((size_t)OC + 15) / 16;
-    return tiles * chunks * ksteps * 3 * 64 * 4;   // 16 bytes = 4 floats per lane per split
+    const size_t chunks = ((size_t)IC + 7) / 8;
+    return (size_t)split_ntiles(OC) * chunks * split_steps(ks, split_dy(OC)) * 3 * 64 * 4;   // 16 bytes = 4 floats per lane per split
 }
 
 int launch_pack_split(const float* w, int Cout, int Cin, int ks, int transposed, float* packed_split, hipStream_t s) {
@@ -359,26 +437,24 @@ int launch_pack_split(const float* w, int Cout, int Cin, int ks, int transposed,
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
+// (ty, cot) are the launch-shape hints of cd_conv2d_fwd_cfg.  A block has 4 (ty <= 4) or 8 M-tiles (rows for DY = 1, row pairs
+// for DY = 2) and 1 or 2 column tiles (cot >= 2 and the filter has >= 2 of them -> 2, then 4 M-tiles).
 int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                       const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
                       int H, int W, int ks, int ty, int cot, hipStream_t s) {
-    if (cot > 2) cot = 2;
-    if (Cout <= 16) cot = 1;
-#define CD_SP(K, T, Y) return launch_split_t<K, T, Y>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
-#define CD_SP_T(K, T)                  \
-    {                                  \
-        if (ty == 16) CD_SP(K, T, 16); \
-        if (ty == 8) CD_SP(K, T, 8);   \
-        CD_SP(K, T, 4);                \
-    }
-#define CD_SP_K(K)                    \
-    if (ks == K) {                    \
-        if (cot == 1) CD_SP_T(K, 1)   \
-        CD_SP_T(K, 2)                 \
+    const int dy = split_dy(Cout);
+    const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
+    const int mb = (nt == 2 || ty <= 4) ? 4 : 8;
+#define CD_SP(K, T, Y, D) return launch_split_t<K, T, Y, D>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
+#define CD_SP_K(K)                                                   \
+    if (ks == K) {                                                   \
+        if (dy == 2) { if (mb == 8) CD_SP(K, 1, 16, 2); CD_SP(K, 1, 8, 2); } \
+        if (nt == 2) CD_SP(K, 2, 4, 1);                              \
+        if (mb == 8) CD_SP(K, 1, 8, 1);                              \
+        CD_SP(K, 1, 4, 1);                                           \
     }
     CD_SP_K(5) CD_SP_K(7) CD_SP_K(11)
 #undef CD_SP_K
-#undef CD_SP_T
 #undef CD_SP
     return CD_ERR_UNSUPPORTED;
 }

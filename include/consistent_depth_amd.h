@@ -254,7 +254,8 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
  * The packed filter holds both layouts, so the mode may change between launches without re-packing. */
 int cd_set_conv_arith(int mode);
 int cd_get_conv_arith(void);
-/* The upper bound of co_tiles for (Cout, ks). */
+/* The upper bound of co_tiles for (Cout, ks) under the current arithmetic mode (split mode, k >= 5: tile_rows 4 / >4 selects
+ * 4 / 8 row tiles per workgroup, co_tiles 1 / 2 one or two 32-channel column tiles). */
 int cd_conv2d_packed_co_tiles(int Cout, int ks);
 
 /* Test hook: force the output-tile height (4, 8, 16; 0 = automatic) of cd_conv2d_fwd so every

@@ -1,10 +1,6 @@
-set -x
 cd $GRAFT_REPO_ROOT
 export CD_AMD_REPORT=1
-timeout 900 python -m pytest tests/test_conv_gpu.py -x -q 2>&1 | tail -25
-cp gpurun_out/parity_log.txt gpurun_out/parity_conv_split.txt 2>/dev/null
-for a in fp32 split; do
-for i in 0 1 2 3 5 7; do timeout 120 python tools/conv_bench.py --arith $a --only $i --cfgs 16x1,8x1,4x1,16x2,8x2 ; done
-for i in 0 1 3; do timeout 120 python tools/conv_bench.py --dgrad --arith $a --only $i --cfgs 16x1,8x1,16x2,8x2 ; done
-done > gpurun_out/conv_split_bench.txt 2>&1
-cat gpurun_out/conv_split_bench.txt
+timeout 1200 python -m pytest tests/test_conv_gpu.py tests/test_hourglass_engine_gpu.py tests/test_finetune_gpu.py tests/test_midas_gpu.py -x -q -k "not baseline_8x384x224" 2>&1 | tail -15
+cp gpurun_out/parity_log.txt gpurun_out/parity_split_engine.txt 2>/dev/null
+for a in fp32 split; do CD_AMD_CONV_ARITH=$a timeout 300 python bench.py --no-cpu-baseline --no-loss-microbench 2>/dev/null | tail -1; done > gpurun_out/bench_arith.txt
+cat gpurun_out/bench_arith.txt
