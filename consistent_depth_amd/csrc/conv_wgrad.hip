@@ -18,6 +18,8 @@
 // No atomics, no zero-initialised workspace, and the sum has ONE fixed order: the weight gradient is bit-reproducible
 // (round 1 flushed with fp32 atomics -- memory-side on MI355X, ~4x the cost of a store, and order-dependent).
 #include "cd_common.h"
+#include "conv_split.h"
+#include "wgrad_split.h"
 
 namespace cd {
 
@@ -525,9 +527,28 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
 
 // Packed layout and launch shape of one weight gradient -- ONE definition for the launchers, the workspace size,
 // cd_conv2d_wgrad_plan and the unpack descriptors.
-struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide; size_t slice; };
-static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W) {
+struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide, split_arith; size_t slice; };
+
+// the split-bf16 kernel (wgrad_split.hip) takes the k = 5, 7, 11 gradients when that arithmetic is selected (cd_set_conv_arith),
+// except the RGB stem (3 input channels would pad a 16-wide tile 5-fold: the few-input-channel fp32 kernel stays)
+static inline bool wgrad_uses_split(int ks, int Cin) { return cd_get_conv_arith() == 1 && split_supported(ks) && Cin >= 8; }
+
+static WgLayout wgrad_layout_split(int Cout, int Cin, int ks, int N, int H, int W) {
     WgLayout L;
+    L.wide = 0; L.fewcin = 0; L.split_arith = 1;
+    L.cob = 16; L.cib = 16;
+    L.cogs = (Cout + 15) / 16; L.cigs = (Cin + 15) / 16;
+    L.slice = (size_t)L.cogs * L.cigs * ks * ks * 256;
+    const int per_cu = wgrad_split_blocks_per_cu(ks);
+    L.max_splits = wgrad_splits(L.cogs * L.cigs, per_cu, 1 << 30);
+    L.splits = N > 0 ? wgrad_splits(L.cogs * L.cigs, per_cu, wgrad_items(N, H, W, wgrad_split_tile_rows(ks))) : L.max_splits;
+    return L;
+}
+
+static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W) {
+    if (wgrad_uses_split(ks, Cin)) return wgrad_layout_split(Cout, Cin, ks, N, H, W);
+    WgLayout L;
+    L.split_arith = 0;
     WgPlan p = wgrad_plan(ks, Cout, Cin);
     L.wide = (N > 0 && g_wgrad_wide && wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p)) ? 1 : 0;
     L.fewcin = (ks == 7 && Cin <= 4 && p.co_t == 2 && !(g_wgrad_dbg & 8)) ? 1 : 0;
@@ -556,6 +577,13 @@ size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     // every block owns a slice: the largest number of blocks per channel group the launcher can choose, for either 1x1 layout
     const cd::WgLayout a = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0);
     size_t n = a.slice * (size_t)a.max_splits;
+    if (cd::split_supported(ks) && Cin >= 8) {   // either arithmetic may be selected later: room for both layouts
+        const int before = cd_get_conv_arith();
+        cd_set_conv_arith(1 - before);
+        const cd::WgLayout b = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0);
+        cd_set_conv_arith(before);
+        if (b.slice * (size_t)b.max_splits > n) n = b.slice * (size_t)b.max_splits;
+    }
     cd::WgPlan w;
     if (cd::wgrad_wide_plan(ks, Cout, Cin, 1 << 20, 2, 32, &w)) {   // the wide 1x1 layout (chosen per launch by the image size)
         const int wob = w.co_t * 16, wib = w.ci_t * 16;
@@ -596,6 +624,16 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     const bool wide = cd::g_wgrad_wide && cd::wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p);
     const cd::WgLayout L = cd::wgrad_layout(Cout, Cin, ks, N, H, W);
     int rc = CD_ERR_UNSUPPORTED;
+    if (L.split_arith) {
+        rc = cd::launch_wgrad_split(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, ks,
+                                    L.splits, s);
+        if (rc != CD_OK || (accumulate & 4)) return rc;
+        const int total = Cout * Cin * ks * ks;
+        hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s, workspace,
+                           Cout, Cin, ks, L.cob, L.cib, L.cigs, L.splits, L.slice, dw, accumulate & 1);
+        CD_CHECK_LAUNCH();
+        return CD_OK;
+    }
 #define CD_WG(K, A, C) rc = cd::launch_wgrad_t<K, A, C>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, s)
     if (ks == 11) CD_WG(11, 1, 1);
     else if (ks == 7 && Cin <= 4 && p.co_t == 2 && !(cd::g_wgrad_dbg & 8))   // the RGB stem

@@ -95,6 +95,7 @@ using namespace cd::hg;
 
 struct cd_hourglass {
     int N = 0, H = 0, W = 0;
+    int conv_arith = 0;   // cd_get_conv_arith() at creation: the packed weight-gradient layouts of the plan belong to that mode
     std::vector<void*> allocs;
     std::vector<Act> acts;
     std::vector<Node> steps;
@@ -427,6 +428,7 @@ int cd_hourglass_create(int N, int H, int W, cd_hourglass** out) {
     if (!out || N <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return CD_ERR_INVALID_ARG;
     cd_hourglass* e = new cd_hourglass();
     e->N = N; e->H = H; e->W = W;
+    e->conv_arith = cd_get_conv_arith();
     // pass 0: sizes that the builder needs up front (arenas are sized generously: 16384 statistic channels like the Python engine)
     e->stats_doubles = (size_t)16384 * CD_BN_STAT_SLOTS * 2;
     e->stats_arena = e->alloc<double>(e->stats_doubles, true);
@@ -615,6 +617,7 @@ int cd_hourglass_forward(cd_hourglass* e, const float* images, float* pred, int 
 
 int cd_hourglass_backward(cd_hourglass* e, const float* dpred, void* stream) {
     if (!e || !dpred) return CD_ERR_INVALID_ARG;
+    if (cd_get_conv_arith() != e->conv_arith) return CD_ERR_INVALID_ARG;   // the mode changed under the handle: re-create it
     hipStream_t s = (hipStream_t)stream;
     const size_t px = (size_t)e->N * e->H * e->W;
     if (hipMemcpyAsync(e->dpred, dpred, sizeof(float) * px, hipMemcpyDeviceToDevice, s) != hipSuccess) return CD_ERR_LAUNCH;

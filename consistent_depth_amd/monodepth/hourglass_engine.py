@@ -45,6 +45,7 @@ from typing import List, Optional
 
 import torch
 
+from .. import _native
 from ..ops import conv as C
 from ..ops import layers as L
 from . import hourglass as HG
@@ -474,7 +475,9 @@ class HourglassEngine:
                 yield from self._all_steps(st.up)
 
     def plan(self, N, H, W):
-        key = (N, H, W)
+        # the arithmetic mode of the k >= 5 convolutions (cd_set_conv_arith) selects different kernels with different packed
+        # weight-gradient layouts and tuned launch shapes: a plan belongs to the mode it was built under
+        key = (N, H, W, _native.lib().cd_get_conv_arith())
         if key not in self._plans:
             self._plans[key] = self._build(N, H, W)
         return self._plans[key]

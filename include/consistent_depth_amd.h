@@ -251,7 +251,9 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
  *     bf16 terms and the six significant cross products run on the BF16 matrix cores with fp32 accumulation --
  *     as close to fp64 as the fp32 instruction (profiles/mfma_split_exp_r02.txt), ~2x faster; not bitwise the fmaf chain;
  *   0: the fp32 matrix instruction (bitwise a k-ordered fmaf chain).
- * The packed filter holds both layouts, so the mode may change between launches without re-packing. */
+ * The packed filter holds both layouts, so the mode may change between launches without re-packing.  The weight gradient of
+ * these filters follows the same switch (wgrad_split.hip); its packed layout (cd_conv2d_wgrad_plan) differs between the modes, so a
+ * plan -- and a cd_hourglass handle -- belongs to the mode it was made under. */
 int cd_set_conv_arith(int mode);
 int cd_get_conv_arith(void);
 /* The upper bound of co_tiles for (Cout, ks) under the current arithmetic mode (split mode, k >= 5: tile_rows 4 / >4 selects

@@ -5,12 +5,23 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["split", "fp32"])
+def arith(request):
+    """Both arithmetic modes of the k >= 5 convolutions (cd_set_conv_arith)."""
+    from consistent_depth_amd import _native
+    lib = _native.lib()
+    before = lib.cd_get_conv_arith()
+    assert lib.cd_set_conv_arith(1 if request.param == "split" else 0) == 0
+    yield request.param
+    lib.cd_set_conv_arith(before)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [
     (2, 64, 16, 20, 36, 11), (2, 32, 32, 17, 40, 7), (2, 64, 64, 16, 32, 7), (2, 32, 64, 12, 24, 5),
     (2, 64, 32, 16, 32, 3), (2, 128, 64, 16, 40, 1), (2, 256, 32, 8, 16, 1), (1, 64, 1, 24, 40, 3), (2, 3, 128, 24, 40, 7),
-    (2, 16, 16, 9, 33, 3), (2, 128, 16, 8, 32, 1),
+    (2, 16, 16, 9, 33, 3), (2, 128, 16, 8, 32, 1), (2, 24, 40, 13, 35, 11), (3, 16, 64, 30, 66, 7), (1, 40, 24, 31, 30, 5),
 ])
-def test_wgrad_matches_autograd(N, Cin, Cout, H, W, ks):
+def test_wgrad_matches_autograd(N, Cin, Cout, H, W, ks, arith):
     import torch
     from consistent_depth_amd.ops import conv
     g = torch.Generator().manual_seed(ks * 77 + Cin)

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export CD_AMD_REPORT=1
-timeout 1200 python -m pytest tests/test_conv_gpu.py tests/test_hourglass_engine_gpu.py tests/test_finetune_gpu.py tests/test_midas_gpu.py -x -q -k "not baseline_8x384x224" 2>&1 | tail -15
-cp gpurun_out/parity_log.txt gpurun_out/parity_split_engine.txt 2>/dev/null
-for a in fp32 split; do CD_AMD_CONV_ARITH=$a timeout 300 python bench.py --no-cpu-baseline --no-loss-microbench 2>/dev/null | tail -1; done > gpurun_out/bench_arith.txt
-cat gpurun_out/bench_arith.txt
+timeout 600 python -m pytest tests/test_layers_gpu.py tests/test_conv_gpu.py -x -q -k "wgrad or weight_gradient" 2>&1 | tail -15
+for a in fp32 split; do
+for i in 0 1 2 3 4 5 7 9; do timeout 120 python tools/conv_bench.py --wgrad --arith $a --only $i 2>/dev/null; done
+done > gpurun_out/wgrad_split_bench.txt 2>&1
+cat gpurun_out/wgrad_split_bench.txt
