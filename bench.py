@@ -255,7 +255,12 @@ def main():
                                f"{H}x{W} clip ({len(store)} pairs, hierarchical sampling, HBM-resident pair store, shared-seed shards), "
                                f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{(3 if world > 1 else 2) if args.backend == 'hip' else 1}]: "
                                + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"),
-                   "conv_backend": args.backend, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "conv_backend": args.backend,
+                   "conv_arith": ("fp32 results from split operands: every fp32 input = 3 exact bf16 terms, 6 cross products on the BF16 matrix "
+                                  "cores, fp32 accumulate (k>=5 fwd/dgrad/wgrad; as close to fp64 as the fp32 MFMA: profiles/mfma_split_exp_r02.txt, "
+                                  "tests/test_conv_gpu.py); k<=3 on the fp32 MFMA" if lib.cd_get_conv_arith() == 1 else "fp32 MFMA (CD_AMD_CONV_ARITH=fp32)")
+                   if args.backend == "hip" else "MIOpen fp32",
+                   "global_batch": B * world, "parallelism": f"dp{world}",
                    "hip_graph": graphed, "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),
                    "last_loss": float(last_loss.item())},
     }

@@ -6,7 +6,7 @@
 namespace cd {
 
 // filter sizes the split-bf16 kernel covers (k = 1, 3 stay on the fp32 instruction: memory / launch bound shapes)
-__host__ __device__ constexpr bool split_supported(int ks) { return ks == 5 || ks == 7 || ks == 11; }
+__host__ __device__ constexpr bool split_supported(int ks) { return ks == 3 || ks == 5 || ks == 7 || ks == 11; }
 
 // One source of a packed filter (cd_pack_desc of the header).
 struct PackDesc {

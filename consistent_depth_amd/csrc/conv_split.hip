@@ -453,7 +453,7 @@ int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const flo
         if (mb == 8) CD_SP(K, 1, 8, 1);                              \
         CD_SP(K, 1, 4, 1);                                           \
     }
-    CD_SP_K(5) CD_SP_K(7) CD_SP_K(11)
+    CD_SP_K(3) CD_SP_K(5) CD_SP_K(7) CD_SP_K(11)
 #undef CD_SP_K
 #undef CD_SP
     return CD_ERR_UNSUPPORTED;

@@ -545,8 +545,8 @@ static WgLayout wgrad_layout_split(int Cout, int Cin, int ks, int N, int H, int 
     return L;
 }
 
-static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W) {
-    if (wgrad_uses_split(ks, Cin)) return wgrad_layout_split(Cout, Cin, ks, N, H, W);
+static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W, int arith = -1) {
+    if (arith < 0 ? wgrad_uses_split(ks, Cin) : (arith == 1 && split_supported(ks) && Cin >= 8)) return wgrad_layout_split(Cout, Cin, ks, N, H, W);
     WgLayout L;
     L.split_arith = 0;
     WgPlan p = wgrad_plan(ks, Cout, Cin);
@@ -578,10 +578,7 @@ size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     const cd::WgLayout a = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0);
     size_t n = a.slice * (size_t)a.max_splits;
     if (cd::split_supported(ks) && Cin >= 8) {   // either arithmetic may be selected later: room for both layouts
-        const int before = cd_get_conv_arith();
-        cd_set_conv_arith(1 - before);
-        const cd::WgLayout b = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0);
-        cd_set_conv_arith(before);
+        const cd::WgLayout b = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0, 1 - cd_get_conv_arith());
         if (b.slice * (size_t)b.max_splits > n) n = b.slice * (size_t)b.max_splits;
     }
     cd::WgPlan w;

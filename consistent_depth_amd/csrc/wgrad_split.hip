@@ -235,6 +235,7 @@ int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const fl
                        hipStream_t s) {
     if (ks == 11) return launch_ws<11>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
     if (ks == 7) return launch_ws<7>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
+    if (ks == 3) return launch_ws<3>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
     if (ks == 5) return launch_ws<5>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
     return CD_ERR_UNSUPPORTED;
 }
