@@ -13,7 +13,7 @@ SHAPES = [  # H, W, ks, Cin, Cout, share of forward MACs
     (384, 224, 11, 64, 16, 20.2), (192, 112, 11, 64, 32, 10.1), (192, 112, 7, 64, 32, 8.2), (384, 224, 7, 64, 16, 8.2),
     (192, 112, 7, 32, 32, 6.1), (96, 56, 11, 64, 64, 5.0), (384, 224, 1, 128, 64, 4.0), (192, 112, 5, 32, 32, 3.1),
     (384, 224, 7, 3, 128, 3.1), (96, 56, 7, 32, 64, 3.1), (192, 112, 1, 128, 32, 2.8), (192, 112, 3, 64, 32, 1.5),
-    (48, 28, 7, 32, 64, 1.3), (24, 14, 7, 32, 64, 0.1), (384, 224, 3, 64, 16, 0.8), (96, 56, 3, 64, 64, 0.4),
+    (48, 28, 7, 32, 64, 1.3), (24, 14, 7, 32, 64, 0.1), (384, 224, 3, 64, 16, 0.8), (96, 56, 3, 64, 64, 0.4), (384, 224, 1, 128, 208, 4.0), (192, 112, 1, 128, 224, 2.8), (96, 56, 1, 256, 160, 1.0),
 ]
 DGRAD_SHAPES = [  # the input-gradient convolutions (channels swapped) of the dominant shapes
     (384, 224, 11, 16, 64, 20.2), (192, 112, 11, 32, 64, 10.1), (192, 112, 7, 32, 64, 8.2), (384, 224, 7, 16, 64, 8.2),
