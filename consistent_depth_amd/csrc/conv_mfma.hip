@@ -481,12 +481,14 @@ __global__ void pack_weights_table_kernel(const PackDesc* __restrict__ table) {
 
 namespace cd {
 static int g_force_conv_ty = 0, g_force_conv_cot = 0, g_conv_pipe = 1;
-// arithmetic of the k >= 5 convolutions: 1 = split-bf16 (conv_split.hip), 0 = the fp32 matrix instruction.
-// Start-up value from CD_AMD_CONV_ARITH ("fp32" / "split"), default split.
+// arithmetic of the convolutions: 0 = the fp32 matrix instruction, 1 = split-bf16 for k >= 3 (conv_split.hip, wgrad_split.hip),
+// 2 = 1 plus the 1x1 forward / input gradient (conv1x1_split.hip).  Start-up value from CD_AMD_CONV_ARITH
+// ("fp32" / "split3" / "split"), default split = 2.
 static int initial_conv_arith() {
     const char* e = getenv("CD_AMD_CONV_ARITH");
     if (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) return 0;
-    return 1;
+    if (e && (!strcmp(e, "split3") || !strcmp(e, "1"))) return 1;
+    return 2;
 }
 static int g_conv_arith = initial_conv_arith();
 }
@@ -511,7 +513,7 @@ int cd_debug_set_conv_pipeline(int on) {
 }
 
 int cd_set_conv_arith(int mode) {
-    if (!(mode == 0 || mode == 1)) return CD_ERR_INVALID_ARG;
+    if (!(mode == 0 || mode == 1 || mode == 2)) return CD_ERR_INVALID_ARG;
     cd::g_conv_arith = mode;
     return CD_OK;
 }
@@ -522,7 +524,7 @@ int cd_get_conv_arith(void) { return cd::g_conv_arith; }
 size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed) {
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
     const int OC = transposed ? Cin : Cout, IC = transposed ? Cout : Cin;
-    return cd::fp32_packed_floats(OC, IC, ks) + cd::split_packed_floats(OC, IC, ks);
+    return cd::fp32_packed_floats(OC, IC, ks) + (cd::split_1x1_supported(ks, OC, IC) ? cd::split_1x1_packed_floats(OC, IC) : cd::split_packed_floats(OC, IC, ks));
 }
 
 int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transposed, float* packed, void* stream) {
@@ -537,6 +539,11 @@ int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transp
     hipLaunchKernelGGL(cd::pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ks,
                        ci_chunk, cob, cobp, transposed, packed, total);
     CD_CHECK_LAUNCH();
+    if (cd::split_1x1_supported(ks, OC, IC)) {
+        const size_t nsplit = cd::split_1x1_packed_floats(OC, IC);
+        if (hipMemsetAsync(packed + total, 0, nsplit * sizeof(float), (hipStream_t)stream) != hipSuccess) return CD_ERR_LAUNCH;
+        return cd::launch_pack_1x1(w, Cout, Cin, transposed, packed + total, (hipStream_t)stream);
+    }
     if (cd::split_supported(ks)) {   // the split layout's padding must be zero: the one-filter form clears it itself
         const size_t nsplit = cd::split_packed_floats(OC, IC, ks);
         if (hipMemsetAsync(packed + total, 0, nsplit * sizeof(float), (hipStream_t)stream) != hipSuccess) return CD_ERR_LAUNCH;
@@ -549,7 +556,8 @@ int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream) {
     if (!table_dev || n <= 0 || n > 65535) return CD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(cd::pack_weights_table_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const cd::PackDesc*)table_dev);
     CD_CHECK_LAUNCH();
-    return cd::launch_pack_split_table(table_dev, n, (hipStream_t)stream);
+    const int rc = cd::launch_pack_split_table(table_dev, n, (hipStream_t)stream);
+    return rc != CD_OK ? rc : cd::launch_pack_1x1_table(table_dev, n, (hipStream_t)stream);
 }
 
 int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const float* packed_w, const float* bias,
@@ -562,7 +570,12 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     const int pack_cot = cd::pick_co_tiles(ks, Cout);
     if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16)) return CD_ERR_INVALID_ARG;
     if (!(co_tiles == 0 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4 || co_tiles == 8 || co_tiles == 16)) return CD_ERR_INVALID_ARG;
-    if (cd::g_conv_arith == 1 && cd::split_supported(ks) && Cin >= 8) {   // (the 3-channel stem would pad K 8/3-fold: fp32 kernel)
+    // (small images -- fewer 32-pixel tiles than the chip has waves -- stay on the staged fp32 kernel: measured equal or faster there)
+    if (cd::g_conv_arith == 2 && cd::split_1x1_supported(ks, Cout, Cin) && (size_t)N * x_ctot * H * W < ((size_t)1 << 30) &&
+        (long long)N * H * ((W + 31) / 32) >= 4096)   // one launch shape: the hints are not used
+        return cd::launch_conv1x1_split(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift, in_relu,
+                                        y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s);
+    if (cd::g_conv_arith >= 1 && cd::split_supported(ks) && Cin >= 8) {   // (the 3-channel stem would pad K 8/3-fold: fp32 kernel)
         // launch-shape hints: tile_rows <= 4 -> 4 M-tiles per block, else 8; co_tiles >= 2 -> two 32-column tiles per block (then 4
         // M-tiles).  Unhinted: 4 M-tiles, two column tiles when the filter has them and the image is large (conv_split_bench)
         int sty = cd::g_force_conv_ty ? cd::g_force_conv_ty : tile_rows, scot = cd::g_force_conv_cot ? cd::g_force_conv_cot : co_tiles;
@@ -617,7 +630,7 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
 }
 
 int cd_conv2d_packed_co_tiles(int Cout, int ks) {
-    if (cd::g_conv_arith == 1 && cd::split_supported(ks)) return cd::split_column_tiles(Cout) >= 2 ? 2 : 1;
+    if (cd::g_conv_arith >= 1 && cd::split_supported(ks)) return cd::split_column_tiles(Cout) >= 2 ? 2 : 1;
     return cd::max_co_tiles(ks, Cout);
 }
 

@@ -531,7 +531,7 @@ struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide, sp
 
 // the split-bf16 kernel (wgrad_split.hip) takes the k = 5, 7, 11 gradients when that arithmetic is selected (cd_set_conv_arith),
 // except the RGB stem (3 input channels would pad a 16-wide tile 5-fold: the few-input-channel fp32 kernel stays)
-static inline bool wgrad_uses_split(int ks, int Cin) { return cd_get_conv_arith() == 1 && split_supported(ks) && Cin >= 8; }
+static inline bool wgrad_uses_split(int ks, int Cin) { return cd_get_conv_arith() >= 1 && split_supported(ks) && Cin >= 8; }
 
 static WgLayout wgrad_layout_split(int Cout, int Cin, int ks, int N, int H, int W) {
     WgLayout L;
@@ -546,7 +546,7 @@ static WgLayout wgrad_layout_split(int Cout, int Cin, int ks, int N, int H, int 
 }
 
 static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W, int arith = -1) {
-    if (arith < 0 ? wgrad_uses_split(ks, Cin) : (arith == 1 && split_supported(ks) && Cin >= 8)) return wgrad_layout_split(Cout, Cin, ks, N, H, W);
+    if (arith < 0 ? wgrad_uses_split(ks, Cin) : (arith >= 1 && split_supported(ks) && Cin >= 8)) return wgrad_layout_split(Cout, Cin, ks, N, H, W);
     WgLayout L;
     L.split_arith = 0;
     WgPlan p = wgrad_plan(ks, Cout, Cin);
@@ -578,7 +578,7 @@ size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     const cd::WgLayout a = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0);
     size_t n = a.slice * (size_t)a.max_splits;
     if (cd::split_supported(ks) && Cin >= 8) {   // either arithmetic may be selected later: room for both layouts
-        const cd::WgLayout b = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0, 1 - cd_get_conv_arith());
+        const cd::WgLayout b = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0, cd_get_conv_arith() >= 1 ? 0 : 1);
         if (b.slice * (size_t)b.max_splits > n) n = b.slice * (size_t)b.max_splits;
     }
     cd::WgPlan w;

@@ -99,7 +99,7 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
         return None
     x_ctot, y_ctot = x_ctot or Cin, y_ctot or Cout
     _load_tune_cache()
-    arith = _native.lib().cd_get_conv_arith() if ks >= 5 else 0     # the two arithmetic modes are different kernels
+    arith = _native.lib().cd_get_conv_arith()     # the arithmetic modes are different kernels
     key = (ks, Cin, Cout, N, H, W, int(bool(affine_in)), int(bool(relu_in)), int(bool(stats)), int(bool(accumulate)), x_ctot, y_ctot, arith)
     if key in _TUNED:
         return _TUNED[key]

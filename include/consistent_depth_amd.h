@@ -246,14 +246,17 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
                       const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                       float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                       int N, int H, int W, int ks, int tile_rows, int co_tiles, void* stream);
-/* Arithmetic of the k = 5, 7, 11 convolutions (forward and input gradient), process-wide:
- *   1 (default; start-up value from CD_AMD_CONV_ARITH = "split" | "fp32"): every fp32 operand is split exactly into three
- *     bf16 terms and the six significant cross products run on the BF16 matrix cores with fp32 accumulation --
- *     as close to fp64 as the fp32 instruction (profiles/mfma_split_exp_r02.txt), ~2x faster; not bitwise the fmaf chain;
- *   0: the fp32 matrix instruction (bitwise a k-ordered fmaf chain).
- * The packed filter holds both layouts, so the mode may change between launches without re-packing.  The weight gradient of
- * these filters follows the same switch (wgrad_split.hip); its packed layout (cd_conv2d_wgrad_plan) differs between the modes, so a
- * plan -- and a cd_hourglass handle -- belongs to the mode it was made under. */
+/* Arithmetic of the convolutions (forward, input gradient and weight gradient), process-wide; start-up value from
+ * CD_AMD_CONV_ARITH = "split" (2, default) | "split3" (1) | "fp32" (0):
+ *   1: k = 3, 5, 7, 11 with >= 8 input channels: every fp32 operand is split exactly into three bf16 terms and the six
+ *     significant cross products run on the BF16 matrix cores with fp32 accumulation -- as close to fp64 as the fp32
+ *     instruction (profiles/mfma_split_exp_r02.txt), 1.5-1.7x faster; not bitwise the fmaf chain, +-inf inputs give NaN;
+ *   2: 1, plus the 1x1 forward / input gradient on images of >= 4096 row tiles (conv1x1_split.hip: filter slice resident in
+ *     LDS, activations split in registers; 1.3-2x faster per launch);
+ *   0: the fp32 matrix instruction everywhere (bitwise a k-ordered fmaf chain).
+ * The packed filter holds every layout, so the mode may change between launches without re-packing.  The weight gradient of
+ * the k >= 3 filters follows the same switch (wgrad_split.hip); its packed layout (cd_conv2d_wgrad_plan) differs between mode 0
+ * and modes 1/2, so a plan -- and a cd_hourglass handle -- belongs to the mode it was made under. */
 int cd_set_conv_arith(int mode);
 int cd_get_conv_arith(void);
 /* The upper bound of co_tiles for (Cout, ks) under the current arithmetic mode (split mode, k >= 5: tile_rows 4 / >4 selects

@@ -9,14 +9,14 @@ from tests.gpu_util import report
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["split", "fp32"])
+@pytest.fixture(autouse=True, params=["split", "fp32", "split3"])
 def arith(request):
-    """Every test runs under both arithmetic modes of the k >= 5 convolutions (cd_set_conv_arith): the split-bf16 kernel
-    (default) and the fp32 matrix instruction."""
+    """Every test runs under the three arithmetic modes (cd_set_conv_arith): split-bf16 incl. the dedicated 1x1 kernel (default), the fp32
+    matrix instruction, and split-bf16 for k >= 3 only."""
     from consistent_depth_amd import _native
     lib = _native.lib()
     before = lib.cd_get_conv_arith()
-    assert lib.cd_set_conv_arith(1 if request.param == "split" else 0) == 0
+    assert lib.cd_set_conv_arith({"fp32": 0, "split3": 1, "split": 2}[request.param]) == 0
     yield request.param
     lib.cd_set_conv_arith(before)
 
@@ -79,7 +79,7 @@ def test_split_arithmetic_is_as_close_to_fp64_as_the_fp32_instruction(N, Cin, Co
     ref = _ref(x, w, None, ks)
     pk = conv.pack_weights(w.cuda())
     err = {}
-    for name, mode in (("split", 1), ("fp32", 0)):
+    for name, mode in (("split", 2), ("fp32", 0)):
         lib.cd_set_conv_arith(mode)
         y = conv.conv2d(x.cuda(), pk, Cin, Cout, ks)
         d = (y.cpu().double() - ref).abs()
@@ -87,6 +87,44 @@ def test_split_arithmetic_is_as_close_to_fp64_as_the_fp32_instruction(N, Cin, Co
     report("conv_split_vs_fp32", shape=f"{N}x{Cin}->{Cout}x{H}x{W}k{ks}", split_max=f"{err['split'][0]:.2e}", fp32_max=f"{err['fp32'][0]:.2e}",
            split_rms=f"{err['split'][1]:.2e}", fp32_rms=f"{err['fp32'][1]:.2e}")
     assert err["split"][0] <= 1.5 * err["fp32"][0] + 1e-8 and err["split"][1] <= 1.25 * err["fp32"][1] + 1e-9
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 128, 208, 128, 512), (1, 208, 128, 256, 500), (2, 100, 72, 128, 510), (4, 256, 160, 64, 512)])
+def test_pointwise_convolution_at_dispatch_size(N, Cin, Cout, H, W, arith):
+    """1x1 filters on images with >= 4096 row tiles: under "split" this is conv1x1_split.hip (filter slice resident in LDS,
+    activations split in registers) -- channel slices of wider buffers, the fused input transform, the statistics epilogue and
+    gradient accumulation, odd widths and channel counts; under the other modes the same call is the staged fp32 kernel."""
+    import torch
+    from consistent_depth_amd.ops import conv, layers
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, Cin + 5, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), torch.randn(Cin, generator=g).cuda()
+    base = torch.randn(N, Cout + 3, H, W, generator=g).cuda()
+    pk = conv.pack_weights(w)
+    act = torch.relu(x[:, 2:2 + Cin].double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    ref = torch.einsum("nchw,oc->nohw", act, w.double().view(Cout, Cin)) + b.double().view(1, -1, 1, 1)
+    out = base.clone()
+    conv.conv2d(x, pk, Cin, Cout, 1, bias=b, x_coff=2, out=out, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True, accumulate=True)
+    got = (out[:, 1:1 + Cout] - base[:, 1:1 + Cout]).double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert torch.equal(out[:, :1], base[:, :1]) and torch.equal(out[:, 1 + Cout:], base[:, 1 + Cout:])
+    out2 = torch.full_like(base, 7.0)
+    stats = layers.new_stats(Cout + 3, "cuda")
+    conv.conv2d(x, pk, Cin, Cout, 1, bias=b, x_coff=2, out=out2, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True, stats=stats)
+    err2 = (out2[:, 1:1 + Cout].double() - ref).abs().max().item() / ref.abs().max().item()
+    st = stats.sum(0)
+    report("conv_pointwise", arith=arith, shape=f"{N}x{Cin}->{Cout}x{H}x{W}", accumulate_err=f"{err:.2e}", plain_err=f"{err2:.2e}")
+    assert err < 3e-6 and err2 < 2e-6
+    assert (out2[:, :1] == 7).all() and (out2[:, 1 + Cout:] == 7).all()
+    torch.testing.assert_close(st[1:1 + Cout, 0], ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(st[1:1 + Cout, 1], (ref ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-2)
+    assert (st[:1] == 0).all() and (st[1 + Cout:] == 0).all()
+    # bit-reproducible
+    out3 = torch.full_like(base, 7.0)
+    conv.conv2d(x, pk, Cin, Cout, 1, bias=b, x_coff=2, out=out3, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True)
+    assert torch.equal(out3, out2)
 
 
 def test_conv_channel_slices_fused_input_and_stats():

@@ -111,7 +111,7 @@ def test_engine_under_both_conv_arithmetics():
     dpred = torch.randn(2, 1, 64, 96, device="cuda")
     out = {}
     try:
-        for mode in (1, 0, 1):
+        for mode in (2, 0, 2):
             lib.cd_set_conv_arith(mode)
             for p in net.parameters():
                 p.grad = torch.zeros_like(p)
@@ -124,7 +124,7 @@ def test_engine_under_both_conv_arithmetics():
             out[mode] = res
     finally:
         lib.cd_set_conv_arith(before)
-    dp, dg = _rel(out[1][0], out[0][0]), _rel(out[1][1], out[0][1])
+    dp, dg = _rel(out[2][0], out[0][0]), _rel(out[2][1], out[0][1])
     print(f"  split vs fp32 arithmetic: pred {dp:.2e}  grads {dg:.2e}")
     assert dp < 2e-4 and dg < 2e-2
 

@@ -11,7 +11,7 @@ def arith(request):
     from consistent_depth_amd import _native
     lib = _native.lib()
     before = lib.cd_get_conv_arith()
-    assert lib.cd_set_conv_arith(1 if request.param == "split" else 0) == 0
+    assert lib.cd_set_conv_arith(2 if request.param == "split" else 0) == 0
     yield request.param
     lib.cd_set_conv_arith(before)
 
