@@ -187,18 +187,20 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
         wt[t] = wsp + (size_t)(gt < pack_tiles ? gt : 0) * n_chunks * KSTEPS * 192 + lane;
     }
     const int steps_total = n_chunks * KSTEPS;
-    bf16x8 bcur[NT][3], bnext[NT][3];
+    // weight fragments: two register buffers used alternately (explicitly -- a "next = load; ...; cur = next" rotation was folded
+    // away by the compiler, which then waited for every fragment right after issuing its load)
+    bf16x8 bA[NT][3], bB[NT][3];
     auto load_b = [&](bf16x8 (&dst)[NT][3], int lin) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) {
-                const u32x4 v = wt[t][(size_t)lin * 192 + sp * 64];
+                const u32x4 v = wt[t][(size_t)(lin < steps_total ? lin : steps_total - 1) * 192 + sp * 64];   // (always a load: no branch)
                 dst[t][sp] = __builtin_bit_cast(bf16x8, v);
             }
     };
     int lin = wid;   // this wave's next step, linear over (chunk, step)
-    if (lin < steps_total) load_b(bcur, lin);
+    load_b(bA, lin);   // invariant at every step-loop entry: bA holds the fragments of step `lin`
 
     const int abase = li + COFF;   // LDS slot of this lane's pixel in tile row 0 at tap (0, 0)
 
@@ -252,10 +254,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
 
         // ---- MFMA over this wave's tap steps of the chunk
         const int lin_end = (chunk + 1) * KSTEPS;
-#pragma unroll 1
-        for (; lin < lin_end; lin += 4) {
-            if (lin + 4 < steps_total) load_b(bnext, lin + 4);
-            const int tap = (lin - chunk * KSTEPS) * 2 + g;
+        auto step = [&](const bf16x8 (&bcur)[NT][3], bf16x8 (&bfill)[NT][3], int l) {
+            load_b(bfill, l + 4);   // this wave's next step: in flight during the MFMAs below
+            const int tap = (l - chunk * KSTEPS) * 2 + g;
             const int ky = tap / KS, kx = tap - ky * KS;
             const int slot0 = abase + ((tap < TAPS) ? ky * RSP + kx : 0);   // a padded tap carries zero weights: any valid slot
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, smallest first
@@ -277,10 +278,19 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
                         for (int t = 0; t < NT; ++t)
                             acc[mg + m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[p]], bcur[t][PB[p]], acc[mg + m][t], 0, 0, 0);
             }
+        };
+#pragma unroll 1
+        for (; lin + 4 < lin_end; lin += 8) {   // two steps per trip: the buffers swap roles without a register copy
+            step(bA, bB, lin);
+            step(bB, bA, lin + 4);
+        }
+        if (lin < lin_end) {   // odd step count of this wave in this chunk: one copy (and wait) per chunk
+            step(bA, bB, lin);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) bcur[t][sp] = bnext[t][sp];
+                for (int sp = 0; sp < 3; ++sp) bA[t][sp] = bB[t][sp];
+            lin += 4;
         }
     }
 
