@@ -206,35 +206,51 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         __syncthreads();   // the previous chunk's fragments are consumed
-        // ---- stage 8 input channels: global fp32 -> (affine, relu) -> three bf16 planes, channels-last
+        // ---- stage 8 input channels: global fp32 -> (affine, relu) -> three bf16 planes, channels-last.  The 8 loads of a unit are
+        // UNCONDITIONAL (clamped address; padding zeroed with an AND afterwards) so that they are all in flight before the first
+        // wait: a load under a divergent branch is followed by s_waitcnt vmcnt(0), which serialised the 8 channels.
         for (int u = threadIdx.x; u < UNITS; u += kBlock) {
             const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
             const int gy = Y0 - P + r, gx = X0 - PADL + q4;
+            const bool row_in = (unsigned)gy < (unsigned)H;
+            const int gyc = row_in ? gy : 0;
             float v[8][4];
+            unsigned keep[4];   // per pixel: all ones inside the image
+            if (vec_in) {       // W % 4 == 0: an aligned quad is inside or outside the image as a whole
+                const bool in = row_in && (unsigned)gx < (unsigned)W;
+                const float* src = xin + (size_t)gyc * W + (in ? gx : 0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int ci = chunk * 8 + c;
+                    const float4 f = *reinterpret_cast<const float4*>(src + (size_t)(ci < Cin ? ci : Cin - 1) * HW);
+                    v[c][0] = f.x; v[c][1] = f.y; v[c][2] = f.z; v[c][3] = f.w;
+                }
+                keep[0] = keep[1] = keep[2] = keep[3] = in ? 0xffffffffu : 0u;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool in = row_in && (unsigned)(gx + p) < (unsigned)W;
+                    keep[p] = in ? 0xffffffffu : 0u;
+                    const float* src = xin + (size_t)gyc * W + (in ? gx + p : 0);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int ci = chunk * 8 + c;
+                        v[c][p] = src[(size_t)(ci < Cin ? ci : Cin - 1) * HW];
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int ci = chunk * 8 + c;
-                v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
-                if (ci < Cin && (unsigned)gy < (unsigned)H) {
-                    const float* src = xin + (size_t)ci * HW + (size_t)gy * W + gx;
-                    bool ok[4];
-                    if (vec_in) {
-                        const bool in = (unsigned)gx < (unsigned)W;   // W % 4 == 0: an aligned quad is inside or outside as a whole
-                        if (in) { const float4 f = *reinterpret_cast<const float4*>(src); v[c][0] = f.x; v[c][1] = f.y; v[c][2] = f.z; v[c][3] = f.w; }
-                        ok[0] = ok[1] = ok[2] = ok[3] = in;
-                    } else {
+                const unsigned kc = ci < Cin ? 0xffffffffu : 0u;
+                float sc = 1.f, sh = 0.f;
+                if (in_scale) { sc = in_scale[ci < Cin ? ci : Cin - 1]; sh = in_shift[ci < Cin ? ci : Cin - 1]; }
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) { ok[p] = (unsigned)(gx + p) < (unsigned)W; if (ok[p]) v[c][p] = src[p]; }
-                    }
-                    if (in_scale) {
-                        const float sc = in_scale[ci], sh = in_shift[ci];
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) if (ok[p]) v[c][p] = __fmaf_rn(v[c][p], sc, sh);   // zero padding stays zero
-                    }
-                    if (in_relu) {
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) v[c][p] = fmaxf(v[c][p], 0.f);
-                    }
+                for (int p = 0; p < 4; ++p) {
+                    float t = v[c][p];
+                    if (in_scale) t = __fmaf_rn(t, sc, sh);
+                    if (in_relu) t = fmaxf(t, 0.f);
+                    v[c][p] = __uint_as_float(__float_as_uint(t) & keep[p] & kc);   // zero padding (pixels and channels) stays an exact zero
                 }
             }
 #pragma unroll

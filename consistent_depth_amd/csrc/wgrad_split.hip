@@ -129,63 +129,71 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int X0 = tx * 32, Y0 = ty * TY;
         __syncthreads();   // the previous tile is consumed
-        // ---- stage dY (zero outside the image / beyond Cout): fp32 -> three bf16 planes, pixels contiguous
-        const float* dyn = dy + ((size_t)n * dy_ctot + dy_coff) * HW;
-        for (int i = threadIdx.x; i < 16 * TY * 8; i += NT) {
-            const int c = i / (TY * 8), rem = i - c * (TY * 8), r = rem >> 3, q = rem & 7;
-            const int co = cog * 16 + c, gy = Y0 + r, gx = X0 + 4 * q;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (co < Cout && gy < H) {
-                const float* src = dyn + (size_t)co * HW + (size_t)gy * W + gx;
-                if (vec) { if (gx < W) { const float4 f = *reinterpret_cast<const float4*>(src); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; } }
-                else {
+        // ---- staging: fp32 -> (affine, relu) -> three bf16 planes, pixels contiguous.  Elements go in batches of 4 per thread whose
+        // loads are UNCONDITIONAL (clamped address, padding zeroed with an AND afterwards): all loads of a batch are in flight before
+        // the first wait (a load under a divergent branch is followed by s_waitcnt vmcnt(0): one full latency per element).
+        // One element = 4 consecutive pixels of one channel row.  `stage(rows, quads, ...)` covers a [16 ch][rows][quads] tile.
+        auto stage = [&](const float* __restrict__ src_n, int ch0, int ch_n, int rows, int quads, int y0, int x0, unsigned* __restrict__ dst,
+                         int plane_words, int row_words, int split_words, bool affine) {
+            const int total = 16 * rows * quads;
+            constexpr int BATCH = 4;
+            for (int i0 = threadIdx.x; i0 < total; i0 += NT * BATCH) {
+                float v[BATCH][4];
+                unsigned keep[BATCH][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (gx + e < W) v[e] = src[e];
+                for (int b = 0; b < BATCH; ++b) {
+                    const int i = i0 + b * NT;
+                    const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
+                    const int ch = ch0 + c, gy = y0 + r, gx = x0 + 4 * q;
+                    const bool base_ok = i < total && ch < ch_n && (unsigned)gy < (unsigned)H;
+                    const float* row = src_n + (size_t)(ch < ch_n ? ch : ch_n - 1) * HW + (size_t)((unsigned)gy < (unsigned)H ? gy : 0) * W;
+                    if (vec) {   // W % 4 == 0: an aligned quad is inside or outside the image as a whole
+                        const bool in = base_ok && (unsigned)gx < (unsigned)W;
+                        const float4 f = *reinterpret_cast<const float4*>(row + ((unsigned)gx < (unsigned)W ? gx : 0));
+                        v[b][0] = f.x; v[b][1] = f.y; v[b][2] = f.z; v[b][3] = f.w;
+                        keep[b][0] = keep[b][1] = keep[b][2] = keep[b][3] = in ? 0xffffffffu : 0u;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool in = base_ok && (unsigned)(gx + e) < (unsigned)W;
+                            v[b][e] = row[(unsigned)(gx + e) < (unsigned)W ? gx + e : 0];
+                            keep[b][e] = in ? 0xffffffffu : 0u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    const int i = i0 + b * NT;
+                    if (i >= total) break;
+                    const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
+                    if (affine) {
+                        const int ch = ch0 + c < ch_n ? ch0 + c : ch_n - 1;
+                        if (in_scale) {
+                            const float sc = in_scale[ch], sh = in_shift[ch];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[b][e] = __fmaf_rn(v[b][e], sc, sh);   // same fma as the BN backward's mask
+                        }
+                        if (in_relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[b][e] = __uint_as_float(__float_as_uint(v[b][e]) & keep[b][e]);   // zero padding stays an exact zero
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    ws_split_pair(v[b][0], v[b][1], h0, m0, l0);
+                    ws_split_pair(v[b][2], v[b][3], h1, m1, l1);
+                    unsigned* d = dst + c * plane_words + r * row_words + 2 * q;
+                    *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(d + split_words) = u32x2{m0, m1};
+                    *reinterpret_cast<u32x2*>(d + 2 * split_words) = u32x2{l0, l1};
                 }
             }
-            unsigned h0, m0, l0, h1, m1, l1;
-            ws_split_pair(v[0], v[1], h0, m0, l0);
-            ws_split_pair(v[2], v[3], h1, m1, l1);
-            unsigned* d = s_dy + c * PSD + r * 16 + 2 * q;
-            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(d + SPD) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2*>(d + 2 * SPD) = u32x2{l0, l1};
-        }
-        // ---- stage the activated input tile with halo (zero padding): rows [Y0 - P, Y0 + TY + P), pixels [X0 - 8, X0 + 40)
-        const float* xn = x + ((size_t)n * x_ctot + x_coff) * HW;
-        for (int i = threadIdx.x; i < 16 * ROWS * 12; i += NT) {
-            const int c = i / (ROWS * 12), rem = i - c * (ROWS * 12), r = rem / 12, q = rem - r * 12;
-            const int ci = cig * 16 + c, gy = Y0 - P + r, gx = X0 - 8 + 4 * q;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ci < Cin && (unsigned)gy < (unsigned)H) {
-                const float* src = xn + (size_t)ci * HW + (size_t)gy * W + gx;
-                bool ok[4];
-                if (vec) {
-                    const bool in = (unsigned)gx < (unsigned)W;
-                    if (in) { const float4 f = *reinterpret_cast<const float4*>(src); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
-                    ok[0] = ok[1] = ok[2] = ok[3] = in;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ok[e] = (unsigned)(gx + e) < (unsigned)W; if (ok[e]) v[e] = src[e]; }
-                }
-                if (in_scale) {
-                    const float sc = in_scale[ci], sh = in_shift[ci];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (ok[e]) v[e] = __fmaf_rn(v[e], sc, sh);   // same fma as the BN backward's mask
-                }
-                if (in_relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-            }
-            unsigned h0, m0, l0, h1, m1, l1;
-            ws_split_pair(v[0], v[1], h0, m0, l0);
-            ws_split_pair(v[2], v[3], h1, m1, l1);
-            unsigned* d = s_x + c * PSX + r * 24 + 2 * q;
-            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(d + SPX) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2*>(d + 2 * SPX) = u32x2{l0, l1};
-        }
+        };
+        // dY tile (zero outside the image / beyond Cout), then the activated input tile with halo: rows [Y0 - P, Y0 + TY + P),
+        // pixels [X0 - 8, X0 + 40)
+        stage(dy + ((size_t)n * dy_ctot + dy_coff) * HW, cog * 16, Cout, TY, 8, Y0, X0, s_dy, PSD, 16, SPD, false);
+        stage(x + ((size_t)n * x_ctot + x_coff) * HW, cig * 16, Cin, ROWS, 12, Y0 - P, X0 - 8, s_x, PSX, 24, SPX, true);
         __syncthreads();
         if (wid == 0) ws_wave<KS, 0>(s_x, s_dy, acc, lane);
         else if (wid == 1) ws_wave<KS, 1>(s_x, s_dy, acc, lane);
