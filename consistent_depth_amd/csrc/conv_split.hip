@@ -134,7 +134,7 @@ int launch_pack_split_table(const void* table_dev, int n, hipStream_t s) {
 // stores it.  The order of accumulation depends on nothing but (Cin, KS, DY): every launch shape gives the same bits.
 constexpr size_t SPLIT_REDUCE_LDS = 4 * 3 * 4096;   // one round of the cross-wave reduction: 4 owners x 3 foreign partials x 4 KB
 
-template <int KS, int NT, int TYP, int DY>
+template <int KS, int NT, int TYP, int DY, bool PIPE>
 __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
     const u32x4* __restrict__ wsp, int pack_tiles, const float* __restrict__ bias,
@@ -204,69 +204,91 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
 
     const int abase = li + COFF;   // LDS slot of this lane's pixel in tile row 0 at tap (0, 0)
 
+    // staging of one unit = (tile row r, 4-pixel quad) x the 8 channels of a chunk, in two halves: raw loads, then transform + split
+    auto stage_load = [&](int chunk, int u, float (&v)[8][4], unsigned (&keep)[4]) {
+        const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
+        const int gy = Y0 - P + r, gx = X0 - PADL + q4;
+        const bool row_in = (unsigned)gy < (unsigned)H;
+        const int gyc = row_in ? gy : 0;
+        if (vec_in) {       // W % 4 == 0: an aligned quad is inside or outside the image as a whole
+            const bool in = row_in && (unsigned)gx < (unsigned)W;
+            const float* src = xin + (size_t)gyc * W + (in ? gx : 0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ci = chunk * 8 + c;
+                const float4 f = *reinterpret_cast<const float4*>(src + (size_t)(ci < Cin ? ci : Cin - 1) * HW);
+                v[c][0] = f.x; v[c][1] = f.y; v[c][2] = f.z; v[c][3] = f.w;
+            }
+            keep[0] = keep[1] = keep[2] = keep[3] = in ? 0xffffffffu : 0u;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bool in = row_in && (unsigned)(gx + p) < (unsigned)W;
+                keep[p] = in ? 0xffffffffu : 0u;
+                const float* src = xin + (size_t)gyc * W + (in ? gx + p : 0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int ci = chunk * 8 + c;
+                    v[c][p] = src[(size_t)(ci < Cin ? ci : Cin - 1) * HW];
+                }
+            }
+        }
+    };
+    auto stage_finish = [&](int chunk, int u, float (&v)[8][4], const unsigned (&keep)[4]) {
+        const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ci = chunk * 8 + c;
+            const unsigned kc = ci < Cin ? 0xffffffffu : 0u;
+            float sc = 1.f, sh = 0.f;
+            if (in_scale) { sc = in_scale[ci < Cin ? ci : Cin - 1]; sh = in_shift[ci < Cin ? ci : Cin - 1]; }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float t = v[c][p];
+                if (in_scale) t = __fmaf_rn(t, sc, sh);
+                if (in_relu) t = fmaxf(t, 0.f);
+                v[c][p] = __uint_as_float(__float_as_uint(t) & keep[p] & kc);   // zero padding (pixels and channels) stays an exact zero
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4 hh, mm, ll;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                unsigned h, m, l;
+                split_pair(v[2 * c2][p], v[2 * c2 + 1][p], h, m, l);
+                hh[c2] = h; mm[c2] = m; ll[c2] = l;
+            }
+            const int slot = r * RSP + q4 + p;
+            s_in[slot] = hh; s_in[PLANE + slot] = mm; s_in[2 * PLANE + slot] = ll;
+        }
+    };
+    float pv[PIPE ? 8 : 1][4];
+    unsigned pkeep[4];
+    if constexpr (PIPE) {
+        static_assert(!PIPE || UNITS <= kBlock, "the pipelined variant stages one unit per thread");
+        stage_load(0, (int)threadIdx.x < UNITS ? threadIdx.x : UNITS - 1, pv, pkeep);   // (idle threads repeat the last unit: no branch around loads)
+    }
+
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         __syncthreads();   // the previous chunk's fragments are consumed
         // ---- stage 8 input channels: global fp32 -> (affine, relu) -> three bf16 planes, channels-last.  The 8 loads of a unit are
         // UNCONDITIONAL (clamped address; padding zeroed with an AND afterwards) so that they are all in flight before the first
         // wait: a load under a divergent branch is followed by s_waitcnt vmcnt(0), which serialised the 8 channels.
-        for (int u = threadIdx.x; u < UNITS; u += kBlock) {
-            const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
-            const int gy = Y0 - P + r, gx = X0 - PADL + q4;
-            const bool row_in = (unsigned)gy < (unsigned)H;
-            const int gyc = row_in ? gy : 0;
-            float v[8][4];
-            unsigned keep[4];   // per pixel: all ones inside the image
-            if (vec_in) {       // W % 4 == 0: an aligned quad is inside or outside the image as a whole
-                const bool in = row_in && (unsigned)gx < (unsigned)W;
-                const float* src = xin + (size_t)gyc * W + (in ? gx : 0);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int ci = chunk * 8 + c;
-                    const float4 f = *reinterpret_cast<const float4*>(src + (size_t)(ci < Cin ? ci : Cin - 1) * HW);
-                    v[c][0] = f.x; v[c][1] = f.y; v[c][2] = f.z; v[c][3] = f.w;
-                }
-                keep[0] = keep[1] = keep[2] = keep[3] = in ? 0xffffffffu : 0u;
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bool in = row_in && (unsigned)(gx + p) < (unsigned)W;
-                    keep[p] = in ? 0xffffffffu : 0u;
-                    const float* src = xin + (size_t)gyc * W + (in ? gx + p : 0);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const int ci = chunk * 8 + c;
-                        v[c][p] = src[(size_t)(ci < Cin ? ci : Cin - 1) * HW];
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int ci = chunk * 8 + c;
-                const unsigned kc = ci < Cin ? 0xffffffffu : 0u;
-                float sc = 1.f, sh = 0.f;
-                if (in_scale) { sc = in_scale[ci < Cin ? ci : Cin - 1]; sh = in_shift[ci < Cin ? ci : Cin - 1]; }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    float t = v[c][p];
-                    if (in_scale) t = __fmaf_rn(t, sc, sh);
-                    if (in_relu) t = fmaxf(t, 0.f);
-                    v[c][p] = __uint_as_float(__float_as_uint(t) & keep[p] & kc);   // zero padding (pixels and channels) stays an exact zero
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                u32x4 hh, mm, ll;
-#pragma unroll
-                for (int c2 = 0; c2 < 4; ++c2) {
-                    unsigned h, m, l;
-                    split_pair(v[2 * c2][p], v[2 * c2 + 1][p], h, m, l);
-                    hh[c2] = h; mm[c2] = m; ll[c2] = l;
-                }
-                const int slot = r * RSP + q4 + p;
-                s_in[slot] = hh; s_in[PLANE + slot] = mm; s_in[2 * PLANE + slot] = ll;
+        if constexpr (PIPE) {   // one unit per thread; its raw loads were issued before the previous chunk's MFMA loop
+            if ((int)threadIdx.x < UNITS) stage_finish(chunk, threadIdx.x, pv, pkeep);
+        } else {
+            for (int u = threadIdx.x; u < UNITS; u += kBlock) {
+                float v[8][4];
+                unsigned keep[4];
+                stage_load(chunk, u, v, keep);
+                stage_finish(chunk, u, v, keep);
             }
         }
         __syncthreads();
+        if constexpr (PIPE) {
+            stage_load(chunk + 1 < n_chunks ? chunk + 1 : chunk, (int)threadIdx.x < UNITS ? threadIdx.x : UNITS - 1, pv, pkeep);   // in flight during the MFMAs
+        }
 
         // ---- MFMA over this wave's tap steps of the chunk
         const int lin_end = (chunk + 1) * KSTEPS;
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     }
 }
 
-template <int KS, int NT, int TYP, int DY>
+template <int KS, int NT, int TYP, int DY, bool PIPE = false>
 static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                           const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                           int N, int H, int W, hipStream_t s) {
@@ -433,13 +455,13 @@ static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const
     const size_t lds = Cfg::LDS > SPLIT_REDUCE_LDS ? Cfg::LDS : SPLIT_REDUCE_LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_split_kernel<KS, NT, TYP, DY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_split_kernel<KS, NT, TYP, DY, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
     const int pack_tiles = split_ntiles(Cout), slices = (pack_tiles + NT - 1) / NT;
     const int tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * N, chunk_tiles = (tiles_total + 7) / 8;
-    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
+    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY, PIPE>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
                        x_coff, Cin, reinterpret_cast<const u32x4*>(wsplit), pack_tiles, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff,
                        Cout, stats, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk_tiles, slices);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
@@ -464,20 +486,23 @@ int launch_pack_split(const float* w, int Cout, int Cin, int ks, int transposed,
 }
 
 // (ty, cot) are the launch-shape hints of cd_conv2d_fwd_cfg.  A block has 4 (ty <= 4) or 8 M-tiles (rows for DY = 1, row pairs
-// for DY = 2) and 1 or 2 column tiles (cot >= 2 and the filter has >= 2 of them -> 2, then 4 M-tiles).
+// for DY = 2) and 1 or 2 column tiles (cot >= 2 and the filter has >= 2 of them -> 2, then 4 M-tiles); ty = 16 selects 4 M-tiles
+// with the next chunk's raw loads prefetched in registers across the MFMA loop.
 int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                       const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
                       int H, int W, int ks, int ty, int cot, hipStream_t s) {
     const int dy = split_dy(Cout);
     const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
-    const int mb = (nt == 2 || ty <= 4) ? 4 : 8;
-#define CD_SP(K, T, Y, D) return launch_split_t<K, T, Y, D>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
+    const bool pipe = ty >= 16;                       // hint 16: 4 M-tiles with the register-prefetch pipeline (latency-bound small images)
+    const int mb = (nt == 2 || ty <= 4 || pipe) ? 4 : 8;
+#define CD_SP(K, T, Y, D, PP) return launch_split_t<K, T, Y, D, PP>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
 #define CD_SP_K(K)                                                   \
     if (ks == K) {                                                   \
-        if (dy == 2) { if (mb == 8) CD_SP(K, 1, 16, 2); CD_SP(K, 1, 8, 2); } \
-        if (nt == 2) CD_SP(K, 2, 4, 1);                              \
-        if (mb == 8) CD_SP(K, 1, 8, 1);                              \
-        CD_SP(K, 1, 4, 1);                                           \
+        if (dy == 2) { if (mb == 8) CD_SP(K, 1, 16, 2, false); if (pipe) CD_SP(K, 1, 8, 2, true); CD_SP(K, 1, 8, 2, false); } \
+        if (nt == 2) { if (pipe) CD_SP(K, 2, 4, 1, true); CD_SP(K, 2, 4, 1, false); }  \
+        if (mb == 8) CD_SP(K, 1, 8, 1, false);                       \
+        if (pipe) CD_SP(K, 1, 4, 1, true);                           \
+        CD_SP(K, 1, 4, 1, false);                                    \
     }
     CD_SP_K(3) CD_SP_K(5) CD_SP_K(7) CD_SP_K(11)
 #undef CD_SP_K
