@@ -134,7 +134,7 @@ int launch_pack_split_table(const void* table_dev, int n, hipStream_t s) {
 // stores it.  The order of accumulation depends on nothing but (Cin, KS, DY): every launch shape gives the same bits.
 constexpr size_t SPLIT_REDUCE_LDS = 4 * 3 * 4096;   // one round of the cross-wave reduction: 4 owners x 3 foreign partials x 4 KB
 
-template <int KS, int NT, int TYP, int DY, bool PIPE>
+template <int KS, int NT, int TYP, int DY, int CGS>
 __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
     const u32x4* __restrict__ wsp, int pack_tiles, const float* __restrict__ bias,
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
             }
         }
     };
-    auto stage_finish = [&](int chunk, int u, float (&v)[8][4], const unsigned (&keep)[4]) {
+    auto stage_finish = [&](int chunk, int u, float (&v)[8][4], const unsigned (&keep)[4], int gbase) {
         const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -259,44 +259,36 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
                 split_pair(v[2 * c2][p], v[2 * c2 + 1][p], h, m, l);
                 hh[c2] = h; mm[c2] = m; ll[c2] = l;
             }
-            const int slot = r * RSP + q4 + p;
+            const int slot = gbase + r * RSP + q4 + p;
             s_in[slot] = hh; s_in[PLANE + slot] = mm; s_in[2 * PLANE + slot] = ll;
         }
     };
-    float pv[PIPE ? 8 : 1][4];
-    unsigned pkeep[4];
-    if constexpr (PIPE) {
-        static_assert(!PIPE || UNITS <= kBlock, "the pipelined variant stages one unit per thread");
-        stage_load(0, (int)threadIdx.x < UNITS ? threadIdx.x : UNITS - 1, pv, pkeep);   // (idle threads repeat the last unit: no branch around loads)
-    }
-
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        __syncthreads();   // the previous chunk's fragments are consumed
-        // ---- stage 8 input channels: global fp32 -> (affine, relu) -> three bf16 planes, channels-last.  The 8 loads of a unit are
-        // UNCONDITIONAL (clamped address; padding zeroed with an AND afterwards) so that they are all in flight before the first
-        // wait: a load under a divergent branch is followed by s_waitcnt vmcnt(0), which serialised the 8 channels.
-        if constexpr (PIPE) {   // one unit per thread; its raw loads were issued before the previous chunk's MFMA loop
-            if ((int)threadIdx.x < UNITS) stage_finish(chunk, threadIdx.x, pv, pkeep);
-        } else {
-            for (int u = threadIdx.x; u < UNITS; u += kBlock) {
-                float v[8][4];
-                unsigned keep[4];
-                stage_load(chunk, u, v, keep);
-                stage_finish(chunk, u, v, keep);
-            }
+    // CGS channel chunks (8 channels each) are staged per barrier round, each into its own LDS image: the deep levels of the
+    // hourglass have few tiles per launch and are a latency chain of rounds -- two chunks per round halve it
+    const int n_rounds = (n_chunks + CGS - 1) / CGS;
+    for (int round = 0; round < n_rounds; ++round) {
+        __syncthreads();   // the previous round's fragments are consumed
+        // ---- stage: global fp32 -> (affine, relu) -> three bf16 planes, channels-last.  The 8 loads of a unit are UNCONDITIONAL
+        // (clamped address; padding zeroed with an AND afterwards) so that they are all in flight before the first wait: a load
+        // under a divergent branch is followed by s_waitcnt vmcnt(0), which serialised the 8 channels.
+        for (int uu = threadIdx.x; uu < CGS * UNITS; uu += kBlock) {
+            const int g2 = uu / UNITS, u = uu - g2 * UNITS;
+            float v[8][4];
+            unsigned keep[4];
+            stage_load(round * CGS + g2, u, v, keep);     // (a chunk beyond the last one: channels >= Cin, zeroed)
+            stage_finish(round * CGS + g2, u, v, keep, g2 * 3 * PLANE);
         }
         __syncthreads();
-        if constexpr (PIPE) {
-            stage_load(chunk + 1 < n_chunks ? chunk + 1 : chunk, (int)threadIdx.x < UNITS ? threadIdx.x : UNITS - 1, pv, pkeep);   // in flight during the MFMAs
-        }
 
         // ---- MFMA over this wave's tap steps of the chunk
-        const int lin_end = (chunk + 1) * KSTEPS;
+        const int lin_end = ((round + 1) * CGS < n_chunks ? (round + 1) * CGS : n_chunks) * KSTEPS;
         auto step = [&](const bf16x8 (&bcur)[NT][3], bf16x8 (&bfill)[NT][3], int l) {
             load_b(bfill, l + 4);   // this wave's next step: in flight during the MFMAs below
+            const int chunk = l / KSTEPS;   // (wave-uniform)
             const int tap = (l - chunk * KSTEPS) * 2 + g;
             const int ky = tap / KS, kx = tap - ky * KS;
-            const int slot0 = abase + ((tap < TAPS) ? ky * RSP + kx : 0);   // a padded tap carries zero weights: any valid slot
+            // a padded tap carries zero weights: any valid slot
+            const int slot0 = abase + (chunk - round * CGS) * 3 * PLANE + ((tap < TAPS) ? ky * RSP + kx : 0);
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, smallest first
 #pragma unroll
             for (int mg = 0; mg < MB; mg += MG) {
@@ -446,22 +438,22 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     }
 }
 
-template <int KS, int NT, int TYP, int DY, bool PIPE = false>
+template <int KS, int NT, int TYP, int DY, int CGS = 1>
 static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                           const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                           int N, int H, int W, hipStream_t s) {
     using Cfg = SplitCfg<KS, TYP, DY>;
     const int tiles_x = (W + SP_TX - 1) / SP_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
-    const size_t lds = Cfg::LDS > SPLIT_REDUCE_LDS ? Cfg::LDS : SPLIT_REDUCE_LDS;
+    const size_t lds = CGS * Cfg::LDS > SPLIT_REDUCE_LDS ? CGS * Cfg::LDS : SPLIT_REDUCE_LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_split_kernel<KS, NT, TYP, DY, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_split_kernel<KS, NT, TYP, DY, CGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
     const int pack_tiles = split_ntiles(Cout), slices = (pack_tiles + NT - 1) / NT;
     const int tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * N, chunk_tiles = (tiles_total + 7) / 8;
-    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY, PIPE>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
+    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY, CGS>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
                        x_coff, Cin, reinterpret_cast<const u32x4*>(wsplit), pack_tiles, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff,
                        Cout, stats, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk_tiles, slices);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
@@ -487,22 +479,22 @@ int launch_pack_split(const float* w, int Cout, int Cin, int ks, int transposed,
 
 // (ty, cot) are the launch-shape hints of cd_conv2d_fwd_cfg.  A block has 4 (ty <= 4) or 8 M-tiles (rows for DY = 1, row pairs
 // for DY = 2) and 1 or 2 column tiles (cot >= 2 and the filter has >= 2 of them -> 2, then 4 M-tiles); ty = 16 selects 4 M-tiles
-// with the next chunk's raw loads prefetched in registers across the MFMA loop.
+// with two 8-channel chunks staged per barrier round.
 int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                       const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
                       int H, int W, int ks, int ty, int cot, hipStream_t s) {
     const int dy = split_dy(Cout);
     const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
-    const bool pipe = ty >= 16;                       // hint 16: 4 M-tiles with the register-prefetch pipeline (latency-bound small images)
-    const int mb = (nt == 2 || ty <= 4 || pipe) ? 4 : 8;
-#define CD_SP(K, T, Y, D, PP) return launch_split_t<K, T, Y, D, PP>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
+    const bool two = ty >= 16;                        // hint 16: 4 M-tiles, two channel chunks per barrier round (latency-bound small images)
+    const int mb = (nt == 2 || ty <= 4 || two) ? 4 : 8;
+#define CD_SP(K, T, Y, D, G) return launch_split_t<K, T, Y, D, G>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
 #define CD_SP_K(K)                                                   \
     if (ks == K) {                                                   \
-        if (dy == 2) { if (mb == 8) CD_SP(K, 1, 16, 2, false); if (pipe) CD_SP(K, 1, 8, 2, true); CD_SP(K, 1, 8, 2, false); } \
-        if (nt == 2) { if (pipe) CD_SP(K, 2, 4, 1, true); CD_SP(K, 2, 4, 1, false); }  \
-        if (mb == 8) CD_SP(K, 1, 8, 1, false);                       \
-        if (pipe) CD_SP(K, 1, 4, 1, true);                           \
-        CD_SP(K, 1, 4, 1, false);                                    \
+        if (dy == 2) { if (mb == 8) CD_SP(K, 1, 16, 2, 1); if (two) CD_SP(K, 1, 8, 2, 2); CD_SP(K, 1, 8, 2, 1); } \
+        if (nt == 2) { if (two) CD_SP(K, 2, 4, 1, 2); CD_SP(K, 2, 4, 1, 1); }  \
+        if (mb == 8) CD_SP(K, 1, 8, 1, 1);                           \
+        if (two) CD_SP(K, 1, 4, 1, 2);                               \
+        CD_SP(K, 1, 4, 1, 1);                                        \
     }
     CD_SP_K(3) CD_SP_K(5) CD_SP_K(7) CD_SP_K(11)
 #undef CD_SP_K
