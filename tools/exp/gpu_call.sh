@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_conv_gpu.py -x -q 2>&1 | tail -3
-for i in 1 2 5 7 9 12 13 11 15; do timeout 120 python tools/conv_bench.py --only $i --cfgs 4x1,16x1,4x2,16x2 2>/dev/null | cut -c1-180; done
-for i in 5 7; do timeout 120 python tools/conv_bench.py --dgrad --only $i --cfgs 4x1,16x1,4x2,16x2 2>/dev/null | cut -c1-180; done
-timeout 300 python bench.py --no-cpu-baseline --no-loss-microbench 2>/dev/null | tail -1 | cut -c90-200
+export CD_AMD_REPORT=1
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -14
+cp gpurun_out/parity_log.txt gpurun_out/parity_full_r02.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python bench.py > gpurun_out/bench_r02_n1.json 2> gpurun_out/bench_r02_n1.err
+cat gpurun_out/bench_r02_n1.json | cut -c1-330
