@@ -2,6 +2,11 @@
 """Roofline table of the convolutions from the committed sweeps (no GPU needed):
 
     python tools/roofline_table.py > profiles/conv_roofline_r01.txt
+    python tools/roofline_table.py r02 > profiles/conv_roofline_r02.txt
+
+r02: launches that run on the split-bf16 kernels (k >= 3 with >= 8 input channels; 1x1 forward / dgrad at >= 4096 row tiles,
+> 16 output channels) are priced at the dense BF16 matrix peak divided by the six products per multiply-add
+(2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work); the others (1x1 weight gradient, RGB stem, small 1x1) at the fp32 peak.
 
 For every forward / input-gradient / weight-gradient shape of one BS4 step (8 images): FLOPs, algorithmic HBM bytes
 (read the two operands once, write the result once; weights are negligible), the two bounds at the MI355X peaks
@@ -9,12 +14,16 @@ For every forward / input-gradient / weight-gradient shape of one BS4 step (8 im
 import json
 import os
 
+import sys
+
 PEAK_TF, PEAK_BW = 157.3e12, 8.0e12
+PEAK_SPLIT = 2500e12 / 6
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rows():
-    for line in open(os.path.join(ROOT, "profiles", "conv_sweep_r01.txt")):
+    for line in open(os.path.join(ROOT, "profiles", f"conv_sweep_{TAG}.txt")):
         r = json.loads(line)
         if "shape" not in r:
             continue
@@ -22,7 +31,7 @@ def rows():
         px = 8 * H * W
         yield ("fwd" if kind == "f" else "dgrad", H, W, ks, ci, co, r["n"], r["best_us"], 2.0 * px * ci * ks * ks * co,
                4.0 * px * (ci + co) + (4.0 * px * co if kind == "d" else 0.0))      # dgrad accumulates: reads its output too
-    for line in open(os.path.join(ROOT, "profiles", "wgrad_sweep_r01.txt")):
+    for line in open(os.path.join(ROOT, "profiles", f"wgrad_sweep_{TAG}.txt")):
         r = json.loads(line)
         if "shape" not in r:
             continue
@@ -34,7 +43,8 @@ def rows():
 def main():
     out, tot = [], {"t": 0.0, "mfma": 0.0, "hbm": 0.0, "roof": 0.0}
     for kind, H, W, ks, ci, co, n, us, flops, byts in rows():
-        t_mfma, t_hbm = flops / PEAK_TF * 1e6, byts / PEAK_BW * 1e6
+        split = TAG != "r01" and ((ks >= 3 and ci >= 8) or (ks == 1 and kind != "wgrad" and co > 16 and 32 <= ci <= 384 and 8 * H * ((W + 31) // 32) >= 4096))
+        t_mfma, t_hbm = flops / (PEAK_SPLIT if split else PEAK_TF) * 1e6, byts / PEAK_BW * 1e6
         roof = max(t_mfma, t_hbm)
         out.append((us * n, f"{kind:5s} {H:3d}x{W:<3d} k={ks:<2d} {ci:3d}->{co:<3d} x{n}  {flops / 1e9:8.2f} GFLOP {byts / 1e6:7.1f} MB  "
                             f"mfma {t_mfma:7.1f} us  hbm {t_hbm:6.1f} us  measured {us:7.1f} us  {'MFMA' if t_mfma >= t_hbm else 'HBM '}-bound: "
