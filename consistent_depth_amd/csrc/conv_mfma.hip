@@ -579,8 +579,11 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
         // launch-shape hints: tile_rows <= 4 -> 4 M-tiles per block, else 8; co_tiles >= 2 -> two 32-column tiles per block (then 4
         // M-tiles).  Unhinted: 4 M-tiles, two column tiles when the filter has them and the image is large (conv_split_bench)
         int sty = cd::g_force_conv_ty ? cd::g_force_conv_ty : tile_rows, scot = cd::g_force_conv_cot ? cd::g_force_conv_cot : co_tiles;
-        if (sty == 0) sty = 4;
-        if (scot == 0) scot = ((long long)N * H * W > 8LL * 96 * 56) ? 2 : 1;
+        // unhinted (profiles/conv_sweep_r02.txt): up to 96x56 (x 8 images) two channel chunks per barrier round win everywhere
+        // (hint 16: latency chains); above, two column tiles when the filter has them (also with two chunks), else 8 M-tiles
+        const bool small = (long long)N * H * W <= 8LL * 96 * 56;
+        if (scot == 0) scot = small ? 1 : 2;
+        if (sty == 0) sty = (small || cd::split_column_tiles(Cout) >= 2) ? 16 : 8;
         return cd::launch_conv_split(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift,
                                      in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, ks, sty, scot, s);
     }
