@@ -257,8 +257,8 @@ def main():
                                + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"),
                    "conv_backend": args.backend,
                    "conv_arith": ("fp32 results from split operands: every fp32 input = 3 exact bf16 terms, 6 cross products on the BF16 matrix "
-                                  "cores, fp32 accumulate (k>=3 fwd/dgrad/wgrad, 1x1 fwd/dgrad; as close to fp64 as the fp32 MFMA: profiles/mfma_split_exp_r02.txt, "
-                                  "tests/test_conv_gpu.py); 1x1 wgrad + RGB stem on the fp32 MFMA" if lib.cd_get_conv_arith() >= 1 else "fp32 MFMA (CD_AMD_CONV_ARITH=fp32)")
+                                  "cores, fp32 accumulate (all convolutions but the RGB stem, fwd/dgrad/wgrad; as close to fp64 as the fp32 MFMA: profiles/mfma_split_exp_r02.txt, "
+                                  "tests/test_conv_gpu.py); RGB stem and small-image 1x1 on the fp32 MFMA" if lib.cd_get_conv_arith() >= 1 else "fp32 MFMA (CD_AMD_CONV_ARITH=fp32)")
                    if args.backend == "hip" else "MIOpen fp32",
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "hip_graph": graphed, "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),

@@ -527,15 +527,29 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
 
 // Packed layout and launch shape of one weight gradient -- ONE definition for the launchers, the workspace size,
 // cd_conv2d_wgrad_plan and the unpack descriptors.
-struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide, split_arith; size_t slice; };
+struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide, split_arith, split1x1, blocks_x; size_t slice; };
 
 // the split-bf16 kernel (wgrad_split.hip) takes the k = 5, 7, 11 gradients when that arithmetic is selected (cd_set_conv_arith),
 // except the RGB stem (3 input channels would pad a 16-wide tile 5-fold: the few-input-channel fp32 kernel stays)
 static inline bool wgrad_uses_split(int ks, int Cin) { return cd_get_conv_arith() >= 1 && split_supported(ks) && Cin >= 8; }
 
+// 1x1 under arithmetic mode 2: wgrad1x1_split.hip (64 x 128 patches per wave, packed [split][cog][cig][64][128])
+static WgLayout wgrad_layout_split1x1(int Cout, int Cin, long long steps) {
+    WgLayout L;
+    L.wide = 0; L.fewcin = 0; L.split_arith = 0; L.split1x1 = 1;
+    L.cob = WGRAD1X1_COB; L.cib = WGRAD1X1_CIB;
+    int pg, sub, groups;
+    wgrad1x1_split_shape(Cout, Cin, &L.cogs, &L.cigs, &pg, &sub, &groups);
+    L.slice = (size_t)L.cogs * L.cigs * L.cob * L.cib;
+    L.max_splits = wgrad1x1_split_blocks(Cout, Cin, 1LL << 40) * sub;
+    L.blocks_x = wgrad1x1_split_blocks(Cout, Cin, steps);
+    L.splits = L.blocks_x * sub;
+    return L;
+}
+
 static WgLayout wgrad_layout_split(int Cout, int Cin, int ks, int N, int H, int W) {
     WgLayout L;
-    L.wide = 0; L.fewcin = 0; L.split_arith = 1;
+    L.wide = 0; L.fewcin = 0; L.split_arith = 1; L.split1x1 = 0; L.blocks_x = 0;
     L.cob = 16; L.cib = 16;
     L.cogs = (Cout + 15) / 16; L.cigs = (Cin + 15) / 16;
     L.slice = (size_t)L.cogs * L.cigs * ks * ks * 256;
@@ -545,10 +559,15 @@ static WgLayout wgrad_layout_split(int Cout, int Cin, int ks, int N, int H, int 
     return L;
 }
 
-static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W, int arith = -1) {
-    if (arith < 0 ? wgrad_uses_split(ks, Cin) : (arith >= 1 && split_supported(ks) && Cin >= 8)) return wgrad_layout_split(Cout, Cin, ks, N, H, W);
+// x_ctot / dy_ctot: channel counts of the buffers the operands are slices of (0 = unknown: the 1x1 split kernel's 32-bit offsets are
+// then checked against Cin / Cout only, and again at launch)
+static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W, int arith = -1, int x_ctot = 0, int dy_ctot = 0) {
+    const int mode = arith < 0 ? cd_get_conv_arith() : arith;
+    if (mode >= 1 && split_supported(ks) && Cin >= 8) return wgrad_layout_split(Cout, Cin, ks, N, H, W);
+    if (mode == 2 && ks == 1 && N > 0 && wgrad1x1_split_ok(Cout, Cin, N, H, W, x_ctot > Cin ? x_ctot : Cin, dy_ctot > Cout ? dy_ctot : Cout))
+        return wgrad_layout_split1x1(Cout, Cin, (long long)N * H * W / 16);
     WgLayout L;
-    L.split_arith = 0;
+    L.split_arith = 0; L.split1x1 = 0; L.blocks_x = 0;
     WgPlan p = wgrad_plan(ks, Cout, Cin);
     L.wide = (N > 0 && g_wgrad_wide && wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p)) ? 1 : 0;
     L.fewcin = (ks == 7 && Cin <= 4 && p.co_t == 2 && !(g_wgrad_dbg & 8)) ? 1 : 0;
@@ -577,6 +596,10 @@ size_t cd_conv2d_wgrad_workspace_floats(int Cout, int Cin, int ks) {
     // every block owns a slice: the largest number of blocks per channel group the launcher can choose, for either 1x1 layout
     const cd::WgLayout a = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0);
     size_t n = a.slice * (size_t)a.max_splits;
+    if (ks == 1 && Cin >= 32 && Cout >= 96) {   // the 1x1 split layout (arithmetic mode 2, chosen per launch by the image size)
+        const cd::WgLayout b = cd::wgrad_layout_split1x1(Cout, Cin, 1LL << 40);
+        if (b.slice * (size_t)b.max_splits > n) n = b.slice * (size_t)b.max_splits;
+    }
     if (cd::split_supported(ks) && Cin >= 8) {   // either arithmetic may be selected later: room for both layouts
         const cd::WgLayout b = cd::wgrad_layout(Cout, Cin, ks, 0, 0, 0, cd_get_conv_arith() >= 1 ? 0 : 1);
         if (b.slice * (size_t)b.max_splits > n) n = b.slice * (size_t)b.max_splits;
@@ -619,8 +642,19 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     // (the workspace needs no initialisation: every block writes its whole slice; bit 1 of `accumulate` is accepted and ignored)
     cd::WgPlan p = cd::wgrad_plan(ks, Cout, Cin);
     const bool wide = cd::g_wgrad_wide && cd::wgrad_wide_plan(ks, Cout, Cin, N, H, W, &p);
-    const cd::WgLayout L = cd::wgrad_layout(Cout, Cin, ks, N, H, W);
+    cd::WgLayout L = cd::wgrad_layout(Cout, Cin, ks, N, H, W);
     int rc = CD_ERR_UNSUPPORTED;
+    if (L.split1x1 && !cd::wgrad1x1_split_ok(Cout, Cin, N, H, W, x_ctot, dy_ctot)) return CD_ERR_UNSUPPORTED;   // (buffers too large for 32-bit offsets)
+    if (L.split1x1) {
+        rc = cd::launch_wgrad1x1_split(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W,
+                                       L.blocks_x, s);
+        if (rc != CD_OK || (accumulate & 4)) return rc;
+        const int total = Cout * Cin;
+        hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s, workspace,
+                           Cout, Cin, 1, L.cob, L.cib, L.cigs, L.splits, L.slice, dw, accumulate & 1);
+        CD_CHECK_LAUNCH();
+        return CD_OK;
+    }
     if (L.split_arith) {
         rc = cd::launch_wgrad_split(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, ks,
                                     L.splits, s);

@@ -14,4 +14,19 @@ int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const fl
                        const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int ks, int splits,
                        hipStream_t s);
 
+// ---- 1x1 weight gradient (wgrad1x1_split.hip): a wave owns a 64 x 128 (co x ci) patch of dW
+constexpr int WGRAD1X1_COB = 64, WGRAD1X1_CIB = 128;
+// usable with >= 96 output channels, when H * W is a multiple of 16 (whole 16-pixel steps inside an image), the tensors have < 2^30 elements per image set and
+// the image is large enough to give every wave several steps
+inline bool wgrad1x1_split_ok(int Cout, int Cin, int N, int H, int W, int x_ctot, int dy_ctot) {
+    const long long hw = (long long)H * W;
+    return Cout >= 96 && Cin >= 32 &&   // (fewer output channels: a single half-empty 64 x 128 patch -- the staged kernel is faster)
+           hw % 16 == 0 && (long long)N * hw >= 20000 && hw * (x_ctot > dy_ctot ? x_ctot : dy_ctot) < (1LL << 30);
+}
+void wgrad1x1_split_shape(int Cout, int Cin, int* cogs, int* cigs, int* pg, int* sub, int* groups);
+int wgrad1x1_split_blocks(int Cout, int Cin, long long steps);   // grid.x; slices of the packed result = blocks * sub
+int launch_wgrad1x1_split(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,
+                          const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int blocks_x,
+                          hipStream_t s);
+
 }  // namespace cd

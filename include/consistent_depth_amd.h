@@ -252,11 +252,12 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
  *     significant cross products run on the BF16 matrix cores with fp32 accumulation -- as close to fp64 as the fp32
  *     instruction (profiles/mfma_split_exp_r02.txt), 1.5-1.7x faster; not bitwise the fmaf chain, +-inf inputs give NaN;
  *   2: 1, plus the 1x1 forward / input gradient on images of >= 4096 row tiles (conv1x1_split.hip: filter slice resident in
- *     LDS, activations split in registers; 1.3-2x faster per launch);
+ *     LDS, activations split in registers; 1.3-2x faster per launch) and the 1x1 weight gradient with >= 96 output channels
+ *     (wgrad1x1_split.hip: both operands straight from global memory into matrix fragments; 1.4-1.5x);
  *   0: the fp32 matrix instruction everywhere (bitwise a k-ordered fmaf chain).
  * The packed filter holds every layout, so the mode may change between launches without re-packing.  The weight gradient of
- * the k >= 3 filters follows the same switch (wgrad_split.hip); its packed layout (cd_conv2d_wgrad_plan) differs between mode 0
- * and modes 1/2, so a plan -- and a cd_hourglass handle -- belongs to the mode it was made under. */
+ * the filters follows the same switch (wgrad_split.hip, wgrad1x1_split.hip); its packed layout (cd_conv2d_wgrad_plan) differs
+ * between the modes, so a plan -- and a cd_hourglass handle -- belongs to the mode it was made under. */
 int cd_set_conv_arith(int mode);
 int cd_get_conv_arith(void);
 /* The upper bound of co_tiles for (Cout, ks) under the current arithmetic mode (split mode, k >= 5: tile_rows 4 / >4 selects

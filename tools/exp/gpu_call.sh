@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python tools/conv_sweep.py --no-pipe-axis --iters 4 > gpurun_out/conv_sweep_r02.txt 2> gpurun_out/conv_sweep_r02.err
-tail -3 gpurun_out/conv_sweep_r02.txt | cut -c1-300
-timeout 300 python tools/wgrad_sweep.py --iters 4 > gpurun_out/wgrad_sweep_r02.txt 2> gpurun_out/wgrad_sweep_r02.err
-tail -2 gpurun_out/wgrad_sweep_r02.txt
+timeout 600 python -m pytest tests/test_layers_gpu.py tests/test_conv_gpu.py -x -q -k "wgrad or weight_gradient" 2>&1 | tail -4
+for a in split3 split; do for i in 16 17 18 6 10; do CD_AMD_CONV_ARITH=$a timeout 120 python tools/conv_bench.py --wgrad --only $i 2>/dev/null; done; done
+timeout 120 python -m pytest tests/test_finetune_gpu.py tests/test_hourglass_engine_gpu.py -x -q -k "reproducible or c_handle or both_conv or 2x64x96" 2>&1 | tail -3
+timeout 300 python bench.py --no-cpu-baseline --no-loss-microbench 2>/dev/null | tail -1 | cut -c90-200
