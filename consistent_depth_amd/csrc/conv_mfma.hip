@@ -520,7 +520,8 @@ int cd_set_conv_arith(int mode) {
 
 int cd_get_conv_arith(void) { return cd::g_conv_arith; }
 
-// fp32 layout, followed (k = 5, 7, 11) by the split-bf16 layout: both are always packed, the launch picks one
+// fp32 layout, followed (where a split kernel exists: k >= 3, and 1x1 with > 16 output channels) by its bf16 layout: both are
+// always packed, the launch picks one
 size_t cd_conv2d_packed_weight_floats(int Cout, int Cin, int ks, int transposed) {
     if (Cout <= 0 || Cin <= 0 || !(ks == 1 || ks == 3 || ks == 5 || ks == 7 || ks == 11)) return 0;
     const int OC = transposed ? Cin : Cout, IC = transposed ? Cout : Cin;

@@ -1,4 +1,4 @@
-// Direct 2-D convolution at fp32 accuracy on the gfx950 BF16 matrix cores (forward and input gradient, k in {5, 7, 11}).
+// Direct 2-D convolution at fp32 accuracy on the gfx950 BF16 matrix cores (forward and input gradient, k in {3, 5, 7, 11}).
 //
 // CDNA4 has no TF32/xf32 and its fp32 matrix instruction runs at the vector rate (157 TFLOP/s); the bf16 instruction
 // v_mfma_f32_32x32x16_bf16 is ~14x faster per multiply-add (2.1 PFLOP/s measured, profiles/mfma_rate_exp_r02.txt).  Every

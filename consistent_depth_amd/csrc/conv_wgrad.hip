@@ -529,7 +529,7 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
 // cd_conv2d_wgrad_plan and the unpack descriptors.
 struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide, split_arith, split1x1, blocks_x; size_t slice; };
 
-// the split-bf16 kernel (wgrad_split.hip) takes the k = 5, 7, 11 gradients when that arithmetic is selected (cd_set_conv_arith),
+// the split-bf16 kernel (wgrad_split.hip) takes the k = 3, 5, 7, 11 gradients when that arithmetic is selected (cd_set_conv_arith),
 // except the RGB stem (3 input channels would pad a 16-wide tile 5-fold: the few-input-channel fp32 kernel stays)
 static inline bool wgrad_uses_split(int ks, int Cin) { return cd_get_conv_arith() >= 1 && split_supported(ks) && Cin >= 8; }
 

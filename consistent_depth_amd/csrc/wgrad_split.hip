@@ -1,4 +1,4 @@
-// Weight gradient of the stride-1 "same" convolution at fp32 accuracy on the gfx950 BF16 matrix cores (k in {5, 7, 11}).
+// Weight gradient of the stride-1 "same" convolution at fp32 accuracy on the gfx950 BF16 matrix cores (k in {3, 5, 7, 11}).
 //
 //   dW[co][ci][ky][kx] = sum_{n,y,x} dY[n][co][y][x] * act(X)[n][ci][y+ky-P][x+kx-P]
 //

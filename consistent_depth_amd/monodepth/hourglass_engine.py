@@ -475,7 +475,7 @@ class HourglassEngine:
                 yield from self._all_steps(st.up)
 
     def plan(self, N, H, W):
-        # the arithmetic mode of the k >= 5 convolutions (cd_set_conv_arith) selects different kernels with different packed
+        # the arithmetic mode of the convolutions (cd_set_conv_arith) selects different kernels with different packed
         # weight-gradient layouts and tuned launch shapes: a plan belongs to the mode it was built under
         key = (N, H, W, _native.lib().cd_get_conv_arith())
         if key not in self._plans:

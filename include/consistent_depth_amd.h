@@ -227,7 +227,8 @@ typedef struct cd_pack_desc {
 int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream);
 
 /* y[:, y_coff : y_coff+Cout] = conv2d(act(x[:, x_coff : x_coff+Cin]), w) + bias, stride 1, zero
- * padding (ks-1)/2, ks in {1,3,5,7,11}, on the fp32 matrix cores (exact fp32).
+ * padding (ks-1)/2, ks in {1,3,5,7,11}, at fp32 accuracy: on the BF16 matrix cores from exactly split operands or on the fp32
+ * matrix instruction, by cd_set_conv_arith (below).
  *   act(v) = relu?(v * in_scale[c] + in_shift[c])   when in_scale/in_shift are given (the producer's
  *            BatchNorm-apply [+ReLU] fused into the load), relu only when in_relu and no scale, else v;
  *   stats (optional, [CD_BN_STAT_SLOTS][y_ctot][2] doubles, caller-zeroed): per-channel sum and sum of squares of the
@@ -260,7 +261,7 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
  * between the modes, so a plan -- and a cd_hourglass handle -- belongs to the mode it was made under. */
 int cd_set_conv_arith(int mode);
 int cd_get_conv_arith(void);
-/* The upper bound of co_tiles for (Cout, ks) under the current arithmetic mode (split mode, k >= 5: tile_rows 4 / >4 selects
+/* The upper bound of co_tiles for (Cout, ks) under the current arithmetic mode (split modes, k >= 3: tile_rows 4 / 8 / 16 selects
  * 4 / 8 row tiles per workgroup, co_tiles 1 / 2 one or two 32-channel column tiles). */
 int cd_conv2d_packed_co_tiles(int Cout, int ks);
 

@@ -68,3 +68,49 @@ def test_product_never_imports_oracle():
         src = open(path).read()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
         assert "libcd_oracle" not in src, path
+
+
+def test_weight_gradient_workspace_covers_every_plan():
+    """Host-side consistency of the weight-gradient layouts (no GPU work): for every arithmetic mode and image size the packed
+    partial sums of cd_conv2d_wgrad_plan -- splits x co groups x ci groups x taps x cob x cib floats -- fit the workspace that
+    cd_conv2d_wgrad_workspace_floats sizes WITHOUT knowing the mode or the image (a caller allocates once)."""
+    import ctypes
+    from consistent_depth_amd import _native
+    lib = _native.lib()
+    before = lib.cd_get_conv_arith()
+    shapes = [(16, 64, 11), (32, 64, 11), (64, 64, 11), (16, 64, 7), (32, 32, 7), (64, 32, 5), (32, 64, 3), (1, 64, 3), (128, 3, 7),
+              (208, 128, 1), (224, 128, 1), (128, 128, 1), (256, 256, 1), (160, 256, 1), (112, 128, 1), (64, 128, 1), (32, 256, 1),
+              (100, 40, 1), (24, 40, 11), (2048, 2048, 1), (8, 8, 3)]
+    images = [(8, 384, 224), (8, 192, 112), (8, 96, 56), (8, 48, 28), (8, 24, 14), (2, 64, 96), (1, 13, 7), (2, 128, 512), (32, 384, 384)]
+    try:
+        for mode in (0, 1, 2):
+            assert lib.cd_set_conv_arith(mode) == 0 and lib.cd_get_conv_arith() == mode
+            for Cout, Cin, ks in shapes:
+                ws = lib.cd_conv2d_wgrad_workspace_floats(Cout, Cin, ks)
+                assert ws > 0
+                for N, H, W in images:
+                    cob, cib, splits = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                    assert lib.cd_conv2d_wgrad_plan(Cout, Cin, ks, N, H, W, ctypes.byref(cob), ctypes.byref(cib), ctypes.byref(splits)) == 0
+                    assert cob.value > 0 and cib.value > 0 and splits.value >= 1
+                    need = (-(-Cout // cob.value)) * (-(-Cin // cib.value)) * ks * ks * cob.value * cib.value * splits.value
+                    assert need <= ws, (mode, Cout, Cin, ks, N, H, W, cob.value, cib.value, splits.value, need, ws)
+        assert lib.cd_set_conv_arith(3) != 0     # unknown mode
+    finally:
+        lib.cd_set_conv_arith(before)
+
+
+def test_packed_filter_holds_every_layout():
+    """cd_conv2d_packed_weight_floats does not depend on the arithmetic mode (the packed buffer carries the fp32 layout and, where a
+    split kernel exists, its bf16 layout), so a mode switch never needs a re-allocation."""
+    from consistent_depth_amd import _native
+    lib = _native.lib()
+    before = lib.cd_get_conv_arith()
+    try:
+        sizes = {}
+        for mode in (0, 1, 2):
+            lib.cd_set_conv_arith(mode)
+            sizes[mode] = [lib.cd_conv2d_packed_weight_floats(co, ci, ks, tr) for co, ci, ks in ((16, 64, 11), (208, 128, 1), (64, 32, 3), (128, 3, 7), (1, 64, 3))
+                           for tr in (0, 1)]
+        assert sizes[0] == sizes[1] == sizes[2] and all(v > 0 for v in sizes[0])
+    finally:
+        lib.cd_set_conv_arith(before)

@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["split", "fp32"])
 def arith(request):
-    """Both arithmetic modes of the k >= 5 convolutions (cd_set_conv_arith)."""
+    """The split-bf16 (default) and the fp32-instruction arithmetic of the convolutions (cd_set_conv_arith)."""
     from consistent_depth_amd import _native
     lib = _native.lib()
     before = lib.cd_get_conv_arith()
