@@ -9,7 +9,8 @@
 // ulp of the product), accumulated in fp32 by the matrix core.  Measured against fp64 this is as close as -- on long sums
 // closer than -- the native fp32 instruction (profiles/mfma_split_exp_r02.txt: error / sum|a*b| 1.3e-7 vs 1.3e-7 at K = 2048,
 // identical with all nine terms), so no precision is traded; what IS different: the result is not bitwise the fmaf chain
-// of conv_mfma.hip (cd_set_conv_arith(0) selects that kernel), and an infinite input gives NaN instead of +-inf.
+// of conv_mfma.hip (cd_set_conv_arith(0) selects that kernel), and an infinite input -- or one in the top binade, |x| >= 2^127 * (2 - 2^-8),
+// whose hi term rounds to infinity -- gives NaN instead of +-inf (tests/test_split_arith_cpu.py restates the arithmetic in numpy).
 //
 // Mapping (implicit GEMM, no im2col buffer): M = the 32 output pixels of one tile row, N = 32 output columns,
 // K = 16 = 8 input channels x 2 consecutive filter taps (taps flattened ky * KS + kx).
