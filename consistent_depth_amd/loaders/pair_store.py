@@ -43,6 +43,8 @@ class _BatchDesc(ctypes.Structure):     # cd_pair_batch
 class PairStore:
     def __init__(self, color, flows, masks, intrinsics, extrinsics, pair_frames, frame_ids=None, device=None):
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.type == "cuda" and dev.index is None:      # "cuda" -> "cuda:<current>": tensors report an indexed device
+            dev = torch.device("cuda", torch.cuda.current_device())
         f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)  # noqa: E731
         self.device = dev
         self.color = f32(color)
@@ -153,9 +155,11 @@ class PairStore:
         images, metadata = self.new_batch_buffers(ids.numel())
         return self.gather_into(ids, images, metadata)
 
-    @classmethod
-    def from_directory(cls, path: str, meta_file: str, device=None):
-        """Load the reference's on-disk layout (see loaders/video_dataset.py) into HBM."""
+    @staticmethod
+    def load_directory(path: str, meta_file: str) -> dict:
+        """The reference's on-disk layout (see loaders/video_dataset.py) as host arrays in store order: the constructor's
+        arguments.  Pairs are the unique ordered pairs of flow_list.json (video_dataset.py:108-125), sorted; colour rows
+        are the frames those pairs use."""
         from . import video_dataset as vd
         ds = vd.VideoDataset(path, meta_file)
         pairs = sorted(tuple(p) for p in ds.flow_indices)
@@ -166,8 +170,13 @@ class PairStore:
                           for i, j in pairs])
         masks = np.stack([np.stack([vd.load_mask(ds.mask_fmt.format(a, b)).numpy() for a, b in ((i, j), (j, i))])
                           for i, j in pairs])
-        return cls(color, flows, masks, ds.intrinsics.numpy()[frames], ds.extrinsics.numpy()[frames],
-                   [[row[i], row[j]] for i, j in pairs], frame_ids=frames, device=device)
+        return dict(color=color, flows=flows, masks=masks, intrinsics=ds.intrinsics.numpy()[frames],
+                    extrinsics=ds.extrinsics.numpy()[frames], pair_frames=[[row[i], row[j]] for i, j in pairs], frame_ids=frames)
+
+    @classmethod
+    def from_directory(cls, path: str, meta_file: str, device=None):
+        """Load the reference's on-disk layout into HBM."""
+        return cls(device=device, **cls.load_directory(path, meta_file))
 
     @classmethod
     def synthetic(cls, n_frames: int, H: int, W: int, flow_ops=("hierarchical2",), seed: int = 0, device=None,

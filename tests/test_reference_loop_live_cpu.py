@@ -1,0 +1,143 @@
+"""CPU, build container only: the reference's OWN loop and readers, run live (oracle/ref_loop.py imports
+/root/reference unmodified with the stub set of SURVEY.md section 8c), against
+
+  * oracle/cpu_loop.py -- the restated loop the GPU tests use as their run-level reference: every artefact of a 2-epoch
+    fp64 run (per-step losses, eval/loss_e*.json, eval/depth_*.raw, the checkpoint, depth/frame_*.raw) must agree, which
+    pins the loop semantics (validation in train mode updating the running statistics, first-sighting rule, short last
+    batch, total_iters in pairs, checkpoint contents) to the reference's code rather than to a reading of it;
+  * the committed golden tests/golden/loop_6f_64x48.npz (what the GPU box compares the product loop with);
+  * this repo's readers: loaders/video_dataset.py::VideoDataset and PairStore.load_directory item by item, bitwise.
+Skipped wherever /root/reference does not exist (the GPU box)."""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+from oracle import ref_loop
+
+pytestmark = pytest.mark.skipif(not ref_loop.available(), reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def clip(tmp_path_factory):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_dataset as msd
+    from oracle import gen_golden_loop as G
+    root = tmp_path_factory.mktemp("loop")
+    path = str(root / "clip")
+    range_dir, pairs = msd.write_dataset(path, **G.CLIP)
+    return {"root": root, "path": path, "range_dir": range_dir, "pairs": pairs, "meta": os.path.join(range_dir, "metadata_scaled.npz")}
+
+
+@pytest.fixture(scope="module")
+def ref_run(clip):
+    """The reference loop in fp64: 2 epochs, BS4, from the seeded initial weights (~50 s)."""
+    import torch
+    from oracle import gen_golden_loop as G
+    init = G.initial_state()
+    run = ref_loop.run(clip["path"], clip["range_dir"], list(range(G.CLIP["n_frames"])), init, str(clip["root"] / "work"),
+                       dtype=torch.float64, num_epochs=G.EPOCHS, seed=G.LOOP_SEED)
+    run["init"] = init
+    return run
+
+
+def test_restated_loop_reproduces_the_reference_loop(clip, ref_run):
+    import torch
+    from consistent_depth_amd.loaders.video_dataset import VideoDataset, load_color
+    from consistent_depth_amd.utils import image_io
+    from oracle import cpu_loop, gen_golden_loop as G
+    ds = VideoDataset(clip["path"], clip["meta"])
+    idx = {tuple(p): i for i, p in enumerate(ds.flow_indices)}
+    steps = ref_run["steps"]
+    assert len(steps) == G.EPOCHS * 3 and [len(p) for _, p, _ in steps[:3]] == [4, 4, 2]     # 10 pairs: the last batch is short
+
+    def order(epoch):
+        return [[idx[tuple(p)] for p in prs] for e, prs, _ in steps if e == epoch]
+    out = str(clip["root"] / "restated")
+    lp = cpu_loop.CpuLoop(ds, ref_run["init"], out, dtype=torch.float64)
+    lp.fine_tune(G.EPOCHS, order)
+    lp.save_depth(out, list(range(G.CLIP["n_frames"])), lambda f: load_color(ds.color_fmt.format(f)))
+    worst = 0.0
+    for (e, p, l), (e2, p2, l2) in zip(steps, lp.step_losses):
+        assert e == e2 and p == p2
+        worst = max(worst, abs(l - l2) / abs(l))
+    assert worst < 1e-10, worst
+    ref_files = [f for f in sorted(glob.glob(os.path.join(ref_run["out_dir"], "eval", "*")) + glob.glob(os.path.join(ref_run["out_dir"], "depth", "*")))
+                 if not f.endswith(".png")]
+    assert len(ref_files) == 3 * (1 + 6) + 6          # 3 sweeps x (json + 6 first sightings) + 6 exported frames
+    for fn in ref_files:
+        other = os.path.join(out, os.path.relpath(fn, ref_run["out_dir"]))
+        assert os.path.exists(other), other            # same names: the iteration count in the suffix is part of the contract
+        if fn.endswith(".json"):
+            with open(fn) as f:
+                a = json.load(f)
+            with open(other) as f:
+                b = json.load(f)
+            assert list(a) == list(b) and list(a["reprojection"]) == list(b["reprojection"])    # same pairs in the same (sweep) order
+            for k in ("reprojection", "disparity"):
+                for pair in a[k]:
+                    assert abs(a[k][pair] - b[k][pair]) <= 1e-10 * abs(a[k][pair])
+                assert abs(a["mean"][k] - b["mean"][k]) <= 1e-6 * abs(a["mean"][k])      # the json's mean is an fp32 tensor mean
+        else:
+            x, y = image_io.load_raw_float32_image(fn), image_io.load_raw_float32_image(other)
+            assert np.abs(x - y).sum() <= 1e-7 * np.abs(x).sum(), fn
+    sa = torch.load(os.path.join(ref_run["out_dir"], "checkpoints", "0002.pth"))
+    sb = torch.load(os.path.join(out, "checkpoints", "0002.pth"))
+    assert list(sa) == list(sb)
+    for k in sa:
+        if sa[k].is_floating_point():
+            d = (sa[k].double() - sb[k].double()).abs().sum().item()
+            assert d <= 1e-6 * max(sa[k].double().abs().sum().item(), 1e-3), k
+        else:
+            assert torch.equal(sa[k], sb[k]), k        # num_batches_tracked: training AND validation batches both count
+
+
+def test_committed_golden_is_what_the_reference_produces(ref_run):
+    from oracle import gen_golden_loop as G
+    z = np.load(os.path.join(GOLDEN, "loop_6f_64x48.npz"))
+    live = G.collect(ref_run)
+    assert [json.loads(s) for s in z["order_pairs"]] == [p for _, p, _ in ref_run["steps"]]
+    for k, v in live.items():
+        g = z["ref64_" + k]
+        if v.dtype.kind in "fc":
+            np.testing.assert_allclose(g, v, rtol=1e-9, atol=1e-12, err_msg=k)
+        else:
+            assert (g == v).all(), k
+
+
+def test_readers_match_the_reference_video_dataset(clip):
+    """loaders/video_dataset.py:108-125 (pair list), :131-207 (items), :20-77 (file decoding): the compat VideoDataset and
+    the arrays the HBM-resident PairStore uploads, against the reference's VideoDataset on the same directory."""
+    import torch
+    from consistent_depth_amd.loaders.pair_store import PairStore
+    from consistent_depth_amd.loaders.video_dataset import VideoDataset
+    with ref_loop.reference_modules(torch.float32):
+        from loaders.video_dataset import VideoDataset as RefDataset
+        rds = RefDataset(clip["path"], clip["meta"])
+        ref_items = [rds[i] for i in range(len(rds))]
+        ref_pairs = [list(p) for p in rds.flow_indices]
+    ds = VideoDataset(clip["path"], clip["meta"])
+    assert [list(p) for p in ds.flow_indices] == ref_pairs      # same pairs in the same order (= the validation sweep's order)
+    arrays = PairStore.load_directory(clip["path"], clip["meta"])
+    store_pairs = [[arrays["frame_ids"][a], arrays["frame_ids"][b]] for a, b in arrays["pair_frames"]]
+    assert sorted(map(tuple, store_pairs)) == sorted(map(tuple, ref_pairs))
+    for k, (rim, rmeta) in enumerate(ref_items):
+        im, meta = ds[k]
+        assert torch.equal(im, rim)
+        assert torch.equal(meta["intrinsics"], rmeta["intrinsics"]) and torch.equal(meta["extrinsics"], rmeta["extrinsics"])
+        rg, g = rmeta["geometry_consistency"], meta["geometry_consistency"]
+        assert g["indices"].tolist() == rg["indices"].tolist()
+        s = store_pairs.index(rg["indices"].tolist())
+        fa, fb = arrays["pair_frames"][s]
+        assert np.array_equal(arrays["color"][fa], rim[0].numpy()) and np.array_equal(arrays["color"][fb], rim[1].numpy())
+        assert np.array_equal(arrays["intrinsics"][[fa, fb]], rmeta["intrinsics"].numpy())
+        assert np.array_equal(arrays["extrinsics"][[fa, fb]], rmeta["extrinsics"].numpy())
+        for d in range(2):
+            assert torch.equal(g["flows"][d], rg["flows"][d]) and torch.equal(g["masks"][d], rg["masks"][d])
+            assert np.array_equal(arrays["flows"][s, d], rg["flows"][d].numpy())
+            assert np.array_equal(arrays["masks"][s, d], rg["masks"][d].numpy())
