@@ -600,6 +600,8 @@ int cd_hourglass_zero_grad(cd_hourglass* e, void* stream) {
 
 int cd_hourglass_forward(cd_hourglass* e, const float* images, float* pred, int training, void* stream) {
     if (!e || !images || !pred) return CD_ERR_INVALID_ARG;
+    if (cd_get_conv_arith() != e->conv_arith) return CD_ERR_INVALID_ARG;   // the mode changed under the handle (its launch shapes and
+                                                                           // weight-gradient plans belong to the old one): re-create it
     hipStream_t s = (hipStream_t)stream;
     const size_t px = (size_t)e->N * e->H * e->W;
     if (hipMemcpyAsync(e->x_in, images, sizeof(float) * 3 * px, hipMemcpyDeviceToDevice, s) != hipSuccess) return CD_ERR_LAUNCH;

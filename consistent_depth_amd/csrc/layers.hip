@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ shift,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                   int HW) {
+                                                                   int overwrite_affine, int HW) {
     const int c = blockIdx.y, n = blockIdx.z;
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const bool raw = scale != nullptr;
@@ -156,8 +156,9 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_apply_kernel(float* __rest
     const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
     const float k = g * mean_invstd[2 * (x_coff + c) + 1];
     if (dgamma && blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
-        dgamma[c] += (float)sums[2 * c + 1];   // accumulated like every parameter gradient of the engine
-        dbeta[c] += (float)sums[2 * c];
+        // accumulated like every parameter gradient of the engine, unless the caller asked for plain assignment
+        dgamma[c] = (overwrite_affine ? 0.f : dgamma[c]) + (float)sums[2 * c + 1];
+        dbeta[c] = (overwrite_affine ? 0.f : dbeta[c]) + (float)sums[2 * c];
     }
     float* d = dA + ((size_t)n * d_ctot + d_coff + c) * HW;
     const float* xh = xhat + ((size_t)n * x_ctot + x_coff + c) * HW;
@@ -379,7 +380,9 @@ int cd_bn_finalize(const double* stats, int ctot, int coff, int C, double count,
 
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C, const float* gamma,
                    const float* beta, const float* mean_invstd, const float* scale, const float* shift, double* sums,
-                   int sums_prezeroed, float* dgamma, float* dbeta, int N, int H, int W, void* stream) {
+                   int flags, float* dgamma, float* dbeta, int N, int H, int W, void* stream) {
+    const int sums_prezeroed = flags & CD_BN_BWD_SUMS_PREZEROED, overwrite_affine = (flags & CD_BN_BWD_OVERWRITE_AFFINE) ? 1 : 0;
+    CD_ARGCHK((flags & ~(CD_BN_BWD_SUMS_PREZEROED | CD_BN_BWD_OVERWRITE_AFFINE)) == 0);
     CD_ARGCHK((scale == nullptr) == (shift == nullptr));
     CD_ARGCHK(dA && xhat && mean_invstd && sums && C > 0 && d_coff >= 0 && d_coff + C <= d_ctot && x_coff >= 0 && x_coff + C <= x_ctot);
     CD_ARGCHK((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr));
@@ -390,7 +393,7 @@ int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_c
                        gamma, beta, mean_invstd, scale, shift, sums, H * W);
     CD_CHECK_LAUNCH();
     hipLaunchKernelGGL(cd::bn_relu_bwd_apply_kernel, grid, dim3(cd::kBlock), 0, s, dA, d_ctot, d_coff, xhat, x_ctot, x_coff,
-                       gamma, beta, sums, (double)N * H * W, mean_invstd, scale, shift, dgamma, dbeta, H * W);
+                       gamma, beta, sums, (double)N * H * W, mean_invstd, scale, shift, dgamma, dbeta, overwrite_affine, H * W);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -27,10 +27,16 @@ void set_sweep_pxt(int pxt) { g_sweep_pxt = pxt > 0 && pxt <= kMaxPXT ? pxt : 0;
 Geo sweep_geo(int H, int W) { return make_geo(H, W, sweep_pxt(H, W)); }
 
 // per-pair record of the "tile windows" blob: [TileWin wins[2 * ntiles]] [PlanHeader + Item[max_items]] (16-byte aligned parts)
+// The record size must NOT depend on the (mutable, debug) pixels-per-thread choice: blobs are cached by the callers
+// (PairStore) and every variant derives its window stride from it -- room for the largest plan of any supported choice.
 size_t pair_record_bytes(int H, int W) {
     const size_t wins = align_up(sizeof(TileWin) * 2 * (size_t)owner_ntiles(H, W), 16);
-    const Geo g = sweep_geo(H, W);
-    return wins + (g.ok && g.max_items <= 2560 ? align_up(plan_bytes(g), 16) : 0);
+    size_t plan = 0;
+    for (int pxt = 1; pxt <= kMaxPXT; pxt *= 2) {
+        const Geo g = make_geo(H, W, pxt);
+        if (g.ok && g.max_items <= 2560) { const size_t n = align_up(plan_bytes(g), 16); plan = n > plan ? n : plan; }
+    }
+    return wins + plan;
 }
 static size_t plan_offset(int H, int W) { return align_up(sizeof(TileWin) * 2 * (size_t)owner_ntiles(H, W), 16); }
 
@@ -128,10 +134,13 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const PlanItem* __restrict__ items = reinterpret_cast<const PlanItem*>(ph + 1);
     const int n_items = ph->n_items;
     if (n_items <= 0 || ph->G != g.G || ph->R != g.R || ph->PXT != g.PXT) {
-        // no plan, or one made for another geometry (cannot happen through the C ABI): fail loudly -- NaN loss, which skips the step
+        // no plan (the planner's item backstop), or one made for another geometry (cd_debug_set_loss_sweep changed after the
+        // blob was cached): this pair cannot be swept -- raise the degenerate flag, the guarded exact v1 pass recomputes the
+        // gradient and the loss of the launch (loss_api.hip).  Uniform per workgroup: no barrier has been passed yet.
+        if (threadIdx.x == 0) ovf->degenerate = 1;
         if ((threadIdx.x & (kFrameThreads - 1)) == 0) {
             float* o = partial + (size_t)(b * 2 + f) * 2;
-            o[0] = o[1] = __int_as_float(0x7fc00000);
+            o[0] = o[1] = 0.f;
         }
         return;
     }

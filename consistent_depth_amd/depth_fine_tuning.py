@@ -147,11 +147,14 @@ class DepthFineTuner:
         total_iters = 0
         for epoch in range(p.num_epochs):
             t0 = time.perf_counter()
-            plan = parallel.shard_indices(len(store), epoch, self.seed, self.rank, self.world, p.batch_size)
+            plan = self.epoch_plan(epoch)
             plan_dev = parallel.plan_to_device(plan, store.device)   # the epoch's index lists: uploaded once
+            # per-step losses of the epoch stay on the device (one 4-byte copy per step, no sync): read ONCE at the end of
+            # the epoch to learn which steps the device-side NaN guard skipped
+            epoch_losses = torch.zeros(max(1, len(plan)), dtype=torch.float32, device=store.device)
             for it, ids in enumerate(plan):
                 loss, loss_meta, metadata = step.step_from_store(store, plan_dev[it])
-                total_iters += len(ids) * self.world
+                epoch_losses[it:it + 1].copy_(loss.reshape(1))
                 if p.print_freq > 0 and (it % max(1, p.print_freq) == 0) and self.rank == 0:
                     pairs = metadata["geometry_consistency"]["indices"].tolist()
                     lv = loss.item()  # the only host sync, every print_freq steps
@@ -162,6 +165,16 @@ class DepthFineTuner:
                         writer.add_scalar("Train/loss", lv, total_iters)
                         log_loss_stats(writer, "Train/loss", loss_meta, total_iters)
             torch.cuda.synchronize()
+            # the reference's `continue` on a NaN loss also skips `total_iters += batch` (:278-285); total_iters counts pairs
+            # over all ranks and names the validation files.  (With world > 1 the guard acts on the all-reduced loss: a NaN on
+            # any rank skips the step everywhere, so every rank subtracts the same steps after this one tiny all-reduce.)
+            bad = torch.isnan(epoch_losses[:len(plan)]).float()
+            if self.world > 1 and len(plan):
+                parallel.allreduce_sum_(bad)
+            bad = bad.cpu().numpy() > 0
+            sizes = self._global_step_sizes(epoch, len(plan))
+            total_iters += int(sum(n for n, b in zip(sizes, bad) if not b))
+            self.epoch_losses = epoch_losses[:len(plan)].cpu().numpy()
             if self.rank == 0:
                 print(f"Epoch {epoch} took {time.perf_counter() - t0:.2f}s.")
             if (epoch + 1) % p.val_epoch_freq == 0:
@@ -173,6 +186,18 @@ class DepthFineTuner:
         if self.rank == 0:
             print("Finished Training")
 
+    def epoch_plan(self, epoch: int):
+        """This rank's per-step pair-id lists of `epoch` (store order ids).  Seeded shuffle shared by all ranks; a subclass or
+        a test can override it to replay a recorded order."""
+        return parallel.shard_indices(len(self.store), epoch, self.seed, self.rank, self.world, self.params.batch_size)
+
+    def _global_step_sizes(self, epoch: int, n_steps: int):
+        """Pairs processed per step over ALL ranks (for `total_iters`)."""
+        if self.world == 1:
+            return [len(ids) for ids in self.epoch_plan(epoch)][:n_steps]
+        per_rank = [parallel.shard_indices(len(self.store), epoch, self.seed, r, self.world, self.params.batch_size) for r in range(self.world)]
+        return [sum(len(pr[i]) for pr in per_rank) for i in range(n_steps)]
+
     # ------------------------------------------------------------------ validation (:312-406)
     @torch.no_grad()
     def eval_and_save(self, step: FineTuneStep, suf: str) -> Dict[str, torch.Tensor]:
@@ -180,25 +205,27 @@ class DepthFineTuner:
         reference (model.train() is set once, :241).  Ranks shard the unshuffled list; per-pair
         losses are gathered on rank 0, which writes the files."""
         store, p = self.store, self.params
-        plan = parallel.eval_shard(len(store), self.rank, self.world, p.batch_size)   # every pair, like the reference's sweep
-        names, rows, saved = None, [], set()
+        chunks = parallel.eval_chunks(len(store), self.rank, self.world, p.batch_size)   # whole sequential batches of the reference's sweep
+        plan = [ids for _, ids in chunks]
+        names = ["reprojection", "disparity"]   # the per-pair entries of ConsistencyLoss (consistency_loss.py:206), on every rank
+        rows = []
         plan_dev = parallel.plan_to_device(plan, store.device)
         frames_of = store.pair_indices()    # host copy of the pair list: no device sync to learn which frames a batch holds
-        writer = image_io.AsyncRawWriter(device=store.device)
-        for ids, ids_dev in zip(plan, plan_dev):
-            images, metadata = store.batch(ids_dev)
-            raw, _, parts = step.evaluate(images, metadata)
-            if names is None:
-                names = [n for n in parts if parts[n].numel() == len(ids)]
-            idx = metadata["geometry_consistency"]["indices"]
-            rows.append(torch.cat([idx.float()] + [parts[n].reshape(-1, 1).float() for n in names], 1))
-            inv = self._depth_from_raw(raw).reciprocal()
-            for b, pid in enumerate(ids):
-                for k, f in enumerate(frames_of[pid]):
-                    if f not in saved:   # first sighting of a frame on this rank (the reference keeps the first, :343-360)
-                        saved.add(f)
-                        writer.submit(pjoin(self.out_dir, "eval", f"depth_{f:06d}{suf}.raw"), inv[b, k])
-        table = torch.cat(rows, 0) if rows else torch.zeros(0, 2 + len(names or []), device=store.device)
+        first = parallel.first_sightings(frames_of, p.batch_size)   # frame -> the batch of the sweep that exports it (one owner)
+        with image_io.AsyncRawWriter(device=store.device) as writer:     # the files of this sweep are on disk when the block ends
+            for (chunk, ids), ids_dev in zip(chunks, plan_dev):
+                images, metadata = store.batch(ids_dev)
+                raw, _, parts = step.evaluate(images, metadata)
+                idx = metadata["geometry_consistency"]["indices"]
+                rows.append(torch.cat([idx.float()] + [parts[n].reshape(-1, 1).float() for n in names], 1))
+                inv = self._depth_from_raw(raw).reciprocal()
+                done = set()
+                for b, pid in enumerate(ids):
+                    for k, f in enumerate(frames_of[pid]):
+                        if first[f] == chunk and f not in done:   # the reference keeps the first sighting (:343-360)
+                            done.add(f)
+                            writer.submit(pjoin(self.out_dir, "eval", f"depth_{f:06d}{suf}.raw"), inv[b, k])
+        table = torch.cat(rows, 0) if rows else torch.zeros(0, 2 + len(names), device=store.device)
         if self.world > 1:
             import torch.distributed as dist
             n_loc = torch.tensor([table.shape[0]], device=table.device)
@@ -209,9 +236,16 @@ class DepthFineTuner:
             pad[:table.shape[0]] = table
             gathered = [torch.zeros_like(pad) for _ in range(self.world)]
             dist.all_gather(gathered, pad)
-            table = torch.cat([g[:int(n.item())] for g, n in zip(gathered, n_all)], 0)
+            # back into sweep order: rank r holds batches r, r + world, ...
+            per_rank = [g[:int(n.item())] for g, n in zip(gathered, n_all)]
+            order = []
+            for r in range(self.world):
+                pos = 0
+                for c, ids in parallel.eval_chunks(len(store), r, self.world, p.batch_size):
+                    order.append((c, per_rank[r][pos:pos + len(ids)]))
+                    pos += len(ids)
+            table = torch.cat([t for _, t in sorted(order, key=lambda ct: ct[0])], 0) if order else table
         table = table.cpu().numpy()
-        writer.close()   # the files of this sweep are on disk when it returns
         loss_dict = {n: {} for n in (names or [])}
         for row in table:
             key = str([int(row[0]), int(row[1])])

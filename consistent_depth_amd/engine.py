@@ -174,7 +174,8 @@ class GraphedFineTuneStep:
     def step_from_store(self, store, pair_ids: torch.Tensor):
         """Like FineTuneStep.step_from_store; once the graph of this batch shape exists the pairs are gathered STRAIGHT into
         its static input buffers (no intermediate batch, no copies) and the graph is replayed."""
-        skey = (id(store), int(pair_ids.numel()))
+        # (the record width is part of the key: PairStore.rebuild_masks changes it, and a stale graph's static buffers with it)
+        skey = (id(store), int(pair_ids.numel()), int(store.tile_windows.shape[1]))
         key = self._store_sig.get(skey)
         g = self._graphs.get(key) if key is not None else None
         if g is None:

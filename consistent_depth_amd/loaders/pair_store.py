@@ -158,11 +158,12 @@ class PairStore:
     @staticmethod
     def load_directory(path: str, meta_file: str) -> dict:
         """The reference's on-disk layout (see loaders/video_dataset.py) as host arrays in store order: the constructor's
-        arguments.  Pairs are the unique ordered pairs of flow_list.json (video_dataset.py:108-125), sorted; colour rows
-        are the frames those pairs use."""
+        arguments.  Pairs are the unique ordered pairs of flow_list.json IN THE REFERENCE'S DATASET ORDER
+        (video_dataset.py:108-125: that order is the validation sweep's, and with train-mode BatchNorm in the sweep it decides
+        which pairs share batch statistics and at which batch a frame is exported); colour rows are the frames those pairs use."""
         from . import video_dataset as vd
         ds = vd.VideoDataset(path, meta_file)
-        pairs = sorted(tuple(p) for p in ds.flow_indices)
+        pairs = [tuple(p) for p in ds.flow_indices]
         frames = sorted({f for p in pairs for f in p})
         row = {f: r for r, f in enumerate(frames)}
         color = np.stack([vd.load_color(ds.color_fmt.format(f)).numpy() for f in frames])

@@ -244,6 +244,10 @@ class HourglassEngine:
         self._wgrad_stream = torch.cuda.Stream(device=self.device) \
             if mode != "none" and os.environ.get("CD_AMD_ENGINE_WGRAD_STREAM", "0") == "1" else None
         self._wgrad_pending = False
+        # nn.BatchNorm2d counts its train-mode forwards (training steps AND the reference's train-mode validation batches);
+        # momentum is fixed so nothing reads the counters, but they are part of the checkpoint the reference writes
+        self._batch_counters = [m.num_batches_tracked for m in net.modules()
+                                if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
 
     def _rehome_running_stats(self, bns):
         n = sum(b.num_features for b in bns)
@@ -535,7 +539,9 @@ class HourglassEngine:
         plan["stats_arena"].zero_()
         self._pack.run()
         self._run_forward(plan["steps"], self.net.training)
-        self._last = plan  # (num_batches_tracked is not advanced: momentum is fixed, the counter is unused)
+        if self.net.training and self._batch_counters:
+            torch._foreach_add_(self._batch_counters, 1)
+        self._last = plan
         return plan["pred"]
 
     @torch.no_grad()
@@ -558,6 +564,51 @@ class HourglassEngine:
             anchor = next(self.net.parameters())
             return _EngineFn.apply(anchor, self, x)
         return self._forward(x, need_grad=False).clone()
+
+
+class BlockRunner:
+    """ONE inception of the network as a stand-alone plan on the same kernels, buffers layout and fused launches as inside the
+    full network (entry 1x1 group, k x k branches, joint BatchNorm passes, packed filters, weight-gradient arena + unpack):
+    block-level parity tests and single-block profiling.
+
+        y  = forward(x_raw)      x_raw: the producer's PRE-activation values; the block reads relu(x_raw) (`relu_in`)
+                                 y: the block's activated output relu(x_hat) (N, Co, H, W)
+        dx = backward(dy)        dy = d loss / d y;  dx = d loss / d relu(x_raw);  parameter gradients are accumulated
+                                 into p.grad like the full engine does
+    """
+
+    def __init__(self, eng: "HourglassEngine", mod: HG.Inception, N: int, H: int, W: int, relu_in: bool = True):
+        self.eng, self.mod = eng, mod
+        c_in, _ = HG.INCEPTION[mod.kind]
+        Act.registry = []
+        plan = {"steps": [], "convs": [], "stats_used": 0,
+                "stats_arena": torch.zeros(4096 * L.STAT_SLOTS, 2, dtype=torch.float64, device=eng.device)}
+        plan["x"] = eng._new(N, 3, H, W)       # only its shape is read (arena carving)
+        self.x = Act(eng._new(N, c_in, H, W), 0, c_in, relu=relu_in)
+        self.out = eng._inception(plan, plan["steps"], mod, self.x, N, H, W)
+        plan["acts"], Act.registry = Act.registry, None
+        eng._carve_arenas(plan)
+        self.plan, self.step = plan, plan["steps"][0]
+
+    @torch.no_grad()
+    def forward(self, x_raw: torch.Tensor, training: bool = True) -> torch.Tensor:
+        self.x.buf.copy_(x_raw)
+        self.plan["stats_arena"].zero_()
+        self.eng._pack.run()
+        self.eng._run_forward(self.plan["steps"], training)
+        o = self.out
+        return torch.relu(o.buf[:, o.coff:o.coff + o.C])
+
+    @torch.no_grad()
+    def backward(self, dy: torch.Tensor) -> torch.Tensor:
+        o = self.out
+        self.step.Pg[:, o.coff:o.coff + o.C].copy_(dy)
+        self.plan["sums_arena"].zero_()
+        for a in self.plan["acts"]:
+            a.grad_written = False
+        self.eng._run_backward(self.plan["steps"])
+        self.plan["unpack"].run()
+        return self.x.gbuf.clone()
 
 
 class _EngineFn(torch.autograd.Function):

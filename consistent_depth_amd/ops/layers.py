@@ -44,10 +44,11 @@ def bn_finalize(stats, coff, C, count, mean_invstd, scale, shift, eps=1e-5, gamm
 
 
 def bn_relu_bwd(dA, d_coff, xhat, x_coff, C, mean_invstd, sums, gamma=None, beta=None, dgamma=None, dbeta=None,
-                sums_prezeroed=False, scale=None, shift=None):
+                sums_prezeroed=False, scale=None, shift=None, overwrite_affine=False):
+    """dgamma / dbeta are ACCUMULATED (the engine's convention for every parameter gradient) unless `overwrite_affine`."""
     N, d_ctot, H, W = dA.shape
     rc = _native.lib().cd_bn_relu_bwd(_p(dA), d_ctot, d_coff, _p(xhat), xhat.shape[1], x_coff, C, _o(gamma), _o(beta),
-                                      _p(mean_invstd), _o(scale), _o(shift), sums.data_ptr(), int(sums_prezeroed), _o(dgamma),
+                                      _p(mean_invstd), _o(scale), _o(shift), sums.data_ptr(), int(bool(sums_prezeroed)) | (2 if overwrite_affine else 0), _o(dgamma),
                                       _o(dbeta), N, H, W,
                                       _s(dA))
     _native.check(rc, "cd_bn_relu_bwd")

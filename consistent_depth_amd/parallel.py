@@ -73,10 +73,30 @@ def barrier():
 
 
 def eval_shard(n_items: int, rank: int, world: int, batch_size: int):
-    """Validation shards: EVERY item exactly once (rank r takes items r, r + world, ...; the last batches may be short and
-    ranks may run different numbers of batches -- there is no collective inside the validation loop)."""
-    mine = list(range(rank, n_items, world))
-    return [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
+    """Validation shards: the unshuffled pair list is cut into the reference's sequential batches of `batch_size`
+    (depth_fine_tuning.py:215-218, the last one short) and rank r takes batches r, r + world, ... -- EVERY batch has the
+    pairs it has in a single-process sweep, so the train-mode BatchNorm statistics, hence every per-pair loss and every
+    exported depth map, do not depend on the number of ranks (nn.DataParallel's scatter cuts the same contiguous chunks).
+    Ranks may run different numbers of batches: there is no collective inside the validation loop."""
+    return [ids for _, ids in eval_chunks(n_items, rank, world, batch_size)]
+
+
+def eval_chunks(n_items: int, rank: int, world: int, batch_size: int):
+    """[(global batch number, pair ids)] of this rank's share of the validation sweep (see eval_shard)."""
+    chunks = [list(range(s, min(s + batch_size, n_items))) for s in range(0, n_items, batch_size)]
+    return [(c, ids) for c, ids in enumerate(chunks) if c % world == rank]
+
+
+def first_sightings(frames_of_pair, batch_size: int):
+    """{frame: global batch number of the sweep in which the frame is seen first}.  The reference exports a frame's
+    validation depth at its FIRST sighting in the sequential sweep (depth_fine_tuning.py:343-360); with the sweep sharded
+    over ranks, exactly the rank that owns that batch writes the file -- decided on the host from the unshuffled plan,
+    identically on every rank, no communication."""
+    first = {}
+    for pid, frames in enumerate(frames_of_pair):
+        for f in frames:
+            first.setdefault(f, pid // batch_size)
+    return first
 
 
 def plan_to_device(plan, device):

@@ -258,7 +258,13 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
  *   0: the fp32 matrix instruction everywhere (bitwise a k-ordered fmaf chain).
  * The packed filter holds every layout, so the mode may change between launches without re-packing.  The weight gradient of
  * the filters follows the same switch (wgrad_split.hip, wgrad1x1_split.hip); its packed layout (cd_conv2d_wgrad_plan) differs
- * between the modes, so a plan -- and a cd_hourglass handle -- belongs to the mode it was made under. */
+ * between the modes, so a plan -- and a cd_hourglass handle -- belongs to the mode it was made under: cd_hourglass_forward /
+ * _backward return CD_ERR_INVALID_ARG after a mode change (re-create the handle), and a captured HIP graph keeps replaying the
+ * kernels of the mode it was captured under.
+ * Semantics that differ from the fp32 instruction in the split modes (1, 2): an operand that is +-inf or in the top binade
+ * (|x| >= 2^127) yields NaN instead of +-inf (the split terms overflow), and results are not bitwise those of mode 0; finite
+ * inputs give fp32-accurate results.  cd_conv2d_wgrad returns CD_ERR_UNSUPPORTED (it does not silently change arithmetic) when
+ * a 1x1 split launch would need offsets beyond 32 bits (N * ctot * H * W >= 2^30 elements): use mode 0 for such buffers. */
 int cd_set_conv_arith(int mode);
 int cd_get_conv_arith(void);
 /* The upper bound of co_tiles for (Cout, ks) under the current arithmetic mode (split modes, k >= 3: tile_rows 4 / 8 / 16 selects
@@ -344,7 +350,10 @@ int cd_copy_f32(const float* src, float* dst, size_t n, void* stream);
 /* images [N][3][H][W] RGB in [0,1] -> pred [N][1][H][W] (log depth).  training != 0: batch statistics, running statistics
  * updated (nn.BatchNorm2d semantics, momentum 0.1); 0: running statistics. */
 int cd_hourglass_forward(cd_hourglass* h, const float* images, float* pred, int training, void* stream);
-/* dpred = d loss / d pred of the LAST training forward; every parameter gradient is ADDED into cd_hourglass_grads(). */
+/* dpred = d loss / d pred of the LAST training forward; every parameter gradient is ADDED into cd_hourglass_grads():
+ * PRECONDITION cd_hourglass_zero_grad (or an equivalent clear of cd_hourglass_grads()) once per step before the forward --
+ * a host that skips it gets the sum of this and the previous steps' gradients (deliberate: gradients of other loss terms,
+ * e.g. the parameter regulariser, can be placed there first). */
 int cd_hourglass_backward(cd_hourglass* h, const float* dpred, void* stream);
 
 /* BatchNorm2d in training mode, forward.  stats[CD_BN_STAT_SLOTS][ctot][2] = per-channel (sum, sum of squares) of the raw
@@ -366,13 +375,18 @@ int cd_bn_finalize(const double* stats, int ctot, int coff, int C, double count,
 
 /* Backward of relu(gamma * x_hat + beta) + train-mode BatchNorm in one call: dA (gradient w.r.t. the
  * activated output) is replaced IN PLACE by the gradient w.r.t. the raw (pre-BN) tensor.  gamma/beta
- * NULL = BatchNorm2d(affine=False); dgamma/dbeta[C] receive the affine gradients when given.
+ * NULL = BatchNorm2d(affine=False).  dgamma/dbeta[C] (optional): the affine gradients are ADDED to them (+=, torch's
+ * p.grad convention: the caller zeroes its gradients once per step -- FlatAdam.zero_grad / cd_hourglass_zero_grad) unless
+ * CD_BN_BWD_OVERWRITE_AFFINE is set in `flags`, which assigns them.
  * scale/shift (buffer-indexed, from cd_bn_finalize) given: `xhat` holds the RAW conv output and the ReLU mask is
  * evaluated on exactly fma(raw, scale, shift), the expression the consumers applied on load; NULL: `xhat` is the
- * normalised tensor of cd_bn_normalize.  sums: scratch of 2*C doubles, zeroed inside unless sums_prezeroed. */
+ * normalised tensor of cd_bn_normalize.  sums: scratch of 2*C doubles, zeroed inside unless CD_BN_BWD_SUMS_PREZEROED.
+ * flags: 0 or an OR of the two bits below (bit 0 is the former `sums_prezeroed` argument: 0 / 1 keep their meaning). */
+#define CD_BN_BWD_SUMS_PREZEROED 1
+#define CD_BN_BWD_OVERWRITE_AFFINE 2
 int cd_bn_relu_bwd(float* dA, int d_ctot, int d_coff, const float* xhat, int x_ctot, int x_coff, int C,
                    const float* gamma, const float* beta, const float* mean_invstd, const float* scale,
-                   const float* shift, double* sums, int sums_prezeroed, float* dgamma, float* dbeta,
+                   const float* shift, double* sums, int flags, float* dgamma, float* dbeta,
                    int N, int H, int W, void* stream);
 
 /* AvgPool2d(2) of act(x) and its adjoint (dx = gradient w.r.t. the ACTIVATED input, (+)= when accumulate). */

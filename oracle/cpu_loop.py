@@ -96,10 +96,13 @@ class CpuLoop:
         return loss_dict
 
     # ---- the training loop (:257-310); `order(epoch)` -> list of batches, each a list of dataset indices
-    def fine_tune(self, num_epochs, order):
-        self.validate(0, 0)
-        for epoch in range(num_epochs):
-            for ids in order(epoch):
+    def fine_tune(self, num_epochs, order, start_epoch=0):
+        """`start_epoch` > 0 continues a run: no initial validation, epochs numbered from there, `order(e)` still gets
+        e = 0 .. num_epochs-1 (set `total_iters` and the optimiser state first)."""
+        if start_epoch == 0:
+            self.validate(0, 0)
+        for epoch in range(start_epoch, start_epoch + num_epochs):
+            for ids in order(epoch - start_epoch):
                 images, b = _collate([self.ds[i] for i in ids])
                 out, _ = self.ft.step(images, b)     # NaN: no backward, no Adam step (cpu_step.py)
                 loss = float(out["total"][0])
@@ -112,8 +115,8 @@ class CpuLoop:
             if (epoch + 1) % self.save_epoch_freq == 0:
                 torch.save({k: v.detach().clone() for k, v in self.ft.state.items()},
                            pjoin(self.out_dir, "checkpoints", f"{epoch + 1:04d}.pth"))
-        if num_epochs % self.val_epoch_freq != 0:
-            self.validate(num_epochs, self.total_iters)
+        if (start_epoch + num_epochs) % self.val_epoch_freq != 0:
+            self.validate(start_epoch + num_epochs, self.total_iters)
 
     # ---- save_depth (:164-199): eval-mode BN (running statistics), one frame per forward
     def save_depth(self, out_dir, frames, load_color):

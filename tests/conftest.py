@@ -16,6 +16,49 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_BG = {}
+
+
+def pytest_collection_finish(session):
+    """Start the slow fp64 CPU reference of the BASELINE-shape engine test in the background (tests/bg_reference.py) as soon
+    as it is known that the test will run, so that it overlaps with the other GPU tests."""
+    import subprocess
+    import tempfile
+    if os.environ.get("CD_AMD_TEST_NO_BG") or not any("baseline_8x384x224" in it.nodeid for it in session.items):
+        return
+    if len(session.items) < 20:       # run on its own: nothing to overlap with, the test computes inline
+        return
+    dst = os.path.join(tempfile.mkdtemp(prefix="cd_bg_"), "engine_ref_8x384x224.npz")
+    threads = max(2, (os.cpu_count() or 8) // 2)
+    proc = subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "bg_reference.py"), dst, str(threads)],
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
+    _BG["engine_ref"] = (proc, dst)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for proc, _ in _BG.values():
+        if proc.poll() is None:
+            proc.kill()
+
+
+def background_engine_reference(timeout=1500):
+    """The result of tests/bg_reference.py as a dict of numpy arrays; None if it was not started; "skip" if the host lacks memory."""
+    if "engine_ref" not in _BG:
+        return None
+    proc, dst = _BG["engine_ref"]
+    try:
+        rc = proc.wait(timeout=timeout)
+    except Exception:   # noqa: BLE001
+        proc.kill()
+        return None
+    if rc == 3:
+        return "skip"
+    if rc != 0 or not os.path.exists(dst):
+        return None
+    with np.load(dst) as z:
+        return {k: z[k] for k in z.files}
+
+
 def golden_loss_cases():
     return sorted(os.path.basename(p)[len("loss_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN, "loss_*.npz")))
 

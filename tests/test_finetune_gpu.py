@@ -134,9 +134,11 @@ def test_run_level_parity_after_burn_in():
     from consistent_depth_amd.monodepth.mannequin_challenge_model import MannequinChallengeModel
     from oracle import cpu_step, hourglass_ref
     import os
-    # (the CPU reference dominates: ~7.5 minutes of host time at the full BS4 batch -- run with CD_AMD_TEST_FULL_BASELINE=1,
-    #  result committed as profiles/parity_run_level_r02.txt; by default 2 pairs and 3 steps at the same resolution)
-    BURN, T, PB, PH, PW = (24, 4, 4, 384, 224) if os.environ.get("CD_AMD_TEST_FULL_BASELINE") else (24, 3, 2, 384, 224)
+    # Default: the BASELINE batch itself -- 4 pairs = 8 images of 384x224, 3 steps.  The CPU reference dominates (~70 s of host
+    # time per fp64 step at this size), so the reference's own fp32 run (the yardstick printed next to the result) is only
+    # computed with CD_AMD_TEST_FULL_BASELINE=1 (4 steps + yardstick: ~8 minutes; result committed under profiles/).
+    full = bool(os.environ.get("CD_AMD_TEST_FULL_BASELINE"))
+    BURN, T, PB, PH, PW = (24, 4, 4, 384, 224) if full else (24, 3, 4, 384, 224)
     params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0, learning_rate=4e-4,
                                 optimizer="Adam")
     model = MannequinChallengeModel(backend="hip", seed=0)
@@ -185,7 +187,10 @@ def test_run_level_parity_after_burn_in():
         return np.array(losses), torch.exp(pred).reshape(PB, 2, PH, PW).double().numpy()
 
     loss64, depth64 = cpu(torch.float64)
-    loss32, depth32 = cpu(torch.float32)
+    if full:
+        loss32, depth32 = cpu(torch.float32)
+    else:      # measured once at this size (profiles/parity_run_level_r02.txt): reference fp32 vs its fp64 self
+        loss32, depth32 = loss64 * (1 + 5.6e-7), depth64 * (1 + 2.6e-5)
     d_gpu, d_ref = _rel_l1(depth_gpu, depth64), _rel_l1(depth32, depth64)
     l_gpu, l_ref = _rel_l1(np.array(losses_gpu), loss64), _rel_l1(loss32, loss64)
     per_step = np.abs(np.array(losses_gpu) - loss64) / np.abs(loss64)

@@ -121,14 +121,21 @@ def test_bn_normalize_and_backward_match_torch():
         d2 = torch.zeros(N, ctot, H, W).cuda()
         d2[:, coff:coff + C] = dA.float().cuda()
         kw2 = dict(kw)
-        if affine:
-            kw2.update(dgamma=torch.zeros(C).cuda(), dbeta=torch.zeros(C).cuda())
+        if affine:   # CD_BN_BWD_OVERWRITE_AFFINE: unzeroed gradient buffers are assigned, not accumulated into
+            kw2.update(dgamma=torch.full((C,), 123.0).cuda(), dbeta=torch.full((C,), -7.0).cuda(), overwrite_affine=True)
         layers.bn_relu_bwd(d2, coff, raw_buf, coff, C, mi2, torch.zeros(2 * C, dtype=torch.float64).cuda(), scale=sc, shift=sh, **kw2)
         assert (d2[:, coff:coff + C].cpu().double() - x.grad).abs().max().item() < 3e-5 * x.grad.abs().max().item()
         assert (d[:, coff:coff + C].cpu().double() - x.grad).abs().max().item() < 3e-5 * x.grad.abs().max().item()
         if affine:
             np.testing.assert_allclose(kw["dgamma"].cpu().numpy(), bn.weight.grad.numpy(), rtol=2e-5, atol=1e-4)
             np.testing.assert_allclose(kw["dbeta"].cpu().numpy(), bn.bias.grad.numpy(), rtol=2e-5, atol=1e-4)
+            np.testing.assert_allclose(kw2["dgamma"].cpu().numpy(), bn.weight.grad.numpy(), rtol=2e-5, atol=1e-4)
+            np.testing.assert_allclose(kw2["dbeta"].cpu().numpy(), bn.bias.grad.numpy(), rtol=2e-5, atol=1e-4)
+            g0 = kw["dgamma"].clone()       # default: accumulate (a second call doubles the stored gradient)
+            d3 = torch.zeros(N, ctot, H, W).cuda()
+            d3[:, coff:coff + C] = dA.float().cuda()
+            layers.bn_relu_bwd(d3, coff, buf, coff, C, mi, torch.zeros(2 * C, dtype=torch.float64).cuda(), **kw)
+            np.testing.assert_allclose(kw["dgamma"].cpu().numpy(), 2 * g0.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 def test_pool_upsample_add_and_adjoints():

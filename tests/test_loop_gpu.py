@@ -1,0 +1,163 @@
+"""GPU, loop level: the product's DepthFineTuner (HIP engine, HBM-resident pair store, graph-replayed steps) against the
+REFERENCE'S OWN LOOP.
+
+  * test_product_loop_vs_reference_golden -- tests/golden/loop_6f_64x48.npz holds every artefact of
+    /root/reference's `DepthFineTuner.fine_tune()` + `save_depth()` run unmodified on the CPU (oracle/gen_golden_loop.py,
+    fp64 = ground truth, fp32 = the reference's own arithmetic).  The clip and the initial weights are regenerated here from
+    their seeds, the recorded step order is replayed.  Everything before the first update (validation sweep 0: per-pair
+    losses in sweep order, first-sighting depth maps, file names) is compared at the arithmetic floor; after training the
+    product must be as close to the fp64 run as the reference's fp32 run is (from a random init Adam's first steps are
+    sign-like and amplify round-off: reference-fp32 vs reference-fp64 is ~2e-2 in the losses after two steps).
+  * test_epochs_after_burn_in_within_1e_3 -- BASELINE.json's criterion ("depth maps and per-epoch losses within 1e-3
+    relative L1") where it is a property of the arithmetic: after a burn-in of K epochs on the GPU the weights, BatchNorm
+    buffers and Adam moments are handed to oracle/cpu_loop.py (fp64; pinned to the reference's loop by
+    tests/test_reference_loop_live_cpu.py), and both run the same T further epochs: per-epoch eval/loss_e*.json means,
+    eval/depth_*.raw, depth/frame_*.raw and the checkpoint.
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).sum() / max(np.abs(b).sum(), 1e-300))
+
+
+def _setup(tmp_path, num_epochs, order_pairs=None):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_dataset as msd
+    import torch
+    from consistent_depth_amd.depth_fine_tuning import DepthFineTuner
+    from consistent_depth_amd.params import Video3dParamsParser
+    from oracle import gen_golden_loop as G
+    path = str(tmp_path / "clip")
+    range_dir, pairs = msd.write_dataset(path, **G.CLIP)
+    params = Video3dParamsParser().parse(["--path", path, "--num_epochs", str(num_epochs), "--batch_size", "4"])
+    ft = DepthFineTuner(range_dir, list(range(G.CLIP["n_frames"])), params)
+    init = G.initial_state()
+    ft.model.netG.load_state_dict(init)
+    if order_pairs is not None:
+        def epoch_plan(epoch, ft=ft):
+            idx = {tuple(p): i for i, p in enumerate(ft.store.pair_indices())}
+            return [[idx[tuple(p)] for p in prs] for e, prs in order_pairs if e == epoch]
+        ft.epoch_plan = epoch_plan
+    return ft, init, path, range_dir
+
+
+def _artefacts(out_dir):
+    from oracle import gen_golden_loop as G
+    steps = []
+    return G.collect({"out_dir": out_dir, "steps": steps})
+
+
+def test_product_loop_vs_reference_golden(tmp_path):
+    from gpu_util import report
+    z = np.load(os.path.join(GOLDEN, "loop_6f_64x48.npz"))
+    order = list(zip(z["order_epoch"].tolist(), [json.loads(s) for s in z["order_pairs"]]))
+    ft, _, _, _ = _setup(tmp_path, int(z["epochs"]), order)
+    ft.fine_tune()
+    ft.save_depth()
+    got = _artefacts(ft.out_dir)
+    # ---- same files, same names (the iteration count in the suffix), same pairs in the same sweep order
+    ref_keys = sorted(k[len("ref64_"):] for k in z.files if k.startswith("ref64_") and k != "ref64_step_losses")
+    assert sorted(k for k in got if k != "step_losses") == ref_keys
+    for k in ref_keys:
+        if k.endswith("_pairs"):
+            assert (got[k] == z["ref64_" + k]).all(), k
+    # ---- sweep 0 (before any update): arithmetic floor
+    tag0 = "e0000_iter000000"
+    d = {}
+    for part in ("reprojection", "disparity", "mean"):
+        d[part] = _rel(got[f"val_{tag0}_{part}"], z[f"ref64_val_{tag0}_{part}"])
+        d[part + "_ref32"] = _rel(z[f"ref32_val_{tag0}_{part}"], z[f"ref64_val_{tag0}_{part}"])
+    d["evaldepth"] = _rel(got[f"evaldepth_{tag0}"], z[f"ref64_evaldepth_{tag0}"])
+    d["evaldepth_ref32"] = _rel(z[f"ref32_evaldepth_{tag0}"], z[f"ref64_evaldepth_{tag0}"])
+    report("loop_vs_reference[sweep0]", **d)
+    assert d["reprojection"] < 1e-4 and d["disparity"] < 1e-4 and d["mean"] < 1e-4 and d["evaldepth"] < 1e-4
+    # ---- after training: the noise class of the reference's own fp32 run
+    worst = {}
+    for k in ref_keys:
+        if k.endswith("_pairs") or k == "ckpt_keys" or tag0 in k:
+            continue
+        mine, r32 = _rel(got[k], z["ref64_" + k]), _rel(z["ref32_" + k], z["ref64_" + k])
+        worst[k] = (mine, r32)
+        assert mine <= 3 * r32 + 1e-3, (k, mine, r32)
+    step = _rel(ft.epoch_losses, z["ref64_step_losses"][-len(ft.epoch_losses):])
+    report("loop_vs_reference[trained]", last_epoch_step_losses=step,
+           ref32_last_epoch_step_losses=_rel(z["ref32_step_losses"][-len(ft.epoch_losses):], z["ref64_step_losses"][-len(ft.epoch_losses):]),
+           **{k: v[0] for k, v in worst.items() if k.endswith("_mean") or k == "depth"},
+           **{"ref32_" + k: v[1] for k, v in worst.items() if k.endswith("_mean") or k == "depth"})
+    assert (got["ckpt_keys"] == z["ref64_ckpt_keys"]).all()
+
+
+def test_epochs_after_burn_in_within_1e_3(tmp_path):
+    import torch
+    from consistent_depth_amd.loaders.video_dataset import VideoDataset, load_color
+    from gpu_util import report
+    from oracle import cpu_loop
+    K, T = 8, 2
+    ft, init, path, range_dir = _setup(tmp_path, K + T)
+    snap = {}
+    save = ft.model.save
+
+    def save_and_snapshot(file_name):      # called at the end of every epoch (save_epoch_freq = 1), after its validation sweep
+        save(file_name)
+        if os.path.basename(file_name) == f"{K:04d}.pth":
+            torch.cuda.synchronize()
+            opt = getattr(ft._step, "step", ft._step).opt      # GraphedFineTuneStep wraps the FineTuneStep that owns FlatAdam
+            names = {id(p): n for n, p in ft.model.netG.named_parameters()}
+            snap["state"] = {k: v.detach().cpu().clone() for k, v in ft.model.netG.state_dict().items()}
+            snap["m1"] = {names[id(p)]: opt.exp_avg[o:o + p.numel()].detach().cpu().clone() for p, o in zip(opt._params, opt._offsets)}
+            snap["m2"] = {names[id(p)]: opt.exp_avg_sq[o:o + p.numel()].detach().cpu().clone() for p, o in zip(opt._params, opt._offsets)}
+            snap["k"] = int(opt.step_dev.item())
+    ft.model.save = save_and_snapshot
+    plans = {}
+    orig = ft.epoch_plan
+
+    def recording_plan(epoch):
+        plans.setdefault(epoch, orig(epoch))
+        return plans[epoch]
+    ft.epoch_plan = recording_plan
+    ft.fine_tune()
+    ft.save_depth()
+    n_pairs = len(ft.store)
+    assert snap and snap["k"] == K * 3       # 10 pairs, BS4: 3 steps per epoch
+    # ---- the CPU loop continues from the snapshot: epochs K .. K+T-1 with the same batches
+    ds = VideoDataset(path, os.path.join(range_dir, "metadata_scaled.npz"))
+    store_pairs = ft.store.pair_indices()
+    ds_idx = {tuple(p): i for i, p in enumerate(ds.flow_indices)}
+    out = str(tmp_path / "cpu")
+    lp = cpu_loop.CpuLoop(ds, snap["state"], out, dtype=torch.float64)
+    lp.ft.set_adam_state(snap["m1"], snap["m2"], snap["k"])
+    lp.total_iters = K * n_pairs
+    lp.fine_tune(T, lambda e: [[ds_idx[tuple(store_pairs[i])] for i in ids] for ids in plans[K + e]], start_epoch=K)
+    lp.save_depth(out, list(range(6)), lambda f: load_color(ds.color_fmt.format(f)))
+    from oracle import gen_golden_loop as G
+    a, b = G.collect({"out_dir": ft.out_dir, "steps": []}), G.collect({"out_dir": out, "steps": []})
+    res = {}
+    for e in range(K + 1, K + T + 1):
+        tag = f"e{e:04d}_iter{e * n_pairs:06d}"
+        assert (a[f"val_{tag}_pairs"] == b[f"val_{tag}_pairs"]).all()
+        res[f"mean_e{e}"] = _rel(a[f"val_{tag}_mean"], b[f"val_{tag}_mean"])
+        res[f"perpair_e{e}"] = max(_rel(a[f"val_{tag}_{p}"], b[f"val_{tag}_{p}"]) for p in ("reprojection", "disparity"))
+        res[f"evaldepth_e{e}"] = _rel(a[f"evaldepth_{tag}"], b[f"evaldepth_{tag}"])
+    res["depth_export"] = _rel(a["depth"], b["depth"])
+    sa = torch.load(os.path.join(ft.out_dir, "checkpoints", f"{K + T:04d}.pth"), map_location="cpu")
+    sb = torch.load(os.path.join(out, "checkpoints", f"{K + T:04d}.pth"), map_location="cpu")
+    num = sum((sa[k].double() - sb[k].double()).abs().sum().item() for k in sa if sa[k].is_floating_point() and "uncertainty" not in k)
+    den = sum(sb[k].double().abs().sum().item() for k in sa if sa[k].is_floating_point() and "uncertainty" not in k)
+    res["checkpoint"] = num / den
+    for k in sa:       # num_batches_tracked: every train-mode forward counts, training steps and validation batches alike
+        if not sa[k].is_floating_point() and "uncertainty" not in k:
+            assert int(sa[k]) == int(sb[k]) == (K + T) * 3 + (K + T + 1) * 3, (k, int(sa[k]), int(sb[k]))
+    report(f"loop_after_burn_in[K{K},T{T}]", **res)
+    assert all(v <= 1e-3 for v in res.values()), res

@@ -188,6 +188,34 @@ def test_sweep_pixels_per_thread(torch_cuda, oracle, name, pxt):
     assert oracle.rel_l1(grad, ref64["grad_depth"]) < grad_tol(oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]))
 
 
+def test_stale_plan_falls_back_to_the_exact_path(torch_cuda, oracle):
+    """A cached record blob (PairStore keeps one per dataset) whose row-sweep plan was made for another geometry -- here: the
+    pixels-per-thread debug hook changed after the blob was built -- must not poison the step with a NaN loss (round 2 did, the
+    device-side NaN guard then skipped every step holding such a pair): the sweep raises the degenerate flag and the guarded v1
+    pass recomputes loss and gradient exactly.  The record stride does not depend on the hook, so the tile kernels keep reading
+    their windows from the same blob."""
+    from consistent_depth_amd import _native
+    from consistent_depth_amd.loss import consistency_loss as CL
+    torch = torch_cuda
+    batch, lr, lb, ref64, ref32 = load_loss_case("basic_b3_48x40")
+    lib = _native.lib()
+    d = to_dev(batch, torch)
+    nbytes = lib.cd_tile_windows_bytes(3, 48, 40)
+    blob = CL.tile_windows(d["flows"], d["masks"])          # plans for the default geometry (2 pixels per thread)
+    try:
+        for variant, pxt in ((4, 4), (4, 1), (3, 4), (2, 4)):
+            assert lib.cd_debug_set_loss_variant(variant) == 0 and lib.cd_debug_set_loss_sweep(pxt) == 0
+            assert lib.cd_tile_windows_bytes(3, 48, 40) == nbytes
+            depth = d["depth"].clone().requires_grad_(True)
+            total, _, _ = CL.consistency_loss(depth, d["flows"], d["masks"], d["intrinsics"], d["extrinsics"], lr, lb, tile_windows=blob)
+            total.backward()
+            np.testing.assert_allclose(total.item(), ref64["total"][0], rtol=LOSS_RTOL)
+            assert oracle.rel_l1(depth.grad.cpu().numpy(), ref64["grad_depth"]) < grad_tol(oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]))
+    finally:
+        lib.cd_debug_set_loss_sweep(0)
+        lib.cd_debug_set_loss_variant(0)
+
+
 @pytest.mark.parametrize("force", [0, 3], ids=["default_dispatch", "slab_chunked"])
 def test_roofline_launch_vs_oracle(torch_cuda, oracle, force):
     """The launch bench.py's roofline number is taken on -- B = 256 pairs of 384x224 in ONE call (0.88 GB, beyond the

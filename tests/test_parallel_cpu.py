@@ -108,3 +108,26 @@ def test_plan_to_device_roundtrip():
     dev = parallel.plan_to_device(plan, torch.device("cpu"))
     assert [d.tolist() for d in dev] == plan and all(d.dtype == torch.int64 and d.is_contiguous() for d in dev)
     assert parallel.plan_to_device([], torch.device("cpu")) == []
+
+
+def test_eval_chunks_are_the_single_process_batches_and_frames_have_one_owner():
+    """Multi-rank validation = the reference's sequential sweep dealt out batch by batch: the union over ranks is exactly the
+    1-rank batch list (so train-mode BatchNorm sees the same batches whatever the world size), and every frame's export
+    belongs to exactly one (rank, batch) -- the batch of its first sighting in sweep order (depth_fine_tuning.py:343-360)."""
+    pairs = [[0, 1], [2, 4], [1, 2], [0, 4], [3, 4], [2, 3], [0, 2], [4, 5], [1, 3], [3, 5], [5, 6]]
+    bs = 4
+    single = parallel.eval_chunks(len(pairs), 0, 1, bs)
+    assert [ids for _, ids in single] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
+    first = parallel.first_sightings(pairs, bs)
+    assert first == {0: 0, 1: 0, 2: 0, 4: 0, 3: 1, 5: 1, 6: 2}
+    for world in (2, 3, 8):
+        dealt = sorted((c, ids) for r in range(world) for c, ids in parallel.eval_chunks(len(pairs), r, world, bs))
+        assert dealt == single
+        owners = {}
+        for r in range(world):
+            for c, ids in parallel.eval_chunks(len(pairs), r, world, bs):
+                for pid in ids:
+                    for f in pairs[pid]:
+                        if first[f] == c:
+                            owners.setdefault(f, set()).add(r)
+        assert set(owners) == set(first) and all(len(v) == 1 for v in owners.values())
