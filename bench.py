@@ -17,7 +17,11 @@ Extra objects in the JSON line:
                     well beyond the 256 MB Infinity Cache), HIP events on the launch stream
   roofline_in_step  the same kernel as launched inside the timed steps (B = 4: 13.8 MB, cache
                     resident and latency bound -- reported for honesty, not an HBM measurement)
-  cpu_baseline      the reference step restated on the host CPU (oracle/cpu_step.py), rank 0, N=1
+  roofline_conv     the convolutions of the step against the matrix-core roof: algorithmic conv flops of the step (forward +
+                    input gradient + weight gradient = 3 x forward) / the measured step time
+  cpu_baseline      the reference step restated on the host CPU (oracle/cpu_step.py), rank 0, N=1 (mc only)
+
+    python bench.py --model midas2 --height 384 --width 384 --batch-size 8      BASELINE configs[4] shape on one GPU
 """
 import argparse
 import ctypes
@@ -39,6 +43,56 @@ LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x
 # = 3.381 MB per pair = 0.98x the algorithmic 3.441 MB (every input read once, every gradient byte written once).  Only
 # valid for the size and the kernel it was measured on; null otherwise.
 LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = (2 * 346.8037e6 + 172.040e6) / 256
+# Matrix-core roofs (TFLOP/s, dense; /opt/skills/guides/MI355X_MICROARCH.md).  The split-operand convolutions compute one fp32
+# result from SIX bf16 products, so the roof they run against, in fp32-equivalent flops, is the dense BF16 peak / 6.
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_FP32_PEAK_TFLOPS = 157.3
+
+
+def mc_conv_macs(H, W):
+    """Forward multiply-accumulates of all convolutions of the mc hourglass for ONE HxW image (SURVEY.md section 8d:
+    52.83 GMAC at 384x224), walked over the architecture tables of consistent_depth_amd/monodepth/hourglass.py."""
+    from consistent_depth_amd.monodepth import hourglass as HG
+    total = H * W * 3 * 49 * 128 + H * W * 64 * 9          # stem 7x7 3->128, head 3x3 64->1 (the unused confidence head is not run)
+
+    def inception(kind, h, w):
+        cin, cfg = HG.INCEPTION[kind]
+        n = h * w * cin * cfg[0][0]
+        for k, mid, out in cfg[1:]:
+            n += h * w * (cin * mid + mid * k * k * out)
+        return n
+
+    def channels(level, h, w):
+        n = 0
+        for side in HG.CHANNELS[level]:
+            hh, ww = h, w
+            for it in side:
+                if it == "pool":
+                    hh, ww = hh // 2, ww // 2
+                elif it == "up":
+                    hh, ww = hh * 2, ww * 2
+                elif isinstance(it, tuple):
+                    n += channels(it[1], hh, ww)
+                else:
+                    n += inception(it, hh, ww)
+        return n
+    return total + channels(4, H, W)
+
+
+def module_conv_macs(net, x):
+    """Forward MACs of every nn.Conv2d of `net` for the input `x` (hooks; used for the MiDaS-shaped backbone)."""
+    macs, hooks = [0], []
+
+    def hook(m, inp, out):
+        macs[0] += out.numel() * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            hooks.append(m.register_forward_hook(hook))
+    with torch.no_grad():
+        net(x)
+    for h in hooks:
+        h.remove()
+    return macs[0]
 
 
 _T0 = time.perf_counter()
@@ -66,6 +120,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="mc", choices=["mc", "midas2"],
+                    help="depth model plugin: mc = Mannequin-Challenge hourglass (BASELINE configs[2]/[3], the headline); midas2 = the "
+                         "MiDaS-v2-shaped ResNeXt-101 backbone (configs[4]: use --height 384 --width 384 --batch-size 8)")
     ap.add_argument("--batch-size", type=int, default=4)
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=224)
@@ -173,15 +230,20 @@ def main():
     lib = _native.lib()
     B, H, W = args.batch_size, args.height, args.width
 
-    params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0,
-                                learning_rate=4e-4, optimizer="Adam")
+    model_cls = get_depth_model(args.model)
+    # the reference takes learning rate and lambda_view_baseline from the model adapter (params.py:110-119)
+    params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=model_cls.lambda_view_baseline, lambda_parameter=0,
+                                learning_rate=model_cls.learning_rate, optimizer="Adam")
     # the reference sets cudnn.benchmark=True (depth_fine_tuning.py:220-221); MIOpen's exhaustive
     # find over the 157 conv shapes x {fwd, dgrad, wgrad} takes many minutes, so the default here
     # is MIOpen's immediate (heuristic) mode
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
-    log(f"rank {rank}/{world} building mc model, conv backend {args.backend}")
-    model = get_depth_model("mc")(backend=args.backend, seed=0)
+    log(f"rank {rank}/{world} building {args.model} model, conv backend {args.backend}")
+    model = model_cls(backend=args.backend, seed=0)
     model.train()
+    if args.model == "midas2" and args.graph:
+        log("midas2: the step runs eager (its layers are autograd functions over torch's allocator, not a static plan)")
+        args.graph = 0
     eager_step = FineTuneStep(model, params, world=world)
     step = GraphedFineTuneStep(eager_step, eager_steps=max(1, min(2, args.warmup - 1))) if args.graph else eager_step
     # the clip, resident in HBM on every rank (replicated like the reference's dataset on every DataLoader worker)
@@ -243,6 +305,10 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     pairs_per_s = B * world * args.steps / elapsed
+    if args.model == "mc":
+        macs_per_image = mc_conv_macs(H, W)
+    else:
+        macs_per_image = module_conv_macs(model.model, torch.zeros(1, 3, H, W, device=device))
     log(f"timed region: {args.steps} steps in {elapsed:.3f}s -> {pairs_per_s:.2f} pairs/s "
         f"(host enqueue {1e3 * t_enqueue / args.steps:.1f} ms/step)")
 
@@ -251,10 +317,17 @@ def main():
         "value": round(pairs_per_s, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"mc hourglass (random init, seed 0) test-time fine-tuning steps over a synthetic {args.frames}-frame "
-                               f"{H}x{W} clip ({len(store)} pairs, hierarchical sampling, HBM-resident pair store, shared-seed shards), "
-                               f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{(3 if world > 1 else 2) if args.backend == 'hip' else 1}]: "
-                               + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"),
+        "config": {"workload": (f"mc hourglass (random init, seed 0) test-time fine-tuning steps over a synthetic {args.frames}-frame "
+                                f"{H}x{W} clip ({len(store)} pairs, hierarchical sampling, HBM-resident pair store, shared-seed shards; full "
+                                f"batches only -- the epoch's short last batch is left out so that ONE graph signature is timed), "
+                                f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{(3 if world > 1 else 2) if args.backend == 'hip' else 1}]: "
+                                + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"))
+                               if args.model == "mc" else
+                               (f"midas2 plugin: MiDaS-v2-shaped backbone (ResNeXt-101 32x8d + feature-fusion decoder restated, random init, "
+                                f"seed 0), fine-tuning steps over a synthetic {args.frames}-frame {H}x{W} clip ({len(store)} pairs), BS{B} pairs/GPU, "
+                                f"lambda_r 1.0 lambda_b 1e-4, Adam lr 1e-4, eager steps (BASELINE configs[4] shape on {world} GPU(s); convolutions: "
+                                + ("hand-written HIP kernels through ops/conv_layer.py)" if args.backend == "hip" else "PyTorch-ROCm/MIOpen)")),
+                   "model": args.model,
                    "conv_backend": args.backend,
                    "conv_arith": ("fp32 results from split operands: every fp32 input = 3 exact bf16 terms, 6 cross products on the BF16 matrix "
                                   "cores, fp32 accumulate (all convolutions but the RGB stem, fwd/dgrad/wgrad; as close to fp64 as the fp32 MFMA: profiles/mfma_split_exp_r02.txt, "
@@ -267,6 +340,19 @@ def main():
 
     if rank == 0:
         px = H * W
+        flops_per_pair = 2 * 3 * 2 * macs_per_image            # 2 images x (forward + input gradient + weight gradient) x 2 flop/MAC
+        ach_tf = flops_per_pair * pairs_per_s / world / 1e12  # per GPU
+        split = args.backend == "hip" and args.model == "mc" and lib.cd_get_conv_arith() >= 1
+        peak_tf = MFMA_BF16_PEAK_TFLOPS / 6 if split else MFMA_FP32_PEAK_TFLOPS
+        out["roofline_conv"] = {
+            "bound": "mfma", "achieved": round(ach_tf, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4),
+            "flops_per_pair": flops_per_pair, "per": "GPU, whole step time (BatchNorm, loss, Adam and launch gaps included: a lower bound "
+                                                     "of what the convolution kernels reach while they run)",
+            "peak_note": ("fp32-equivalent roof of the split-operand kernels = dense BF16 peak 2500 / 6 products" if split else
+                          "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)"),
+            "frac_of_fp32_mfma_peak": round(ach_tf / MFMA_FP32_PEAK_TFLOPS, 4),
+            "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r03.txt (SQ_INSTS_VALU_MFMA_MOPS / SQ_BUSY_CU_CYCLES per kernel family), "
+                                "profiles/conv_roofline_r03.txt (per launch)"}
         in_step_ms = float(np.mean(ms_step)) if len(ms_step) else None
         if in_step_ms:
             ach = LOSS_BYTES_PER_PAIR_PX * px * B / (in_step_ms * 1e-3) / 1e9
@@ -293,7 +379,7 @@ def main():
                                "traffic_source": "profiles/rocprofv3_loss_sweep_b256_r02.txt (PMC, separate passes; FETCH_SIZE x2 + WRITE_SIZE)",
                                "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "mc":
             # the reference step restated on the host (oracle/cpu_step.py), in a bounded subprocess so a slow
             # host can never stall the benchmark: 1 warm-up + --cpu-steps timed steps of the same BS4 workload
             log("cpu baseline")

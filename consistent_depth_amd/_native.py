@@ -11,7 +11,8 @@ import os
 import torch  # imported first on purpose: libcd_amd.so then binds to torch's libamdhip64
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_PKG, "libcd_amd.so")
+# CD_AMD_LIB: load another build of the SAME library (A/B measurements of kernel variants, tools/exp/build_variants.sh); not a fallback
+SO_PATH = os.environ.get("CD_AMD_LIB") or os.path.join(_PKG, "libcd_amd.so")
 ABI_VERSION = 5
 BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 

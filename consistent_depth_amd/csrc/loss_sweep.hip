@@ -99,13 +99,18 @@ struct SweepShape { Geo g; size_t stride, plan_off; };
 __device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-template <int MODE, bool REPROJ, int PXT>
+// SG: 0 = the geometry arrives at run time (kernel argument); 1 = the BASELINE shape 384 x 224 at 2 pixels per thread as
+// COMPILE-TIME constants: ring strides, rows per pass, image size fold into immediates (the kernel is short of scalar registers:
+// ~30 wave-uniform camera constants, 10 pointers and the plan records live next to them) -- same code, same results.
+constexpr int kStaticH = 384, kStaticW = 224, kStaticPXT = 2;
+
+template <int MODE, bool REPROJ, int PXT, int SG>
 __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const float* __restrict__ depth, const float* __restrict__ ff, const float* __restrict__ fb, const float* __restrict__ mf,
     const float* __restrict__ mb, const PairCam* __restrict__ cams, const char* __restrict__ blob, float* __restrict__ partial,
     float* __restrict__ grad, Overflow* ovf, unsigned* __restrict__ oidx, float* __restrict__ oval, const SweepShape sh) {
     extern __shared__ __align__(16) unsigned long long smem[];
-    const Geo g = sh.g;
+    const Geo g = SG == 1 ? make_geo(kStaticH, kStaticW, kStaticPXT) : sh.g;
     const int b = blockIdx.x, HW = g.H * g.W, ring = g.R * g.RW;
     const int f = uni((int)(threadIdx.x / kFrameThreads)), k = 1 - f;   // whole waves serve one frame: everything derived from f is scalar
     View v;
@@ -161,30 +166,30 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     //   rows [s_lo, s_hi) enter ring j in the slots just vacated (their depth was loaded during item t - 1),
     //   the source rows of item t are evaluated against rows staged BEFORE item t (Rec::nv).
     // Software pipeline: the depth rows entering at item t + 1 are loaded during item t (r.sv is free once item t's rows are
-    // staged); the flow / mask of item t + 1's sources go into a second register set when the pixel count allows it (DB),
-    // else they are loaded at the top of their own item, covered by its flush / stage work.
-    constexpr bool DB = PXT <= 2;
+    // staged).
+    // A row group is evaluated in one or two PASSES of RP rows (Geo::G, kGroupPasses); the flow / mask of a pass are loaded
+    // while the pass before it is evaluated, through two register sets that alternate explicitly (no copies): pass 0 reads set
+    // A (loaded during the previous item), pass 1 set B (loaded during pass 0).  The record of the next item is read one item
+    // ahead: loading it at the top of its own item exposed the scalar-load latency (0.344 -> 0.374 ms at 256 pairs).
+    Inputs<PXT> inA, inB;
+    const bool two = kGroupPasses > 1 && uni((int)(g.G > g.RP)) != 0;
     Rec me = items[0].f[f];
     int wk = items[0].f[k].w, wsk = items[0].f[k].ws, nvk = items[0].f[k].nv;
-    if (DB) load_inputs<PXT>(v, l, me.p, r.fx, r.fy, r.m);
+    load_inputs<PXT>(v, l, me.p, 0, inA);
     __syncthreads();
     for (int it = 0; it < n_items; ++it) {
-        if (!DB) load_inputs<PXT>(v, l, me.p, r.fx, r.fy, r.m);
         r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, me.w, me.ws, r.sv) || r.bad;
         const bool more = it + 1 < n_items;
         const int nt = more ? it + 1 : it;
         const Rec nx = items[nt].f[f];
         const int nwk = items[nt].f[k].w, nwsk = items[nt].f[k].ws, nnvk = items[nt].f[k].nv;
         load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
-        float nfx[DB ? PXT : 1], nfy[DB ? PXT : 1], nm[DB ? PXT : 1];
-        if (DB) load_inputs<PXT>(v, l, more ? nx.p : -1, nfx, nfy, nm);
+        if (two) load_inputs<PXT>(v, l, me.p, 1, inB);
         flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi, me.fl_slot);
-        process_rows<MODE, REPROJ, PXT>(v, env, r, l, me.p, me.w, me.ws, wk, wsk, nvk);
+        process_rows<MODE, REPROJ, PXT>(v, env, r, l, inA, me.p, 0, me.w, me.ws, wk, wsk, nvk);
+        load_inputs<PXT>(v, l, more ? nx.p : -1, 0, inA);
+        if (two) process_rows<MODE, REPROJ, PXT>(v, env, r, l, inB, me.p, 1, me.w, me.ws, wk, wsk, nvk);
         __syncthreads();
-        if (DB) {
-#pragma unroll
-            for (int i = 0; i < PXT; ++i) { r.fx[i] = nfx[i]; r.fy[i] = nfy[i]; r.m[i] = nm[i]; }
-        }
         me = nx; wk = nwk; wsk = nwsk; nvk = nnvk;
     }
     if (env.any(r.bad) && (threadIdx.x & (kWave - 1)) == 0) env.degenerate();
@@ -208,18 +213,29 @@ struct SweepArgs {
     SweepShape sh;
 };
 
-template <int MODE, bool REPROJ, int PXT>
-static int launch_sweep_inst(const SweepArgs& a, int B, size_t lds, hipStream_t s) {
+template <int MODE, bool REPROJ, int PXT, int SG>
+static int launch_sweep_sg(const SweepArgs& a, int B, size_t lds, hipStream_t s) {
     static bool configured = false;   // raise the dynamic-LDS limit of this instantiation once
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_sweep_kernel<MODE, REPROJ, PXT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_sweep_kernel<MODE, REPROJ, PXT, SG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess)
             return CD_ERR_LAUNCH;
         configured = true;
     }
-    hipLaunchKernelGGL((loss_sweep_kernel<MODE, REPROJ, PXT>), dim3(B), dim3(kThreads), lds, s, a.depth, a.ff, a.fb, a.mf, a.mb,
+    hipLaunchKernelGGL((loss_sweep_kernel<MODE, REPROJ, PXT, SG>), dim3(B), dim3(kThreads), lds, s, a.depth, a.ff, a.fb, a.mf, a.mb,
                        a.cams, a.blob, a.partial, a.grad, a.ovf, a.oidx, a.oval, a.sh);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+static bool g_sweep_static_geo = true;   // CD_AMD_SWEEP_STATIC_GEO=0: always the run-time-geometry instantiation (A/B measurements)
+
+template <int MODE, bool REPROJ, int PXT>
+static int launch_sweep_inst(const SweepArgs& a, int B, size_t lds, hipStream_t s) {
+    if (PXT == kStaticPXT && a.sh.g.H == kStaticH && a.sh.g.W == kStaticW && g_sweep_static_geo) {
+        const Geo c = make_geo(kStaticH, kStaticW, kStaticPXT);
+        if (memcmp(&c, &a.sh.g, sizeof(Geo)) == 0) return launch_sweep_sg<MODE, REPROJ, PXT, PXT == kStaticPXT ? 1 : 0>(a, B, lds, s);
+    }
+    return launch_sweep_sg<MODE, REPROJ, PXT, 0>(a, B, lds, s);
 }
 
 template <int MODE, bool REPROJ>
@@ -250,6 +266,12 @@ bool sweep_preferred(int B, int H, int W) {
 }
 
 // Enqueues: overflow header reset, [before_main] sweep [after_main], overflow apply.  Partial sums: partial[(b*2+k)*2 + {0,1}].
+static const bool g_sweep_env_read = [] {
+    const char* e = getenv("CD_AMD_SWEEP_STATIC_GEO");
+    if (e && e[0] == '0') g_sweep_static_geo = false;
+    return true;
+}();
+
 int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, const void* cams,
                  const void* blob, int mode, bool reproj, int B, int H, int W, float* partial, float* grad, void* ovf_mem,
                  int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t)) {

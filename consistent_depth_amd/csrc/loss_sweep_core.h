@@ -34,6 +34,14 @@ namespace sweep {
 constexpr int kThreads = 1024;       // one workgroup per pair = 16 waves = one CU at 4 waves per SIMD
 constexpr int kFrameThreads = 512;   // threads [0, 512) serve frame 0, [512, 1024) frame 1 (whole waves per frame)
 constexpr int kStagePasses = 2;      // at most SMAX = kStagePasses * RP rows enter / leave a ring per item
+// A row group (the source rows of one item) is evaluated in up to this many passes of RP rows.  Two passes halve the barriers
+// and the per-item scalar work, but the second inlined copy of the evaluation code pushes the kernel over its register budget:
+// measured at 256 pairs of 384x224 (profiles/loss_sweep_variants_r03.txt) 0.344 ms with 1 pass, 0.361 ms with 2 (0.374 with
+// the two passes sharing one non-unrolled copy).  The code path stays (CPU emulation tests run it: -DCD_SWEEP_GROUP_PASSES=2).
+#ifndef CD_SWEEP_GROUP_PASSES
+#define CD_SWEEP_GROUP_PASSES 1
+#endif
+constexpr int kGroupPasses = CD_SWEEP_GROUP_PASSES;
 constexpr int kMaxGroups = 1024;     // row groups per frame the planner handles
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kLdsReserve = 1024;    // reduction scratch etc.
@@ -41,11 +49,12 @@ constexpr int kMaxPXT = 4;
 
 struct Geo {
     int H, W;
-    int PXT;        // pixels per thread: columns cg + i * CG, i < PXT (adjacent lanes = adjacent columns: conflict-free LDS, coalesced HBM)
-    int CG;         // column groups = ceil(W / PXT)
+    int PXT;        // ADJACENT pixels per thread: columns PXT * cg + i, i < PXT -- one 4*PXT-byte load / store / LDS access per plane and
+                    // row (W is a multiple of PXT), and the pixels of a thread sit in consecutive registers (packed fp32 instructions)
+    int CG;         // column groups = W / PXT
     int RP;         // image rows per pass of the 512 threads of a frame = kFrameThreads / CG
-    int G;          // source rows per item and frame (<= RP)
-    int RW;         // ring row stride in elements: W + 1 pad column (weight-0 taps land there), rounded up to even
+    int G;          // source rows per item and frame (<= kGroupPasses * RP)
+    int RW;         // ring row stride in elements: W + pad column(s) (weight-0 taps land there), a multiple of PXT
     int R;          // ring rows per frame
     int NG;         // row groups per frame = ceil(H / G)
     int SMAX;       // max ring-window advance per item
@@ -57,18 +66,21 @@ CD_HD Geo make_geo(int H, int W, int pxt) {
     Geo g;
     memset(&g, 0, sizeof(g));
     g.H = H; g.W = W; g.PXT = pxt;
-    if (H < 2 || W < 2 || H > 16384 || pxt < 1 || pxt > kMaxPXT) return g;
-    g.CG = (W + pxt - 1) / pxt;
+    if (H < 2 || W < 2 || H > 16384 || (pxt != 1 && pxt != 2 && pxt != 4) || W % pxt != 0) return g;
+    g.CG = W / pxt;
     if (g.CG > kFrameThreads) return g;
     g.RP = kFrameThreads / g.CG;
     if (g.RP > 16) g.RP = 16;
-    g.RW = (W + 2) & ~1;
+    g.RW = (W + pxt) / pxt * pxt;                // >= W + 1
     int R = (kLdsBytes - kLdsReserve) / (2 * g.RW * 12);
     if (R > H + 2) R = H + 2;                 // rows 0 .. H (H = the pad row under the image) never need more
     if (R > 512) R = 512;
     g.R = R;
     if (R < 12) return g;
-    g.G = g.RP < (R - 8) / 3 ? g.RP : (R - 8) / 3;    // small images: fewer source rows per item than the threads could take
+    // rows per item: as many as two passes of the threads can take (half the barriers and per-item scalar work of one pass),
+    // as long as a third of the ring stays free for the taps' spread; small images: fewer
+    const int gmax = (R - 8) / 3;
+    g.G = kGroupPasses * g.RP < gmax ? kGroupPasses * g.RP : gmax;
     if (g.G < 1) return g;
     g.SMAX = kStagePasses * g.RP;
     if (g.SMAX > R - g.G - 8) g.SMAX = R - g.G - 8;   // leave room for the taps' spread
@@ -256,14 +268,16 @@ struct View {
     unsigned gbj, gbk;         // element index of the two gradient planes in the whole gradient tensor (overflow list)
 };
 
+// PXT floats / accumulator words of one thread and row: ONE aligned memory or LDS access
+template <int N> struct alignas(4 * N) VecF { float v[N]; };
+template <int N> struct alignas(8 * N > 16 ? 16 : 8 * N) VecU { unsigned long long v[N]; };
+
 template <int PXT> struct Lane {   // per-thread constants
-    int rr;                 // row inside a pass / group
+    int rr;                 // row inside a pass
     unsigned rrW;           // rr * W
-    bool on, gon;           // takes part in flush / stage passes (rr < RP); in source groups (rr < G)
-    unsigned x[PXT];        // its columns: cg + i * CG (adjacent lanes = adjacent columns: conflict-free LDS, coalesced HBM)
-    bool cok[PXT];          // x < W
-    static constexpr int NA = PXT <= 2 ? PXT : 1;   // hoisted only while the registers allow it
-    float a0[NA], a1[NA], a2[NA];      // M[0], M[3], M[6] * r0(x): the column part of a = M (r0, r1, -1)
+    bool on;                // takes part at all (rr < RP and its column group exists); whole waves are off at W = 224 (448 of 512 lanes)
+    unsigned x0;            // its columns: x0 + i, i < PXT
+    float a0[PXT], a1[PXT], a2[PXT];      // M[0], M[3], M[6] * r0(x): the column part of a = M (r0, r1, -1)
 };
 template <int PXT> CD_HD Lane<PXT> make_lane(const View& v, int lt /* thread index inside its frame's 512 */) {
     Lane<PXT> l;
@@ -271,49 +285,51 @@ template <int PXT> CD_HD Lane<PXT> make_lane(const View& v, int lt /* thread ind
     const int cg = lt - l.rr * v.CG;
     l.rrW = (unsigned)(l.rr * v.W);
     l.on = l.rr < v.RP;
-    l.gon = l.rr < v.G;
+    l.x0 = (unsigned)(cg * PXT);
     for (int i = 0; i < PXT; ++i) {
-        l.x[i] = (unsigned)(cg + i * v.CG);
-        l.cok[i] = (int)l.x[i] < v.W;
-        if (PXT <= 2) {
-            const float r0 = ((float)l.x[i] - v.cj.cx_r) * v.cj.ifx_r;
-            l.a0[i] = v.cj.M[0] * r0; l.a1[i] = v.cj.M[3] * r0; l.a2[i] = v.cj.M[6] * r0;
-        }
+        const float r0 = ((float)(l.x0 + i) - v.cj.cx_r) * v.cj.ifx_r;
+        l.a0[i] = v.cj.M[0] * r0; l.a1[i] = v.cj.M[3] * r0; l.a2[i] = v.cj.M[6] * r0;
     }
-    if (PXT > 2) l.a0[0] = l.a1[0] = l.a2[0] = 0.f;
     return l;
 }
 
-// global load / store at a 32-bit BYTE offset from a wave-uniform base: the address is base (SGPRs) + offset (one VGPR)
-CD_HD float ldg(const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
-CD_HD void stg(float* base, unsigned byte_off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+// global load / store of the PXT pixels of a thread at a 32-bit BYTE offset from a wave-uniform base: the address is base
+// (SGPRs) + offset (one VGPR), one dwordxPXT instruction (rows start at multiples of 4 * PXT bytes: W % PXT == 0, planes 16-byte aligned)
+template <int N> CD_HD VecF<N> ldgv(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const VecF<N>*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <int N> CD_HD void stgv(float* base, unsigned byte_off, const VecF<N>& v) {
+    *reinterpret_cast<VecF<N>*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+template <int PXT> struct Inputs { float fx[PXT], fy[PXT], m[PXT]; };   // flow and mask of the PXT source pixels of one pass
 
 template <int PXT> struct Regs {
-    float fx[PXT], fy[PXT], m[PXT];      // inputs of the source rows being processed
     float sv[kStagePasses][PXT];         // raw depth of the rows entering the ring
     double acc_r, acc_d;                 // loss partial sums of this thread (its frame = direction)
     bool bad;                            // a staged depth was not a positive finite number (see stage_rows)
 };
 template <int PXT> CD_HD void init_regs(Regs<PXT>& r) {
-    for (int i = 0; i < PXT; ++i) {
-        r.fx[i] = r.fy[i] = r.m[i] = 0.f;
+    for (int i = 0; i < PXT; ++i)
         for (int s = 0; s < kStagePasses; ++s) r.sv[s][i] = 0.f;
-    }
     r.acc_r = r.acc_d = 0.0;
     r.bad = false;
 }
 
-// inputs of the source rows [p, p + G) of the wave's frame (p < 0: nothing).  32-bit element offsets from uniform bases.
-template <int PXT> CD_HD void load_inputs(const View& v, const Lane<PXT>& l, int p, float* fx, float* fy, float* m) {
-    const bool rowok = l.gon && p >= 0 && p + l.rr < v.H;
-    const unsigned rowoff = (unsigned)(p < 0 ? 0 : p) * (unsigned)v.W + l.rrW;
+// does pass q of the row group at p give this thread a source row?  (p < 0: the item has no group for this frame)
+template <int PXT> CD_HD bool pass_row_ok(const View& v, const Lane<PXT>& l, int p, int q) {
+    const int ro = q * v.RP + l.rr;
+    return l.on && p >= 0 && ro < v.G && p + ro < v.H;
+}
+
+// inputs of pass q of the source rows [p, p + G) of the wave's frame.  Unconditional loads on clamped offsets (a load under a
+// divergent branch makes hipcc wait for it at once), the values of inactive threads are zeroed afterwards.
+template <int PXT> CD_HD void load_inputs(const View& v, const Lane<PXT>& l, int p, int q, Inputs<PXT>& in) {
+    const bool ok = pass_row_ok<PXT>(v, l, p, q);
+    const unsigned off = ok ? ((unsigned)(p + q * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2 : 0u;
+    const VecF<PXT> a = ldgv<PXT>(v.flj, off), b = ldgv<PXT>(v.flj + v.HW, off), mm = ldgv<PXT>(v.mkj, off);
 #pragma unroll
-    for (int i = 0; i < PXT; ++i) {
-        const bool ok = rowok && l.cok[i];
-        const unsigned q = ok ? (rowoff + l.x[i]) << 2 : 0u;
-        const float a = ldg(v.flj, q), b = ldg(v.flj + v.HW, q), mm = ldg(v.mkj, q);
-        fx[i] = ok ? a : 0.f; fy[i] = ok ? b : 0.f; m[i] = ok ? mm : 0.f;
-    }
+    for (int i = 0; i < PXT; ++i) { in.fx[i] = ok ? a.v[i] : 0.f; in.fy[i] = ok ? b.v[i] : 0.f; in.m[i] = ok ? mm.v[i] : 0.f; }
 }
 
 // raw depth of the rows [s_lo, s_hi) that enter the wave's ring
@@ -321,14 +337,11 @@ template <int PXT> CD_HD void load_stage(const View& v, const Lane<PXT>& l, int 
 #pragma unroll
     for (int s = 0; s < kStagePasses; ++s) {
         const int row = s_lo + s * v.RP + l.rr;
-        const bool rowok = l.on && row < s_hi && row < v.H;
-        const unsigned rowoff = (unsigned)(s_lo + s * v.RP) * (unsigned)v.W + l.rrW;
+        const bool ok = l.on && row < s_hi && row < v.H;
+        const unsigned off = ok ? ((unsigned)(s_lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2 : 0u;
+        const VecF<PXT> a = ldgv<PXT>(v.vj, off);
 #pragma unroll
-        for (int i = 0; i < PXT; ++i) {
-            const bool ok = rowok && l.cok[i];
-            const float a = ldg(v.vj, ok ? (rowoff + l.x[i]) << 2 : 0u);
-            sv[s][i] = ok ? a : 0.f;
-        }
+        for (int i = 0; i < PXT; ++i) sv[s][i] = ok ? a.v[i] : 0.f;
     }
 }
 
@@ -345,15 +358,15 @@ CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, int
             if (slot >= v.R) slot -= v.R;
             const unsigned base = (unsigned)(slot * v.RW);
             const bool img = row < v.H;         // row H is the pad row: finite depth, only ever sampled with weight 0
+            VecF<PXT> d;
 #pragma unroll
             for (int i = 0; i < PXT; ++i) {
-                if (l.cok[i]) {
-                    const float d = img ? to_depth<MODE>(sv[s][i]) : 1.f;
-                    good = good && (d > 0.f && d < INFINITY);
-                    v.Dj[base + l.x[i]] = d;
-                }
+                d.v[i] = img ? to_depth<MODE>(sv[s][i]) : 1.f;
+                good = good && (d.v[i] > 0.f && d.v[i] < INFINITY);
             }
-            if (l.x[0] == 0u) { v.Dj[base + (unsigned)v.W] = 1.f; v.Dj[base + (unsigned)v.RW - 1u] = 1.f; }   // the pad column(s)
+            *reinterpret_cast<VecF<PXT>*>(&v.Dj[base + l.x0]) = d;
+            if (l.x0 == 0u)
+                for (int c = v.W; c < v.RW; ++c) v.Dj[base + (unsigned)c] = 1.f;   // the pad column(s)
         }
     }
     return good;
@@ -371,27 +384,28 @@ CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi, int slo
             int slot = slot0 + (row - lo);
             if (slot >= v.R) slot -= v.R;
             const unsigned base = (unsigned)(slot * v.RW);
-            const unsigned goff = (unsigned)(lo + s * v.RP) * (unsigned)v.W + l.rrW;
+            VecU<PXT>* ap = reinterpret_cast<VecU<PXT>*>(&v.Aj[base + l.x0]);
+            const VecU<PXT> n = *ap;
+            VecU<PXT> z;
+            VecF<PXT> g;
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) {
-                if (l.cok[i]) {
-                    const unsigned long long n = v.Aj[base + l.x[i]];
-                    v.Aj[base + l.x[i]] = 0ull;
-                    stg(v.gradj, (goff + l.x[i]) << 2, (float)((double)(long long)n * unit));
-                }
-            }
-            if (l.x[0] == 0u) { v.Aj[base + (unsigned)v.W] = 0ull; v.Aj[base + (unsigned)v.RW - 1u] = 0ull; }
+            for (int i = 0; i < PXT; ++i) { z.v[i] = 0ull; g.v[i] = (float)((double)(long long)n.v[i] * unit); }
+            *ap = z;
+            stgv<PXT>(v.gradj, ((unsigned)(lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2, g);
+            if (l.x0 == 0u)
+                for (int c = v.W; c < v.RW; ++c) v.Aj[base + (unsigned)c] = 0ull;
         }
     }
 }
 
-// Evaluate the source rows [p, p + G) of the wave's frame j: loss partials, direct gradient -> ring j, the 4 tap
+// Evaluate pass q of the source rows [p, p + G) of the wave's frame j: loss partials, direct gradient -> ring j, the 4 tap
 // contributions -> ring k.  Closed form: SURVEY.md appendix A.1 (= oracle/cd_oracle_body.inc).
 // Env supplies what differs between the GPU and the host emulation:
 //   env.add64(p, v)   64-bit LDS atomic add            env.any(x)   wave vote
 //   env.push(need, idx, v)   wave-aggregated append to the overflow list (gradient element idx += v)
 // The pixels of a thread go through the stages TOGETHER, two at a time (coordinates -> tap reads -> algebra -> atomics):
-// independent dependency chains per wave and one wave vote per stage instead of per pixel.
+// independent dependency chains per wave, one wave vote per stage instead of per pixel, and -- the two pixels being adjacent
+// registers -- packed fp32 instructions for the algebra.
 //
 // "Lenient" lanes.  A source with mask == 0 scatters nothing and adds m * |...| = 0 to the loss -- unless a sampled depth is
 // zero, negative or not finite (0 * inf = NaN in the reference).  Such sources are mostly the ones whose flow points out of
@@ -400,36 +414,37 @@ CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi, int slo
 // could differ from the reference: if any depth of the pair is not a positive finite number, the kernel raises the fallback
 // flag and the exact v1 pass recomputes gradient and loss (loss_api.hip).
 template <int MODE, bool REPROJ, int PXT, class Env>
-CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& l, int p, int wj, int wsj, int wk, int wsk, int nvk) {
-    const int y = p + l.rr;
-    const bool rowok = l.gon && p >= 0 && y < v.H;
+CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& l, const Inputs<PXT>& in, int p, int q, int wj, int wsj,
+                        int wk, int wsk, int nvk) {
+    const int y = p + q * v.RP + l.rr;
+    const bool rowok = pass_row_ok<PXT>(v, l, p, q);
     const Cam& cj = v.cj;
     const float yf = (float)y;
     const float r1 = -(yf - cj.cy_r) * cj.ify_r;
     const float B0 = cj.M[1] * r1 - cj.M[2], B1 = cj.M[4] * r1 - cj.M[5], B2 = cj.M[7] * r1 - cj.M[8];
-    const unsigned own = rowok ? mad24(wrapu((unsigned)(wsj + (y - wj)), (unsigned)v.R), (unsigned)v.RW, 0u) : 0u;
+    const unsigned own = rowok ? mad24(wrapu((unsigned)(wsj + (y - wj)), (unsigned)v.R), (unsigned)v.RW, l.x0) : 0u;
     const int R = v.R, RW = v.RW, W = v.W, H = v.H;
+    VecF<PXT> dv;
+    if (rowok) dv = *reinterpret_cast<const VecF<PXT>*>(&v.Dj[own]);
     // at most 2 pixels share the staged registers (a 1024-thread workgroup has 128 VGPRs per lane); PXT = 4 runs two batches
     constexpr int NB = PXT < 2 ? PXT : 2;
     float sum_r = 0.f, sum_d = 0.f;
 #pragma unroll
     for (int b0 = 0; b0 < PXT; b0 += NB) {
         // ---- stage 0: own depth, sampling coordinates, ring addresses
-        bool act[NB];
         unsigned i0[NB], i1[NB];
         float d[NB];
         Taps tp[NB];
         bool need_slow_rd = false;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            act[i] = rowok && l.cok[b0 + i];
-            d[i] = act[i] ? v.Dj[own + l.x[b0 + i]] : 1.f;
-            tp[i] = tap_coords((float)l.x[b0 + i], yf, r.fx[b0 + i], r.fy[b0 + i], cj.sx, cj.sy, W, H);
+            d[i] = rowok ? dv.v[b0 + i] : 1.f;
+            tp[i] = tap_coords((float)(l.x0 + b0 + i), yf, in.fx[b0 + i], in.fy[b0 + i], cj.sx, cj.sy, W, H);
             // Ring addressing uses the UNCLIPPED neighbours (xa + 1, ya + 1): the pad column / pad row hold a finite depth and
             // the clipped tap's weight is exactly 0 there, so no min() is needed on the fast path.
             const int ra = tp[i].ya - wk;
             const bool inside = (unsigned)ra < (unsigned)(nvk - 1);      // rows ya, ya + 1 both in [wk, wk + nvk); nvk >= 1
-            const bool lenient = !act[i] || r.m[b0 + i] == 0.f;
+            const bool lenient = !rowok || in.m[b0 + i] == 0.f;
             need_slow_rd = need_slow_rd || (!inside && !lenient);
             const unsigned rac = inside ? (unsigned)ra : 0u;              // outside (lenient lanes): the window's first row, always staged
             const unsigned sa = wrapu((unsigned)wsk + rac, (unsigned)R), sb = wrapu(sa + 1u, (unsigned)R);
@@ -445,7 +460,7 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
         } else {   // some valid source of the wave samples outside the ring: every tap decides for itself (LDS or global)
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const bool exact = act[i] && r.m[b0 + i] != 0.f;
+                const bool exact = rowok && in.m[b0 + i] != 0.f;
                 auto tap = [&](int rq, int cq) -> float {
                     const int rel = rq - wk;
                     if ((unsigned)rel < (unsigned)nvk) return v.Dk[wrap_slot(wsk + rel, R) * RW + cq];
@@ -461,11 +476,9 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
         bool need_slow = false;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const float xf = (float)l.x[b0 + i];
-            const float m = r.m[b0 + i], fx = r.fx[b0 + i], fy = r.fy[b0 + i];      // 0 for inactive lanes
-            float a0, a1, a2;
-            if (PXT <= 2) { a0 = l.a0[(b0 + i) % Lane<PXT>::NA] + B0; a1 = l.a1[(b0 + i) % Lane<PXT>::NA] + B1; a2 = l.a2[(b0 + i) % Lane<PXT>::NA] + B2; }
-            else { const float r0 = (xf - cj.cx_r) * cj.ifx_r; a0 = cj.M[0] * r0 + B0; a1 = cj.M[3] * r0 + B1; a2 = cj.M[6] * r0 + B2; }
+            const float xf = (float)(l.x0 + b0 + i);
+            const float m = in.m[b0 + i], fx = in.fx[b0 + i], fy = in.fy[b0 + i];      // 0 for inactive lanes
+            const float a0 = l.a0[b0 + i] + B0, a1 = l.a1[b0 + i] + B1, a2 = l.a2[b0 + i] + B2;
             const float X = d[i] * a0 + cj.c[0], Y = d[i] * a1 + cj.c[1], Z = d[i] * a2 + cj.c[2];
             const float iZ = cd_rcp(Z);
             float gdi = 0.f;   // direct term, in units of ring j
@@ -474,14 +487,14 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
                 const float ex = (cj.cx_t - cj.fx_t * X * iZ) - mx, ey = (cj.cy_t + cj.fy_t * Y * iZ) - my;
                 const float e2 = ex * ex + ey * ey;
                 const float ie = e2 > 0.f ? cd_rsq(e2) : 0.f;       // subgradient 0 at e = 0
-                sum_r += act[i] ? m * (e2 * ie) : 0.f;              // multiply, not select: 0*inf = NaN exactly like the reference
+                sum_r += rowok ? m * (e2 * ie) : 0.f;               // multiply, not select: 0*inf = NaN exactly like the reference
                 const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
                 gdi = cj.drs * m * (ex * dpx + ey * dpy) * ie;
             }
             const float zs = -(d00[i] * tp[i].w00 + d01[i] * tp[i].w01 + d10[i] * tp[i].w10 + d11[i] * tp[i].w11);
             const float izs = cd_rcp(zs);
             const float dd = iZ - izs;
-            sum_d += act[i] ? m * fabsf(dd) : 0.f;
+            sum_d += rowok ? m * fabsf(dd) : 0.f;
             const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
             const float ms = m * sg;
             gdi -= cj.dbs * ms * a2 * iZ * iZ;
@@ -492,7 +505,7 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
             gd[i] = gdi;
             // inside the fixed-point range?  (a sum, not a max: NaN must fail the test)
             const bool fits = fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]) + fabsf(gdi) <= SWEEP_FX_LIMIT_SCALED;
-            need_slow = need_slow || (act[i] && !fits);
+            need_slow = need_slow || (rowok && !fits);
         }
         const bool slow = slow_rd || env.any(need_slow);
 
@@ -500,9 +513,9 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
         if (!slow) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                if (act[i]) {
-                    env.add64(&v.Aj[own + l.x[b0 + i]], sweep_scaled_to_fixed(gd[i]));
-                    if (r.m[b0 + i] != 0.f) {
+                if (rowok) {
+                    env.add64(&v.Aj[own + (unsigned)(b0 + i)], sweep_scaled_to_fixed(gd[i]));
+                    if (in.m[b0 + i] != 0.f) {
                         env.add64(&v.Ak[i0[i]], sweep_scaled_to_fixed(c00[i])); env.add64(&v.Ak[i0[i] + 1], sweep_scaled_to_fixed(c01[i]));
                         env.add64(&v.Ak[i1[i]], sweep_scaled_to_fixed(c10[i])); env.add64(&v.Ak[i1[i] + 1], sweep_scaled_to_fixed(c11[i]));
                     }
@@ -512,9 +525,9 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const bool dfit = fabsf(gd[i]) <= SWEEP_FX_LIMIT_SCALED;
-                if (act[i] && dfit) env.add64(&v.Aj[own + l.x[b0 + i]], sweep_scaled_to_fixed(gd[i]));
-                env.push(act[i] && !dfit, v.gbj + (unsigned)(y * W) + l.x[b0 + i], gd[i] * cj.unit_s);
-                const bool a = act[i];
+                if (rowok && dfit) env.add64(&v.Aj[own + (unsigned)(b0 + i)], sweep_scaled_to_fixed(gd[i]));
+                env.push(rowok && !dfit, v.gbj + (unsigned)(y * W) + l.x0 + (unsigned)(b0 + i), gd[i] * cj.unit_s);
+                const bool a = rowok;
                 auto scatter = [&](int rq, int cq, float cv) {
                     const int rel = rq - wk;
                     const bool live = a && cv != 0.f;                        // NaN != 0: it propagates like in the reference

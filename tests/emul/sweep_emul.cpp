@@ -92,7 +92,6 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
             regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], lo, hi, 0, 0, sv) || regs[t].bad;
         }
     }
-    for (int t = 0; t < kThreads; ++t) load_inputs<PXT>(vw[fr[t]], lanes[t], items[0].f[fr[t]].p, regs[t].fx, regs[t].fy, regs[t].m);
     int wlast[2] = {0, 0};
     for (int it = 0; it < n_items; ++it) {
         for (int f = 0; f < 2; ++f) {
@@ -107,22 +106,25 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
         // LAST (1): a plan that let them depend on this item's entering / leaving rows would give different results.
         const bool more = it + 1 < n_items;
         std::vector<Regs<PXT>> nxt;
-        if (more) {
+        if (more) {      // the kernel loads the next item's entering rows while this item runs
             nxt = regs;
             for (int t = 0; t < kThreads; ++t) {
                 const Rec& nx = items[it + 1].f[fr[t]];
-                load_inputs<PXT>(vw[fr[t]], lanes[t], nx.p, nxt[t].fx, nxt[t].fy, nxt[t].m);
                 load_stage<PXT>(vw[fr[t]], lanes[t], nx.s_lo, nx.s_hi, nxt[t].sv);
             }
         }
+        const int passes = g.G > g.RP ? 2 : 1;
         for (int pass = 0; pass < 2; ++pass) {
             if ((pass == 0) == (g_order == 0)) {
-                for (int t = 0; t < kThreads; ++t) {
-                    const int f = fr[t];
-                    const Rec& me = items[it].f[f];
-                    const Rec& ot = items[it].f[1 - f];
-                    process_rows<MODE, REPROJ, PXT>(vw[f], env, regs[t], lanes[t], me.p, me.w, me.ws, ot.w, ot.ws, ot.nv);
-                }
+                for (int q = 0; q < passes; ++q)
+                    for (int t = 0; t < kThreads; ++t) {
+                        const int f = fr[t];
+                        const Rec& me = items[it].f[f];
+                        const Rec& ot = items[it].f[1 - f];
+                        Inputs<PXT> in;
+                        load_inputs<PXT>(vw[f], lanes[t], me.p, q, in);
+                        process_rows<MODE, REPROJ, PXT>(vw[f], env, regs[t], lanes[t], in, me.p, q, me.w, me.ws, ot.w, ot.ws, ot.nv);
+                    }
             } else {
                 for (int t = 0; t < kThreads; ++t) {
                     const Rec& me = items[it].f[fr[t]];
@@ -133,10 +135,8 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
         }
         if (more)
             for (int t = 0; t < kThreads; ++t)
-                for (int i = 0; i < PXT; ++i) {
-                    regs[t].fx[i] = nxt[t].fx[i]; regs[t].fy[i] = nxt[t].fy[i]; regs[t].m[i] = nxt[t].m[i];
+                for (int i = 0; i < PXT; ++i)
                     for (int s = 0; s < kStagePasses; ++s) regs[t].sv[s][i] = nxt[t].sv[s][i];
-                }
     }
     for (int f = 0; f < 2; ++f)
         if (wlast[f] < H) { fprintf(stderr, "emul: rows left in ring %d\n", f); return -5; }
@@ -176,7 +176,7 @@ int sweep_emul_geo(int H, int W, int pxt, int ring_rows, int* out) {
     Geo g = make_geo(H, W, pxt);
     if (ring_rows > 0 && g.CG > 0) {   // same rules as make_geo with a smaller ring
         g.R = ring_rows;
-        g.G = g.RP < (g.R - 8) / 3 ? g.RP : (g.R - 8) / 3;
+        g.G = kGroupPasses * g.RP < (g.R - 8) / 3 ? kGroupPasses * g.RP : (g.R - 8) / 3;
         g.SMAX = kStagePasses * g.RP;
         if (g.SMAX > g.R - g.G - 8) g.SMAX = g.R - g.G - 8;
         g.ok = g.G >= 1 && g.SMAX >= g.G;

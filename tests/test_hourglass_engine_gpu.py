@@ -224,9 +224,17 @@ def test_inception_block_matches_fp64(kind, N, H, W):
     """The gap between "one convolution at 2e-6" (test_conv_gpu.py) and "157 convolutions at the fp32-autograd noise level" (above):
     ONE inception block -- fused 1x1 entry group, three k x k branches, train-mode BatchNorm (batch statistics), ReLU -- on the
     engine's own fused launches and buffer layout, against fp64 autograd of the same block: activated output, input gradient and
-    every weight gradient at <= 1e-5 relative L1.  A block is two layers deep, so nothing chaotic hides a mis-scaled branch, a
-    wrong concat offset or a mis-wired BatchNorm slice (each shows up as >= 1e-2).  Shapes: the finest level (16-channel
-    two-row tiles, k = 11), the 96x56 / 48x28 levels (the latency-chain launches) and 192x112."""
+    every weight gradient.  A block is two layers deep, so nothing chaotic hides a mis-scaled branch, a wrong concat offset or a
+    mis-wired BatchNorm slice (each shows up as >= 1e-2).
+
+    The loss is L = 1/2 sum_c w_c sum y_c^2 (random positive channel weights), i.e. dL/dy = w_c y on each side's OWN output -- not
+    a random upstream gradient.  Measured with one (profiles/parity_blocks_r03.txt): a weight gradient is then a sum of ~10^5..10^6
+    zero-mean terms (condition number ~ sqrt(N H W)), and ONE ReLU mask that flips on a pre-activation within round-off of zero
+    moves the two weight tensors of its branch by 1e-4..1e-3 -- in this engine, in its fp32-MFMA mode and in torch's fp32
+    autograd alike, each on different branches.  With dL/dy = w y the gradient vanishes where the output mask flips and the sums
+    carry signal, so the comparison measures the arithmetic.  Bounds: output <= 1e-5; gradients <= 1e-5 or within 3x of torch's
+    own fp32 autograd on the same tensor.  Shapes: the finest level (16-channel two-row tiles, k = 11), the 96x56 / 48x28 levels
+    (the latency-chain launches) and 192x112."""
     import torch
     from consistent_depth_amd.monodepth.hourglass import HourglassModel, INCEPTION
     from consistent_depth_amd.monodepth.hourglass_engine import BlockRunner, HourglassEngine
@@ -236,34 +244,47 @@ def test_inception_block_matches_fp64(kind, N, H, W):
     eng = HourglassEngine(net)
     mod = _inception_of(net, kind)
     c_in = INCEPTION[kind][0]
+    sd0 = {k: v.cpu() for k, v in mod.state_dict().items()}
     ref = type(mod)(kind).double()
-    ref.load_state_dict({k: v.double().cpu() if v.is_floating_point() else v.cpu() for k, v in mod.state_dict().items()})
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in sd0.items()})
     ref.train()
+    ref32 = type(mod)(kind)
+    ref32.load_state_dict(sd0)
+    ref32.train()
     g = torch.Generator().manual_seed(11)
     x_raw = torch.randn(N, c_in, H, W, generator=g, dtype=torch.float64)
-    dy = torch.randn(N, sum(c[-1] if len(c) > 1 else c[0] for c in INCEPTION[kind][1]), H, W, generator=g, dtype=torch.float64)
+    co = sum(c[-1] if len(c) > 1 else c[0] for c in INCEPTION[kind][1])
+    wc = (0.5 + torch.rand(1, co, 1, 1, generator=g, dtype=torch.float64))
     a = torch.relu(x_raw).requires_grad_(True)
     y_ref = ref(a)
-    y_ref.backward(dy)
+    (0.5 * (wc * y_ref * y_ref).sum()).backward()
+    a32 = torch.relu(x_raw).float().requires_grad_(True)
+    y32 = ref32(a32)
+    (0.5 * (wc.float() * y32 * y32).sum()).backward()
     for p in mod.parameters():
         p.grad = torch.zeros_like(p)
     blk = BlockRunner(eng, mod, N, H, W, relu_in=True)
     y = blk.forward(x_raw.float().cuda())
-    dx = blk.backward(dy.float().cuda())
+    dx = blk.backward(wc.float().cuda() * y)
     torch.cuda.synchronize()
-    res = {"y": _rel(y.cpu(), y_ref.detach()), "dx": _rel(dx.cpu(), a.grad)}
-    gref = dict(ref.named_parameters())
-    worst_w, worst_name = 0.0, ""
+    res = {"y": _rel(y.cpu(), y_ref.detach()), "y_torch32": _rel(y32.detach(), y_ref.detach()),
+           "dx": _rel(dx.cpu(), a.grad), "dx_torch32": _rel(a32.grad, a.grad)}
+    gref, g32 = dict(ref.named_parameters()), dict(ref32.named_parameters())
+    rows = []
     for name, p in mod.named_parameters():
         if name.endswith(".bias"):
             assert p.grad.abs().max().item() == 0.0      # in front of a train-mode BatchNorm: identically zero
             continue
-        e = _rel(p.grad.cpu(), gref[name].grad)
-        if e > worst_w:
-            worst_w, worst_name = e, name
-    res["dw_worst"] = worst_w
-    report(f"inception_block[{kind},{N}x{H}x{W}]", **res, worst_weight=worst_name)
-    assert res["y"] <= 1e-5 and res["dx"] <= 1e-5 and res["dw_worst"] <= 1e-5, res
+        rows.append((_rel(p.grad.cpu(), gref[name].grad), _rel(g32[name].grad, gref[name].grad), name))
+    worst = max(rows)
+    res["dw_worst"], res["dw_worst_torch32"] = worst[0], worst[1]
+    res["dw_median"] = sorted(r[0] for r in rows)[len(rows) // 2]
+    res["dw_median_torch32"] = sorted(r[1] for r in rows)[len(rows) // 2]
+    report(f"inception_block[{kind},{N}x{H}x{W}]", **res, worst_weight=worst[2])
+    assert res["y"] <= 1e-5, res
+    assert res["dx"] <= max(1e-5, 3 * res["dx_torch32"]), res
+    for e, e32, name in rows:
+        assert e <= max(1e-5, 3 * e32), (name, e, e32)
     # running statistics of the block's BatchNorms follow nn.BatchNorm2d
     sd_ref, sd = ref.state_dict(), mod.state_dict()
     for k in sd_ref:
