@@ -633,6 +633,29 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                              accumulate, N, H, W, ks, 0, 0, stream);
 }
 
+int cd_conv2d_fwd_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* packed_w, size_t packed_group_stride,
+                          const float* bias, float* y, int y_ctot, int y_coff, int cout_g, int groups, int accumulate, int N, int H, int W,
+                          int ks, void* stream) {
+    if (!x || !packed_w || !y || groups <= 0 || cin_g <= 0 || cout_g <= 0 || N <= 0 || H <= 0 || W <= 0) return CD_ERR_INVALID_ARG;
+    if (x_coff < 0 || x_coff + groups * cin_g > x_ctot || y_coff < 0 || y_coff + groups * cout_g > y_ctot) return CD_ERR_INVALID_ARG;
+    if (groups > 1 && (packed_group_stride < cd_conv2d_packed_weight_floats(cout_g, cin_g, ks, 0) || packed_group_stride % 4)) return CD_ERR_INVALID_ARG;
+    if (cd::g_conv_arith >= 1 && cd::split_supported(ks) && cin_g >= 8 && groups <= 65535) {   // ONE launch: blockIdx.y = the group
+        const bool small = (long long)N * H * W <= 8LL * 96 * 56;
+        cd::ConvGroups grp;
+        grp.n = groups; grp.x_stride = cin_g; grp.y_stride = cout_g; grp.w_stride = packed_group_stride / 4;
+        return cd::launch_conv_split(x, x_ctot, x_coff, cin_g, packed_w + cd::fp32_packed_floats(cout_g, cin_g, ks), bias, nullptr, nullptr, 0, y,
+                                     y_ctot, y_coff, cout_g, nullptr, accumulate, N, H, W, ks, (small || cd::split_column_tiles(cout_g) >= 2) ? 16 : 8,
+                                     small ? 1 : 2, (hipStream_t)stream, grp);
+    }
+    for (int g = 0; g < groups; ++g) {   // other arithmetic modes / filter sizes: the dense kernels, group by group
+        const int rc = cd_conv2d_fwd(x, x_ctot, x_coff + g * cin_g, cin_g, packed_w + (size_t)g * packed_group_stride,
+                                     bias ? bias + g * cout_g : nullptr, nullptr, nullptr, 0, y, y_ctot, y_coff + g * cout_g, cout_g, nullptr,
+                                     accumulate, N, H, W, ks, stream);
+        if (rc != CD_OK) return rc;
+    }
+    return CD_OK;
+}
+
 int cd_conv2d_packed_co_tiles(int Cout, int ks) {
     if (cd::g_conv_arith >= 1 && cd::split_supported(ks)) return cd::split_column_tiles(Cout) >= 2 ? 2 : 1;
     return cd::max_co_tiles(ks, Cout);

@@ -53,8 +53,12 @@ int split_column_tiles(int OC);
 int launch_pack_split_table(const void* table_dev, int n, hipStream_t s);
 int launch_pack_split(const float* w, int Cout, int Cin, int ks, int transposed, float* packed_split, hipStream_t s);
 
+// Grouped launches: group g works on input channels [x_coff + g * x_stride, + Cin), output channels [y_coff + g * y_stride, + Cout)
+// and the packed filter at wsplit + g * w_stride (16-byte units); n = 1 and zero strides = a dense convolution.
+struct ConvGroups { int n = 1, x_stride = 0, y_stride = 0; size_t w_stride = 0; };
+
 int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                       const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
-                      int H, int W, int ks, int ty, int cot, hipStream_t s);
+                      int H, int W, int ks, int ty, int cot, hipStream_t s, const ConvGroups& grp = ConvGroups());
 
 }  // namespace cd

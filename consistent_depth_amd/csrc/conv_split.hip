@@ -142,8 +142,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     float* __restrict__ y, int y_ctot, int y_coff, int Cout,
     double* __restrict__ stats, int accumulate, int H, int W, int tiles_x, int tiles_img, int tiles_total, int chunk_tiles,
-    int slices) {
+    int slices, const ConvGroups grp) {
     using Cfg = SplitCfg<KS, TYP, DY>;
+    // grouped convolution (ResNeXt's 32 x 8d 3x3): blockIdx.y = the group, a dense convolution on its channel slices with its
+    // own packed filter; dense launches have one group and zero strides
+    x_coff += (int)blockIdx.y * grp.x_stride;
+    y_coff += (int)blockIdx.y * grp.y_stride;
+    wsp += (size_t)blockIdx.y * grp.w_stride;
+    if (bias != nullptr) bias += (int)blockIdx.y * grp.y_stride;
     constexpr int TY = Cfg::TY, ROWS = Cfg::ROWS, RSP = Cfg::RSP, COFF = Cfg::COFF, PADL = Cfg::PADL, PLANE = Cfg::PLANE;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, KSTEPS = Cfg::KSTEPS;
     constexpr int MB = TY / DY;                       // M-tiles (tile rows, DY output rows each) per block
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
 template <int KS, int NT, int TYP, int DY, int CGS = 1>
 static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                           const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
-                          int N, int H, int W, hipStream_t s) {
+                          int N, int H, int W, const ConvGroups& grp, hipStream_t s) {
     using Cfg = SplitCfg<KS, TYP, DY>;
     const int tiles_x = (W + SP_TX - 1) / SP_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
     const size_t lds = CGS * Cfg::LDS > SPLIT_REDUCE_LDS ? CGS * Cfg::LDS : SPLIT_REDUCE_LDS;
@@ -454,9 +460,9 @@ static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
     const int pack_tiles = split_ntiles(Cout), slices = (pack_tiles + NT - 1) / NT;
     const int tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * N, chunk_tiles = (tiles_total + 7) / 8;
-    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY, CGS>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices), dim3(kBlock), lds, s, x, x_ctot,
+    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY, CGS>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices, (unsigned)grp.n), dim3(kBlock), lds, s, x, x_ctot,
                        x_coff, Cin, reinterpret_cast<const u32x4*>(wsplit), pack_tiles, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff,
-                       Cout, stats, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk_tiles, slices);
+                       Cout, stats, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk_tiles, slices, grp);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -483,12 +489,12 @@ int launch_pack_split(const float* w, int Cout, int Cin, int ks, int transposed,
 // with two 8-channel chunks staged per barrier round.
 int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                       const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
-                      int H, int W, int ks, int ty, int cot, hipStream_t s) {
+                      int H, int W, int ks, int ty, int cot, hipStream_t s, const ConvGroups& grp) {
     const int dy = split_dy(Cout);
     const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
     const bool two = ty >= 16;                        // hint 16: 4 M-tiles, two channel chunks per barrier round (latency-bound small images)
     const int mb = (nt == 2 || ty <= 4 || two) ? 4 : 8;
-#define CD_SP(K, T, Y, D, G) return launch_split_t<K, T, Y, D, G>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s)
+#define CD_SP(K, T, Y, D, G) return launch_split_t<K, T, Y, D, G>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, grp, s)
 #define CD_SP_K(K)                                                   \
     if (ks == K) {                                                   \
         if (dy == 2) { if (mb == 8) CD_SP(K, 1, 16, 2, 1); if (two) CD_SP(K, 1, 8, 2, 2); CD_SP(K, 1, 8, 2, 1); } \

@@ -318,7 +318,11 @@ __device__ __forceinline__ void unpack_rows(const float* __restrict__ packed, fl
 
 // packed [split][cog][cig][tap][COB][CIB] -> dW[Cout][Cin][KS][KS]  (accumulate = 0: overwrite, 1: add)
 __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, int Cout, int Cin, int KS, int COB, int CIB,
-                                    int ci_groups, int splits, size_t split_stride, float* __restrict__ dw, int accumulate) {
+                                    int ci_groups, int splits, size_t split_stride, float* __restrict__ dw, int accumulate,
+                                    size_t ws_group_stride) {
+    // blockIdx.y = the group of a grouped convolution (its own workspace and its own [Cout][Cin][KS][KS] block of dw)
+    packed += (size_t)blockIdx.y * ws_group_stride;
+    dw += (size_t)blockIdx.y * Cout * Cin * KS * KS;
     unpack_rows(packed, dw, Cin, KS, COB, CIB, ci_groups, 0, Cout, accumulate, splits, split_stride,
                 blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
@@ -651,7 +655,7 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
         if (rc != CD_OK || (accumulate & 4)) return rc;
         const int total = Cout * Cin;
         hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s, workspace,
-                           Cout, Cin, 1, L.cob, L.cib, L.cigs, L.splits, L.slice, dw, accumulate & 1);
+                           Cout, Cin, 1, L.cob, L.cib, L.cigs, L.splits, L.slice, dw, accumulate & 1, (size_t)0);
         CD_CHECK_LAUNCH();
         return CD_OK;
     }
@@ -661,7 +665,7 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
         if (rc != CD_OK || (accumulate & 4)) return rc;
         const int total = Cout * Cin * ks * ks;
         hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s, workspace,
-                           Cout, Cin, ks, L.cob, L.cib, L.cigs, L.splits, L.slice, dw, accumulate & 1);
+                           Cout, Cin, ks, L.cob, L.cib, L.cigs, L.splits, L.slice, dw, accumulate & 1, (size_t)0);
         CD_CHECK_LAUNCH();
         return CD_OK;
     }
@@ -699,8 +703,38 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     const int cob = p.co_t * 16, cib = p.ci_t * 16;
     const int total = Cout * Cin * ks * ks;
     hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
-                       workspace, Cout, Cin, ks, cob, cib, L.cigs, L.splits, L.slice, dw, accumulate & 1);
+                       workspace, Cout, Cin, ks, cob, cib, L.cigs, L.splits, L.slice, dw, accumulate & 1, (size_t)0);
     CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_conv2d_wgrad_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* dy, int dy_ctot, int dy_coff, int cout_g,
+                            int groups, float* dw, int accumulate, float* workspace, size_t workspace_group_stride, int N, int H, int W,
+                            int ks, void* stream) {
+    if (!x || !dy || !dw || !workspace || groups <= 0 || cin_g <= 0 || cout_g <= 0 || N <= 0 || H <= 0 || W <= 0) return CD_ERR_INVALID_ARG;
+    if (x_coff < 0 || x_coff + groups * cin_g > x_ctot || dy_coff < 0 || dy_coff + groups * cout_g > dy_ctot) return CD_ERR_INVALID_ARG;
+    const size_t wsf = cd_conv2d_wgrad_workspace_floats(cout_g, cin_g, ks);
+    if (wsf == 0) return CD_ERR_UNSUPPORTED;
+    if (groups > 1 && workspace_group_stride < wsf) return CD_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const cd::WgLayout L = cd::wgrad_layout(cout_g, cin_g, ks, N, H, W);
+    if (L.split_arith && groups <= 65535 / L.cogs) {   // ONE launch for all groups (+ one unpack)
+        const int rc = cd::launch_wgrad_split(x, x_ctot, x_coff, cin_g, nullptr, nullptr, 0, dy, dy_ctot, dy_coff, cout_g, workspace, N, H, W, ks,
+                                              L.splits, s, groups, workspace_group_stride);
+        if (rc != CD_OK) return rc;
+        const int total = cout_g * cin_g * ks * ks;
+        const int bx = (total + 255) / 256 > 64 ? 64 : (total + 255) / 256;
+        hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3(bx, groups), dim3(256), 0, s, workspace, cout_g, cin_g, ks, L.cob, L.cib, L.cigs, L.splits,
+                           L.slice, dw, accumulate & 1, workspace_group_stride);
+        CD_CHECK_LAUNCH();
+        return CD_OK;
+    }
+    for (int g = 0; g < groups; ++g) {   // other arithmetic modes / filter sizes: the dense kernels, group by group
+        const int rc = cd_conv2d_wgrad(x, x_ctot, x_coff + g * cin_g, cin_g, nullptr, nullptr, 0, dy, dy_ctot, dy_coff + g * cout_g, cout_g,
+                                       dw + (size_t)g * cout_g * cin_g * ks * ks, accumulate & 1, workspace + (size_t)g * workspace_group_stride, N, H,
+                                       W, ks, stream);
+        if (rc != CD_OK) return rc;
+    }
     return CD_OK;
 }
 

@@ -205,7 +205,12 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         }
         g_prof.pending_batch = B;
         const int cap = (g_force_overflow_cap >= 0 && g_force_overflow_cap < w.ovf_cap) ? g_force_overflow_cap : w.ovf_cap;
-        const bool use_sweep = d_on && sweep_supported(H, W) && (g_loss_variant == 4 || (g_loss_variant == 0 && sweep_preferred(B, H, W)));
+        // the row sweep moves the pixels of a thread with one vector access per plane and row: planes must start on 16-byte boundaries
+        const bool sweep_aligned = ((reinterpret_cast<uintptr_t>(depth) | reinterpret_cast<uintptr_t>(ff) | reinterpret_cast<uintptr_t>(fb) |
+                                     reinterpret_cast<uintptr_t>(mf) | reinterpret_cast<uintptr_t>(mb) | reinterpret_cast<uintptr_t>(grad)) % 16 == 0) &&
+                                   ((size_t)HW * 4) % 16 == 0;
+        const bool use_sweep = d_on && sweep_aligned && sweep_supported(H, W) &&
+                               (g_loss_variant == 4 || (g_loss_variant == 0 && sweep_preferred(B, H, W)));
         if (use_sweep)
             rc = launch_sweep(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf, cap,
                               s, prof_before, prof_after);

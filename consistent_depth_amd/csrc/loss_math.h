@@ -142,32 +142,39 @@ CD_HD void prep_pair(const float* intr_p, const float* extr_p, const float* msum
 }
 
 // ---------------------------------------------------------------- fixed point of the row-sweep accumulator
-// value (in units U) * 2^34 as a 64-bit integer; |value| <= 2^17 (beyond that, and for NaN/inf, the contribution
-// takes the overflow list and propagates like the reference's float arithmetic).  Integer sums are order-independent:
-// the gradient is bit-reproducible.  2^-34 of an O(1) unit is 6e-11: far below fp32 resolution.
-constexpr double SWEEP_FX_ONE = 17179869184.0;          // 2^34
-constexpr double SWEEP_FX_MAGIC = 6755399441055744.0;   // 1.5 * 2^52: low 32 bits of its pattern are zero
-constexpr float SWEEP_FX_LIMIT = 131072.f;              // 2^17  (2^17 * 2^34 = 2^51 < the magic-number range)
-
-CD_HD unsigned long long sweep_to_fixed(float c) {
-    const double d = fma((double)c, SWEEP_FX_ONE, SWEEP_FX_MAGIC);
-    unsigned long long u, m;
-    const double mg = SWEEP_FX_MAGIC;
-    memcpy(&u, &d, 8);
-    memcpy(&m, &mg, 8);
-    return u - m;
-}
-CD_HD double sweep_from_fixed(unsigned long long v) { return (double)(long long)v * (1.0 / SWEEP_FX_ONE); }
-// The kernel folds 2^34 into its wave-uniform scale factors (exact: a power of two), so a value arrives PRE-SCALED and
-// the conversion is cvt_f64_f32 + add_f64(magic) + one 32-bit subtract (the magic pattern's low word is zero).
-constexpr float SWEEP_FX_ONE_F = 17179869184.f;                       // 2^34
-constexpr float SWEEP_FX_LIMIT_SCALED = 2251799813685248.f;           // 2^51 = limit * 2^34
-CD_HD unsigned long long sweep_scaled_to_fixed(float cs) {
-    const double d = (double)cs + SWEEP_FX_MAGIC;
-    unsigned long long u;
-    memcpy(&u, &d, 8);
-    return u - 0x4338000000000000ull;
+// Round 3: a 32-BIT integer per ring element (round 2: 64-bit, 2^34 per unit).  The ring of frame j counts in units U_j with
+// SWEEP_FX_BITS fractional bits: a contribution c (gradient units) is added as round(c / U_j * 2^20).  Why 32 bits are enough:
+//   * resolution: rounding is +-1/2 * 2^-20 U per contribution, ~5 contributions per element -> a mean absolute error of
+//     ~5e-7 U; with U_j <= the mean |gradient| of the plane (sweep_units below: a data-dependent estimate, a power of two)
+//     that is <= 1e-6 relative L1, the class of the reference's own fp32 arithmetic (and integer sums are order independent:
+//     the gradient stays bit-reproducible);
+//   * range: a source is accepted while the |.| sum of its 5 contributions is <= LIMIT; larger ones (and NaN / inf) take the
+//     overflow list like before.  An element cannot wrap: the plan counts, from the flows (a dataset constant), how many sources
+//     reach each target pixel; with a fan-in of at most F the pair's LIMIT is the largest power of two with (F + 1) LIMIT < 2^31,
+//     capped at 2^27 = 128 U (F <= 15: every consistent flow field; zooming 2x gives ~16) and never below 2^25 = 32 U -- pairs
+//     with more than 62 sources on one pixel get no plan and take the exact fallback path.
+// What it buys (the kernel is VALU- and register-bound): one v_cvt_rpi_i32_f32 + one ds_add_u32 per contribution
+// instead of cvt_f64_f32 + add_f64 + sub + ds_add_u64 with a register pair, a 2-instruction flush conversion instead of the
+// i64 -> f64 -> f32 chain, and 8 instead of 12 bytes of LDS per ring element (a 45-row ring at W = 224 instead of 30).
+constexpr int SWEEP_FX_BITS = 20;
+constexpr float SWEEP_FX_ONE_F = 1048576.f;                // 2^20: folded into the wave-uniform scale factors (exact)
+constexpr int SWEEP_MAX_FAN_IN = 62;                       // sources per target pixel a plan accepts: (62 + 1 direct) * 2^25 < 2^31
+// bound of the |.| sum of one source's pre-scaled contributions for a pair whose target pixels receive at most `fan_in` sources
+CD_HD float sweep_limit_scaled(int fan_in) {
+    if (fan_in < 16) return 134217728.f;    // 2^27
+    if (fan_in < 32) return 67108864.f;     // 2^26
+    return 33554432.f;                      // 2^25 (fan_in <= SWEEP_MAX_FAN_IN)
 }
 
+// pre-scaled value -> accumulator integer, round to nearest (ties up): ONE instruction
+CD_HD int sweep_scaled_to_fixed(float cs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(cs));   // floor(cs + 0.5) computed exactly
+    return r;
+#else
+    return (int)floor((double)cs + 0.5);
+#endif
+}
 
 }  // namespace cd

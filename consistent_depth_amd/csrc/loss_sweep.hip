@@ -41,6 +41,7 @@ size_t pair_record_bytes(int H, int W) {
 static size_t plan_offset(int H, int W) { return align_up(sizeof(TileWin) * 2 * (size_t)owner_ntiles(H, W), 16); }
 
 // ---------------------------------------------------------------- plan (dataset constant: flows and masks only)
+constexpr int kFanWords = 16384;      // fan-in counters of one band of target rows (64 KB)
 constexpr int kPlanItemsLds = 2560;   // Item scratch of the planner (8 B each); plans longer than this are not made (-> v3)
 
 __global__ __launch_bounds__(kBlock) void sweep_plan_kernel(const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd,
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void sweep_plan_kernel(const float* __restr
     __shared__ int lo_i[2 * kMaxGroups], hi_i[2 * kMaxGroups];
     __shared__ short lo_s[2 * kMaxGroups], hi_s[2 * kMaxGroups], suf[2 * (kMaxGroups + 1)];
     __shared__ Item items[kPlanItemsLds];
+    __shared__ int fan[kFanWords];
     const int b = blockIdx.x, HW = g.H * g.W, NG = g.NG;
     for (int i = threadIdx.x; i < 2 * NG; i += kBlock) { lo_i[i] = kNoRow; hi_i[i] = -1; }
     __syncthreads();
@@ -68,11 +70,44 @@ __global__ __launch_bounds__(kBlock) void sweep_plan_kernel(const float* __restr
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * NG; i += kBlock) { lo_s[i] = (short)lo_i[i]; hi_s[i] = (short)hi_i[i]; }
     __syncthreads();
+    // FAN-IN: how many valid sources add to one target pixel (its 4 taps count a source once each).  The 32-bit accumulators
+    // (loss_math.h) cannot wrap while (fan-in + 1) * LIMIT < 2^31.  Counted band by band of target rows in LDS; the sources are
+    // re-scanned per band (a once-per-dataset kernel).
+    const int cw = g.W + 1, band = kFanWords / cw;
+    int fmax = 0;
+    for (int f = 0; f < 2; ++f) {
+        const float* fl = (f == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
+        const float* mk = (f == 0 ? mask_fwd : mask_bwd) + (size_t)b * HW;
+        for (int r0 = 0; r0 <= g.H; r0 += band) {
+            for (int i = threadIdx.x; i < band * cw; i += kBlock) fan[i] = 0;
+            __syncthreads();
+            for (int p = threadIdx.x; p < HW; p += kBlock) {
+                if (mk[p] != 0.f) {
+                    const int y = p / g.W, x = p - y * g.W;
+                    int xa, ya;
+                    tap_targets((float)x, (float)y, fl[p], fl[HW + p], g.W, g.H, &xa, &ya);
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int rr = ya + dy - r0;
+                        if ((unsigned)rr < (unsigned)band) { atomicAdd(&fan[rr * cw + xa], 1); atomicAdd(&fan[rr * cw + xa + 1], 1); }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < band * cw; i += kBlock) fmax = fan[i] > fmax ? fan[i] : fmax;
+            __syncthreads();
+        }
+    }
+    lo_i[threadIdx.x] = fmax;          // (lo_i is free now: block-wide max through it)
+    __syncthreads();
     if (threadIdx.x == 0) {
+        int fan_in = 0;
+        for (int i = 0; i < kBlock; ++i) fan_in = lo_i[i] > fan_in ? lo_i[i] : fan_in;
         PlanHeader* ph = reinterpret_cast<PlanHeader*>(blob + (size_t)b * stride + plan_off);
-        const int n = plan_items(g, lo_s, hi_s, suf, items);
+        int n = plan_items(g, lo_s, hi_s, suf, items);
+        if (n > 0 && fan_in > SWEEP_MAX_FAN_IN) n = -3;     // a 32-bit accumulator could wrap: no plan, the exact fallback path
         if (n > 0) expand_plan(g, items, n, reinterpret_cast<PlanItem*>(ph + 1));
         ph->n_items = n; ph->G = g.G; ph->R = g.R; ph->PXT = g.PXT;
+        ph->fan_in = fan_in; ph->limit = sweep_limit_scaled(fan_in); ph->pad[0] = ph->pad[1] = 0;
     }
 }
 
@@ -85,10 +120,43 @@ int launch_sweep_plan(const float* ff, const float* fb, const float* mf, const f
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------- accumulator units (per launch: they depend on the depths)
+template <int MODE>
+__global__ __launch_bounds__(kUnitGrid * kUnitGrid) void sweep_units_kernel(const float* __restrict__ depth, const float* __restrict__ ff,
+                                                                            const float* __restrict__ fb, const float* __restrict__ mf,
+                                                                            const float* __restrict__ mb, PairCam* __restrict__ cams, int H, int W) {
+    constexpr int NS = kUnitGrid * kUnitGrid;
+    __shared__ float sd[2][NS], ss[2][NS];
+    __shared__ int sn[2][NS];
+    const int b = blockIdx.x, t = threadIdx.x, HW = H * W;
+    for (int j = 0; j < 2; ++j) {
+        const UnitSample u = unit_sample_at<MODE>(cams + b * 2, depth + (size_t)b * 2 * HW, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW,
+                                                  mf + (size_t)b * HW, mb + (size_t)b * HW, H, W, j, t);
+        sd[j][t] = u.direct; ss[j][t] = u.scatter; sn[j][t] = u.valid;
+    }
+    __syncthreads();
+    if (t == 0) {   // 256 samples: summed in index order by one thread -- the order of the host emulation, bit-reproducible
+        float D[2] = {0.f, 0.f}, S[2] = {0.f, 0.f};
+        int n[2] = {0, 0};
+        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < NS; ++i) { D[j] += sd[j][i]; S[j] += ss[j][i]; n[j] += sn[j][i]; }
+        units_from_samples(cams + b * 2, D, S, n);
+    }
+}
+
+static int launch_sweep_units(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, PairCam* cams, int mode,
+                              int B, int H, int W, hipStream_t s) {
+    const dim3 grid(B), block(kUnitGrid * kUnitGrid);
+    if (mode == CD_DEPTH_EXP) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_EXP>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W);
+    else if (mode == CD_DEPTH_RECIPROCAL) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_RECIPROCAL>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W);
+    else hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_IDENTITY>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
 // ---------------------------------------------------------------- the sweep
 struct DevEnv {
     Overflow* ovf; unsigned* oidx; float* oval;
-    __device__ __forceinline__ static void add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }   // ds_add_u64, no return
+    __device__ __forceinline__ static void add32(unsigned* p, int v) { atomicAdd(p, (unsigned)v); }   // ds_add_u32, no return
     __device__ __forceinline__ static bool any(bool x) { return __any(x) != 0; }
     __device__ __forceinline__ void push(bool need, unsigned idx, float v) { ovf_push(need, ovf, oidx, oval, idx, v); }
     __device__ __forceinline__ void degenerate() { ovf->degenerate = 1; }
@@ -109,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const float* __restrict__ depth, const float* __restrict__ ff, const float* __restrict__ fb, const float* __restrict__ mf,
     const float* __restrict__ mb, const PairCam* __restrict__ cams, const char* __restrict__ blob, float* __restrict__ partial,
     float* __restrict__ grad, Overflow* ovf, unsigned* __restrict__ oidx, float* __restrict__ oval, const SweepShape sh) {
-    extern __shared__ __align__(16) unsigned long long smem[];
+    extern __shared__ __align__(16) unsigned smem[];   // [2][ring] accumulators, [2][ring] depths, reduction scratch
     const Geo g = SG == 1 ? make_geo(kStaticH, kStaticW, kStaticPXT) : sh.g;
     const int b = blockIdx.x, HW = g.H * g.W, ring = g.R * g.RW;
     const int f = uni((int)(threadIdx.x / kFrameThreads)), k = 1 - f;   // whole waves serve one frame: everything derived from f is scalar
@@ -138,6 +206,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const PlanHeader* ph = reinterpret_cast<const PlanHeader*>(blob + (size_t)b * sh.stride + sh.plan_off);
     const PlanItem* __restrict__ items = reinterpret_cast<const PlanItem*>(ph + 1);
     const int n_items = ph->n_items;
+    v.limit = uni(ph->limit);
     if (n_items <= 0 || ph->G != g.G || ph->R != g.R || ph->PXT != g.PXT) {
         // no plan (the planner's item backstop), or one made for another geometry (cd_debug_set_loss_sweep changed after the
         // blob was cached): this pair cannot be swept -- raise the degenerate flag, the guarded exact v1 pass recomputes the
@@ -153,13 +222,13 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const Lane<PXT> l = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);
     Regs<PXT> r;
     init_regs<PXT>(r);
-    for (int i = threadIdx.x; i < 2 * ring; i += kThreads) smem[i] = 0ull;
+    for (int i = threadIdx.x; i < 2 * ring; i += kThreads) smem[i] = 0u;
     const int init_hi = init_stage_hi(g);
     for (int lo = 0; lo < init_hi; lo += kStagePasses * g.RP) {     // prologue: the initial window [0, R)
         const int hi = min(lo + kStagePasses * g.RP, init_hi);
         float sv[kStagePasses][PXT];
         load_stage<PXT>(v, l, lo, hi, sv);
-        r.bad = !stage_rows<MODE, PXT>(v, l, lo, hi, 0, 0, sv) || r.bad;
+        r.bad = !stage_rows<MODE, PXT>(v, l, lo, hi, sv) || r.bad;
     }
     // One barrier per item.  During item t three things run side by side, on disjoint ring rows by construction of the plan:
     //   rows [fl_lo, fl_hi) -- which no source of item t or later touches -- leave ring j (accumulator -> gradient row),
@@ -174,23 +243,23 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     Inputs<PXT> inA, inB;
     const bool two = kGroupPasses > 1 && uni((int)(g.G > g.RP)) != 0;
     Rec me = items[0].f[f];
-    int wk = items[0].f[k].w, wsk = items[0].f[k].ws, nvk = items[0].f[k].nv;
+    int wk = items[0].f[k].w, nvk = items[0].f[k].nv;
     load_inputs<PXT>(v, l, me.p, 0, inA);
     __syncthreads();
     for (int it = 0; it < n_items; ++it) {
-        r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, me.w, me.ws, r.sv) || r.bad;
+        r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
         const bool more = it + 1 < n_items;
         const int nt = more ? it + 1 : it;
         const Rec nx = items[nt].f[f];
-        const int nwk = items[nt].f[k].w, nwsk = items[nt].f[k].ws, nnvk = items[nt].f[k].nv;
+        const int nwk = items[nt].f[k].w, nnvk = items[nt].f[k].nv;
         load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
         if (two) load_inputs<PXT>(v, l, me.p, 1, inB);
-        flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi, me.fl_slot);
-        process_rows<MODE, REPROJ, PXT>(v, env, r, l, inA, me.p, 0, me.w, me.ws, wk, wsk, nvk);
+        flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);
+        process_rows<MODE, REPROJ, PXT>(v, env, r, l, inA, me.p, 0, wk, nvk);
         load_inputs<PXT>(v, l, more ? nx.p : -1, 0, inA);
-        if (two) process_rows<MODE, REPROJ, PXT>(v, env, r, l, inB, me.p, 1, me.w, me.ws, wk, wsk, nvk);
+        if (two) process_rows<MODE, REPROJ, PXT>(v, env, r, l, inB, me.p, 1, wk, nvk);
         __syncthreads();
-        me = nx; wk = nwk; wsk = nwsk; nvk = nnvk;
+        me = nx; wk = nwk; nvk = nnvk;
     }
     if (env.any(r.bad) && (threadIdx.x & (kWave - 1)) == 0) env.degenerate();
     // loss partial sums: one (reprojection, disparity) pair per (pair, direction)
@@ -285,6 +354,7 @@ int launch_sweep(const float* depth, const float* ff, const float* fb, const flo
     SweepArgs prm{depth, ff, fb, mf, mb, (const PairCam*)cams, (const char*)blob, partial, grad, ovf, oidx, oval,
                   SweepShape{g, pair_record_bytes(H, W), plan_offset(H, W)}};
     const size_t lds = ring_lds_bytes(g);
+    if (launch_sweep_units(depth, ff, fb, mf, mb, (PairCam*)const_cast<void*>(cams), mode, B, H, W, s) != CD_OK) return CD_ERR_LAUNCH;
     if (before_main) before_main(s);
     int rc;
     if (mode == CD_DEPTH_EXP) rc = launch_sweep_mode<CD_DEPTH_EXP>(reproj, prm, B, lds, s);

@@ -72,9 +72,12 @@ CD_HD Geo make_geo(int H, int W, int pxt) {
     g.RP = kFrameThreads / g.CG;
     if (g.RP > 16) g.RP = 16;
     g.RW = (W + pxt) / pxt * pxt;                // >= W + 1
-    int R = (kLdsBytes - kLdsReserve) / (2 * g.RW * 12);
-    if (R > H + 2) R = H + 2;                 // rows 0 .. H (H = the pad row under the image) never need more
+    int R = (kLdsBytes - kLdsReserve) / (2 * g.RW * 8);   // fp32 depth + 32-bit accumulator per element
     if (R > 512) R = 512;
+    // a POWER OF TWO: image row r lives in slot r & (R - 1) -- one AND per ring address instead of a window-relative offset
+    // with a wrap (the rings are direct mapped; windows only say which rows are resident)
+    while (R & (R - 1)) R &= R - 1;
+    while (R >= 2 * (H + 2) && R > 16) R >>= 1;   // rows 0 .. H (H = the pad row under the image) never need more
     g.R = R;
     if (R < 12) return g;
     // rows per item: as many as two passes of the threads can take (half the barriers and per-item scalar work of one pass),
@@ -91,7 +94,7 @@ CD_HD Geo make_geo(int H, int W, int pxt) {
     return g;
 }
 
-CD_HD size_t ring_lds_bytes(const Geo& g) { return (size_t)2 * g.R * g.RW * 12 + kLdsReserve; }
+CD_HD size_t ring_lds_bytes(const Geo& g) { return (size_t)2 * g.R * g.RW * 8 + kLdsReserve; }
 
 // ---------------------------------------------------------------- plan
 struct Item {
@@ -193,7 +196,8 @@ struct Rec {
 };
 static_assert(sizeof(Rec) == 48, "Rec layout");
 struct PlanItem { Rec f[2]; };
-struct PlanHeader { int n_items, G, R, PXT; };
+struct PlanHeader { int n_items, G, R, PXT; int fan_in; float limit; int pad[2]; };   // fan_in: max sources per target pixel; limit: sweep_limit_scaled(fan_in)
+static_assert(sizeof(PlanHeader) == 32, "PlanHeader layout");
 CD_HD size_t plan_bytes(const Geo& g) { return sizeof(PlanHeader) + sizeof(PlanItem) * (size_t)g.max_items; }
 
 CD_HD int wrap_slot(int s, int R) { return s >= R ? s - R : s; }
@@ -233,11 +237,88 @@ CD_HD void expand_plan(const Geo& g, const Item* items, int n, PlanItem* out) {
     }
 }
 
+// ---------------------------------------------------------------- accumulator units from the data
+// The 32-bit accumulator of ring j resolves 2^-20 U_j and accepts sources of up to 64 U_j (loss_math.h), so U_j has to sit near
+// the typical gradient magnitude of plane j -- which depends on the depths (1/z^2 factors), the baseline and the lambdas, not
+// only on the per-pair constants prep_pair knows.  It is ESTIMATED per launch from a 16 x 16 grid of sample sources per
+// direction: the mean |direct term| of direction j plus the mean |scatter| of direction k = 1 - j (what lands in ring j), rounded
+// down to a power of two (scaling by U is then exact).  Any estimate gives a correct gradient -- a poor one costs resolution
+// (too large) or overflow-list traffic (too small); non-finite or empty estimates keep prep_pair's rule.
+constexpr int kUnitGrid = 16;
+
+struct UnitSample { float direct, scatter; int valid; };
+
+// one sample source (x, y) of direction j: c = its PairCam, vj / vk the raw depth planes of its frame / the other frame
+template <int MODE>
+CD_HD UnitSample unit_sample(const PairCam& c, const float* vj, const float* vk, const float* fl, const float* mk, int H, int W, int x, int y) {
+    UnitSample u;
+    u.direct = u.scatter = 0.f; u.valid = 0;
+    const int HW = H * W, p = y * W + x;
+    const float m = mk[p];
+    if (m == 0.f) return u;
+    const float d = to_depth<MODE>(vj[p]);
+    const Taps t = tap_coords((float)x, (float)y, fl[p], fl[HW + p], c.sx, c.sy, W, H);
+    const float d00 = to_depth<MODE>(vk[t.ya * W + t.xa]), d01 = to_depth<MODE>(vk[t.ya * W + t.xb]);
+    const float d10 = to_depth<MODE>(vk[t.yb * W + t.xa]), d11 = to_depth<MODE>(vk[t.yb * W + t.xb]);
+    const float r0 = ((float)x - c.cx_r) * c.ifx_r, r1 = -((float)y - c.cy_r) * c.ify_r;
+    const float a0 = c.M[0] * r0 + c.M[1] * r1 - c.M[2], a1 = c.M[3] * r0 + c.M[4] * r1 - c.M[5], a2 = c.M[6] * r0 + c.M[7] * r1 - c.M[8];
+    const float X = d * a0 + c.c[0], Y = d * a1 + c.c[1], Z = d * a2 + c.c[2];
+    const float iZ = 1.f / Z;
+    const float ex = (c.cx_t - c.fx_t * X * iZ) - ((float)x + fl[p]), ey = (c.cy_t + c.fy_t * Y * iZ) - ((float)y + fl[HW + p]);
+    const float e2 = ex * ex + ey * ey;
+    const float ie = e2 > 0.f ? 1.f / sqrtf(e2) : 0.f;
+    const float dpx = c.fx_t * iZ * (X * a2 * iZ - a0), dpy = c.fy_t * iZ * (a1 - Y * a2 * iZ);
+    const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
+    const float izs = 1.f / zs;
+    const float direct = (fabsf(c.gr * m * (ex * dpx + ey * dpy) * ie) + fabsf(c.gb * m * a2 * iZ * iZ)) * fabsf(depth_jac<MODE>(d));
+    const float scat = fabsf(c.gb * m * izs * izs) * (t.w00 * fabsf(depth_jac<MODE>(d00)) + t.w01 * fabsf(depth_jac<MODE>(d01)) +
+                                                        t.w10 * fabsf(depth_jac<MODE>(d10)) + t.w11 * fabsf(depth_jac<MODE>(d11)));
+    if (!(direct < INFINITY) || !(scat < INFINITY)) return u;   // NaN / inf: not a sample (such inputs end on the exact paths anyway)
+    u.direct = direct; u.scatter = scat; u.valid = 1;
+    return u;
+}
+
+CD_HD float pow2_floor(float x) {   // largest power of two <= x (x a positive normal number)
+    unsigned b;
+    memcpy(&b, &x, 4);
+    b &= 0x7f800000u;
+    float r;
+    memcpy(&r, &b, 4);
+    return r;
+}
+
+// sums over the samples of both directions -> cams[0..1].{unit, dr, db, sc}
+CD_HD void units_from_samples(PairCam* cams, const float* sum_direct, const float* sum_scatter, const int* n) {
+    float U[2];
+    for (int j = 0; j < 2; ++j) {
+        const int k = 1 - j;
+        const float est = (n[j] > 0 ? sum_direct[j] / (float)n[j] : 0.f) + (n[k] > 0 ? sum_scatter[k] / (float)n[k] : 0.f);
+        U[j] = (est > 1e-30f && est < 1e30f) ? pow2_floor(est) : cams[j].unit;
+    }
+    for (int j = 0; j < 2; ++j) {
+        const int k = 1 - j;
+        cams[j].unit = U[j];
+        cams[j].dr = cams[j].gr / U[j];
+        cams[j].db = cams[j].gb / U[j];
+        cams[j].sc = cams[j].gb / U[k];
+    }
+}
+
+// the sample of grid point t (< kUnitGrid^2) of direction j of one pair (depth_p: [2][HW] raw depths; fwd / bwd flow and mask planes of the pair)
+template <int MODE>
+CD_HD UnitSample unit_sample_at(const PairCam* cams, const float* depth_p, const float* ff, const float* fb, const float* mf, const float* mb,
+                                int H, int W, int j, int t) {
+    const int iy = t / kUnitGrid, ix = t - iy * kUnitGrid;
+    const int x = (2 * ix + 1) * W / (2 * kUnitGrid), y = (2 * iy + 1) * H / (2 * kUnitGrid);
+    const int HW = H * W;
+    return unit_sample<MODE>(cams[j], depth_p + (j ? HW : 0), depth_p + (j ? 0 : HW), j ? fb : ff, j ? mb : mf, H, W, x, y);
+}
+
 // ---------------------------------------------------------------- execution state
 struct Cam {   // the fields of PairCam the sweep uses, copied once into registers
     float M[9], c[3], ifx_r, ify_r, cx_r, cy_r, fx_t, fy_t, cx_t, cy_t, sx, sy;
-    float drs, dbs, scs;   // dr, db, sc of PairCam times 2^34: the algebra produces fixed-point-ready values (exact scaling)
-    float unit_s;          // unit * 2^-34: accumulator integer -> gradient, and pre-scaled value -> gradient (overflow list)
+    float drs, dbs, scs;   // dr, db, sc of PairCam times 2^20: the algebra produces fixed-point-ready values (exact scaling)
+    float unit_s;          // unit * 2^-20: accumulator integer -> gradient, and pre-scaled value -> gradient (overflow list)
 };
 CD_HD Cam make_cam(const PairCam& p) {
     Cam c;
@@ -262,15 +343,16 @@ struct View {
     const float* mkj;          // mask of direction j
     float* gradj;              // gradient plane of frame j (w.r.t. the raw depth input)
     float* Dj; float* Dk;      // LDS depth rings [R][RW]
-    unsigned long long* Aj; unsigned long long* Ak;   // LDS accumulator rings [R][RW]
+    unsigned* Aj; unsigned* Ak;   // LDS accumulator rings [R][RW]: 32-bit fixed point (loss_math.h)
     Cam cj;                    // direction j
-    float unit_k_s;            // accumulator unit of ring k, times 2^-34
+    float unit_k_s;            // accumulator unit of ring k, times 2^-20
+    float limit;               // bound of the |.| sum of a source's pre-scaled contributions (PlanHeader::limit)
     unsigned gbj, gbk;         // element index of the two gradient planes in the whole gradient tensor (overflow list)
 };
 
 // PXT floats / accumulator words of one thread and row: ONE aligned memory or LDS access
 template <int N> struct alignas(4 * N) VecF { float v[N]; };
-template <int N> struct alignas(8 * N > 16 ? 16 : 8 * N) VecU { unsigned long long v[N]; };
+template <int N> struct alignas(4 * N) VecU { unsigned v[N]; };
 
 template <int PXT> struct Lane {   // per-thread constants
     int rr;                 // row inside a pass
@@ -345,18 +427,16 @@ template <int PXT> CD_HD void load_stage(const View& v, const Lane<PXT>& l, int 
     }
 }
 
-// rows [s_lo, s_hi) enter the ring (their values are in sv); window base w at slot ws.  Returns false if a staged depth
+// rows [s_lo, s_hi) enter the ring (their values are in sv; row r -> slot r & (R - 1)).  Returns false if a staged depth
 // is not a positive finite number (such an input takes the exact v1 path: see process_rows, "lenient").
 template <int MODE, int PXT>
-CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, int w, int ws, const float (*sv)[PXT]) {
+CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, const float (*sv)[PXT]) {
     bool good = true;
 #pragma unroll
     for (int s = 0; s < kStagePasses; ++s) {
         const int row = s_lo + s * v.RP + l.rr;
         if (l.on && row < s_hi) {
-            int slot = ws + (row - w);          // row - w <= R: at most one wrap
-            if (slot >= v.R) slot -= v.R;
-            const unsigned base = (unsigned)(slot * v.RW);
+            const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW);
             const bool img = row < v.H;         // row H is the pad row: finite depth, only ever sampled with weight 0
             VecF<PXT> d;
 #pragma unroll
@@ -372,28 +452,26 @@ CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, int
     return good;
 }
 
-// rows [lo, hi) leave the ring (lo sits in slot `slot0`): accumulator -> gradient row (one plain store), accumulator
+// rows [lo, hi) leave the ring: accumulator -> gradient row (one plain store), accumulator
 // cleared for the next tenant
 template <int PXT>
-CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi, int slot0) {
-    const double unit = (double)v.cj.unit_s;
+CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi) {
+    const float unit = v.cj.unit_s;
 #pragma unroll
     for (int s = 0; s < kStagePasses; ++s) {
         const int row = lo + s * v.RP + l.rr;
         if (l.on && row < hi) {
-            int slot = slot0 + (row - lo);
-            if (slot >= v.R) slot -= v.R;
-            const unsigned base = (unsigned)(slot * v.RW);
+            const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW);
             VecU<PXT>* ap = reinterpret_cast<VecU<PXT>*>(&v.Aj[base + l.x0]);
             const VecU<PXT> n = *ap;
             VecU<PXT> z;
             VecF<PXT> g;
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) { z.v[i] = 0ull; g.v[i] = (float)((double)(long long)n.v[i] * unit); }
+            for (int i = 0; i < PXT; ++i) { z.v[i] = 0u; g.v[i] = (float)(int)n.v[i] * unit; }
             *ap = z;
             stgv<PXT>(v.gradj, ((unsigned)(lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2, g);
             if (l.x0 == 0u)
-                for (int c = v.W; c < v.RW; ++c) v.Aj[base + (unsigned)c] = 0ull;
+                for (int c = v.W; c < v.RW; ++c) v.Aj[base + (unsigned)c] = 0u;
         }
     }
 }
@@ -401,7 +479,7 @@ CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi, int slo
 // Evaluate pass q of the source rows [p, p + G) of the wave's frame j: loss partials, direct gradient -> ring j, the 4 tap
 // contributions -> ring k.  Closed form: SURVEY.md appendix A.1 (= oracle/cd_oracle_body.inc).
 // Env supplies what differs between the GPU and the host emulation:
-//   env.add64(p, v)   64-bit LDS atomic add            env.any(x)   wave vote
+//   env.add32(p, v)   32-bit LDS atomic add            env.any(x)   wave vote
 //   env.push(need, idx, v)   wave-aggregated append to the overflow list (gradient element idx += v)
 // The pixels of a thread go through the stages TOGETHER, two at a time (coordinates -> tap reads -> algebra -> atomics):
 // independent dependency chains per wave, one wave vote per stage instead of per pixel, and -- the two pixels being adjacent
@@ -414,15 +492,14 @@ CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi, int slo
 // could differ from the reference: if any depth of the pair is not a positive finite number, the kernel raises the fallback
 // flag and the exact v1 pass recomputes gradient and loss (loss_api.hip).
 template <int MODE, bool REPROJ, int PXT, class Env>
-CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& l, const Inputs<PXT>& in, int p, int q, int wj, int wsj,
-                        int wk, int wsk, int nvk) {
+CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& l, const Inputs<PXT>& in, int p, int q, int wk, int nvk) {
     const int y = p + q * v.RP + l.rr;
     const bool rowok = pass_row_ok<PXT>(v, l, p, q);
     const Cam& cj = v.cj;
     const float yf = (float)y;
     const float r1 = -(yf - cj.cy_r) * cj.ify_r;
     const float B0 = cj.M[1] * r1 - cj.M[2], B1 = cj.M[4] * r1 - cj.M[5], B2 = cj.M[7] * r1 - cj.M[8];
-    const unsigned own = rowok ? mad24(wrapu((unsigned)(wsj + (y - wj)), (unsigned)v.R), (unsigned)v.RW, l.x0) : 0u;
+    const unsigned own = rowok ? mad24((unsigned)(y & (v.R - 1)), (unsigned)v.RW, l.x0) : 0u;
     const int R = v.R, RW = v.RW, W = v.W, H = v.H;
     VecF<PXT> dv;
     if (rowok) dv = *reinterpret_cast<const VecF<PXT>*>(&v.Dj[own]);
@@ -442,15 +519,14 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
             tp[i] = tap_coords((float)(l.x0 + b0 + i), yf, in.fx[b0 + i], in.fy[b0 + i], cj.sx, cj.sy, W, H);
             // Ring addressing uses the UNCLIPPED neighbours (xa + 1, ya + 1): the pad column / pad row hold a finite depth and
             // the clipped tap's weight is exactly 0 there, so no min() is needed on the fast path.
-            const int ra = tp[i].ya - wk;
-            const bool inside = (unsigned)ra < (unsigned)(nvk - 1);      // rows ya, ya + 1 both in [wk, wk + nvk); nvk >= 1
+            const bool inside = (unsigned)(tp[i].ya - wk) < (unsigned)(nvk - 1);      // rows ya, ya + 1 both in [wk, wk + nvk); nvk >= 1
             const bool lenient = !rowok || in.m[b0 + i] == 0.f;
             need_slow_rd = need_slow_rd || (!inside && !lenient);
-            const unsigned rac = inside ? (unsigned)ra : 0u;              // outside (lenient lanes): the window's first row, always staged
-            const unsigned sa = wrapu((unsigned)wsk + rac, (unsigned)R), sb = wrapu(sa + 1u, (unsigned)R);
-            i0[i] = mad24(sa, (unsigned)RW, (unsigned)tp[i].xa); i1[i] = mad24(sb, (unsigned)RW, (unsigned)tp[i].xa);
+            const unsigned ra = (unsigned)(inside ? tp[i].ya : wk);       // outside (lenient lanes): the window's first row, always staged
+            i0[i] = mad24(ra & (unsigned)(R - 1), (unsigned)RW, (unsigned)tp[i].xa);
+            i1[i] = mad24((ra + 1u) & (unsigned)(R - 1), (unsigned)RW, (unsigned)tp[i].xa);
         }
-        const bool slow_rd = env.any(need_slow_rd);
+        const bool slow_rd = __builtin_expect(env.any(need_slow_rd), 0);   // (hot path laid out contiguously)
 
         // ---- stage 1: the 4 depth taps of frame k
         float d00[NB], d01[NB], d10[NB], d11[NB];
@@ -463,8 +539,8 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
                 const bool exact = rowok && in.m[b0 + i] != 0.f;
                 auto tap = [&](int rq, int cq) -> float {
                     const int rel = rq - wk;
-                    if ((unsigned)rel < (unsigned)nvk) return v.Dk[wrap_slot(wsk + rel, R) * RW + cq];
-                    return exact ? to_depth<MODE>(v.vk[(unsigned)(rq * W + cq)]) : v.Dk[wsk * RW + cq];
+                    if ((unsigned)rel < (unsigned)nvk) return v.Dk[(rq & (R - 1)) * RW + cq];
+                    return exact ? to_depth<MODE>(v.vk[(unsigned)(rq * W + cq)]) : v.Dk[(wk & (R - 1)) * RW + cq];
                 };
                 d00[i] = tap(tp[i].ya, tp[i].xa); d01[i] = tap(tp[i].ya, tp[i].xb);
                 d10[i] = tap(tp[i].yb, tp[i].xa); d11[i] = tap(tp[i].yb, tp[i].xb);
@@ -491,48 +567,48 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
                 const float dpx = cj.fx_t * iZ * (X * a2 * iZ - a0), dpy = cj.fy_t * iZ * (a1 - Y * a2 * iZ);
                 gdi = cj.drs * m * (ex * dpx + ey * dpy) * ie;
             }
-            const float zs = -(d00[i] * tp[i].w00 + d01[i] * tp[i].w01 + d10[i] * tp[i].w10 + d11[i] * tp[i].w11);
-            const float izs = cd_rcp(zs);
+            // z of the sampled point = -(sum of the weighted taps); 1 / z through ONE reciprocal of the positive sum
+            const float izs = -cd_rcp(d00[i] * tp[i].w00 + d01[i] * tp[i].w01 + d10[i] * tp[i].w10 + d11[i] * tp[i].w11);
             const float dd = iZ - izs;
             sum_d += rowok ? m * fabsf(dd) : 0.f;
             const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
             const float ms = m * sg;
             gdi -= cj.dbs * ms * a2 * iZ * iZ;
             gdi *= depth_jac<MODE>(d[i]);
-            const float gz = cj.scs * ms * izs * izs;           // scatter scale, in units of ring k (times 2^34)
+            const float gz = cj.scs * ms * izs * izs;           // scatter scale, in units of ring k (times 2^20)
             c00[i] = -gz * tp[i].w00 * depth_jac<MODE>(d00[i]); c01[i] = -gz * tp[i].w01 * depth_jac<MODE>(d01[i]);
             c10[i] = -gz * tp[i].w10 * depth_jac<MODE>(d10[i]); c11[i] = -gz * tp[i].w11 * depth_jac<MODE>(d11[i]);
             gd[i] = gdi;
             // inside the fixed-point range?  (a sum, not a max: NaN must fail the test)
-            const bool fits = fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]) + fabsf(gdi) <= SWEEP_FX_LIMIT_SCALED;
+            const bool fits = fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]) + fabsf(gdi) <= v.limit;
             need_slow = need_slow || (rowok && !fits);
         }
-        const bool slow = slow_rd || env.any(need_slow);
+        const bool slow = __builtin_expect(slow_rd || env.any(need_slow), 0);
 
         // ---- stage 3: 5 integer LDS atomics per pixel
         if (!slow) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (rowok) {
-                    env.add64(&v.Aj[own + (unsigned)(b0 + i)], sweep_scaled_to_fixed(gd[i]));
+                    env.add32(&v.Aj[own + (unsigned)(b0 + i)], sweep_scaled_to_fixed(gd[i]));
                     if (in.m[b0 + i] != 0.f) {
-                        env.add64(&v.Ak[i0[i]], sweep_scaled_to_fixed(c00[i])); env.add64(&v.Ak[i0[i] + 1], sweep_scaled_to_fixed(c01[i]));
-                        env.add64(&v.Ak[i1[i]], sweep_scaled_to_fixed(c10[i])); env.add64(&v.Ak[i1[i] + 1], sweep_scaled_to_fixed(c11[i]));
+                        env.add32(&v.Ak[i0[i]], sweep_scaled_to_fixed(c00[i])); env.add32(&v.Ak[i0[i] + 1], sweep_scaled_to_fixed(c01[i]));
+                        env.add32(&v.Ak[i1[i]], sweep_scaled_to_fixed(c10[i])); env.add32(&v.Ak[i1[i] + 1], sweep_scaled_to_fixed(c11[i]));
                     }
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const bool dfit = fabsf(gd[i]) <= SWEEP_FX_LIMIT_SCALED;
-                if (rowok && dfit) env.add64(&v.Aj[own + (unsigned)(b0 + i)], sweep_scaled_to_fixed(gd[i]));
+                const bool dfit = fabsf(gd[i]) <= v.limit;
+                if (rowok && dfit) env.add32(&v.Aj[own + (unsigned)(b0 + i)], sweep_scaled_to_fixed(gd[i]));
                 env.push(rowok && !dfit, v.gbj + (unsigned)(y * W) + l.x0 + (unsigned)(b0 + i), gd[i] * cj.unit_s);
                 const bool a = rowok;
                 auto scatter = [&](int rq, int cq, float cv) {
                     const int rel = rq - wk;
                     const bool live = a && cv != 0.f;                        // NaN != 0: it propagates like in the reference
-                    const bool in_ring = (unsigned)rel < (unsigned)nvk && fabsf(cv) <= SWEEP_FX_LIMIT_SCALED;
-                    if (live && in_ring) env.add64(&v.Ak[wrap_slot(wsk + rel, R) * RW + cq], sweep_scaled_to_fixed(cv));
+                    const bool in_ring = (unsigned)rel < (unsigned)nvk && fabsf(cv) <= v.limit;
+                    if (live && in_ring) env.add32(&v.Ak[(rq & (R - 1)) * RW + cq], sweep_scaled_to_fixed(cv));
                     env.push(live && !in_ring, v.gbk + (unsigned)(rq * W + cq), cv * v.unit_k_s);
                 };
                 scatter(tp[i].ya, tp[i].xa, c00[i]); scatter(tp[i].ya, tp[i].xb, c01[i]);
@@ -547,6 +623,12 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
 CD_HD void tap_rows(float xf, float yf, float fx, float fy, int W, int H, int* ya, int* yb) {
     const Taps t = tap_coords(xf, yf, fx, fy, (float)W / (float)(W - 1), (float)H / (float)(H - 1), W, H);
     *ya = t.ya; *yb = t.ya + 1;   // the unclipped neighbour row: what the fast path addresses (row H = the pad row)
+}
+
+// the 4 target pixels (unclipped neighbours: column W / row H are the pad column / row) a valid source adds to
+CD_HD void tap_targets(float xf, float yf, float fx, float fy, int W, int H, int* xa, int* ya) {
+    const Taps t = tap_coords(xf, yf, fx, fy, (float)W / (float)(W - 1), (float)H / (float)(H - 1), W, H);
+    *xa = t.xa; *ya = t.ya;
 }
 
 }  // namespace sweep

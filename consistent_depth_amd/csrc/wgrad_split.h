@@ -12,7 +12,7 @@ __host__ __device__ constexpr int wgrad_split_blocks_per_cu(int ks) { return ks 
 // partial sums into packed[split][co group][ci group][tap][16][16]; `splits` blocks per channel-group pair
 int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,
                        const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int ks, int splits,
-                       hipStream_t s);
+                       hipStream_t s, int groups = 1, size_t ws_group_stride = 0);   // groups > 1: Cin / Cout per group, slices g * Cin / g * Cout
 
 // ---- 1x1 weight gradient (wgrad1x1_split.hip): a wave owns a 64 x 128 (co x ci) patch of dW
 constexpr int WGRAD1X1_COB = 64, WGRAD1X1_CIB = 128;

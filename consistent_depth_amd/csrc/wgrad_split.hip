@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
-    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y) {
+    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y, int cogs, int g_xc, int g_dyc, size_t g_ws) {
     using Cfg = WsCfg<KS>;
     constexpr int TY = Cfg::TY, P = Cfg::P, TAPS = Cfg::TAPS, TPW = Cfg::TPW, ROWS = Cfg::ROWS, PSX = Cfg::PSX, PSD = Cfg::PSD;
     constexpr int SPX = Cfg::SPX, SPD = Cfg::SPD, NT = Cfg::NW * 64;
@@ -114,7 +114,13 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
     unsigned* s_x = ws_smem;               // [3][16 ci][PSX]
     unsigned* s_dy = ws_smem + 3 * SPX;    // [3][16 co][PSD]
 
-    const int cig = blockIdx.y, cog = blockIdx.z;
+    // blockIdx.z = group * cogs + cog: a grouped convolution is `groups` independent gradients on channel slices, each with its
+    // own packed workspace (g_ws floats apart); dense launches have one group
+    const int grp = blockIdx.z / cogs;
+    const int cig = blockIdx.y, cog = blockIdx.z - grp * cogs;
+    x_coff += grp * g_xc;
+    dy_coff += grp * g_dyc;
+    dw_packed += (size_t)grp * g_ws;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t HW = (size_t)H * W;
     const int items = N * tiles_x * tiles_y;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
     }
 
     // ---- flush: this block's slice, packed [split][cog][cig][tap][16 co][16 ci]
-    const size_t slice = (size_t)gridDim.z * gridDim.y * TAPS * 256;
+    const size_t slice = (size_t)cogs * gridDim.y * TAPS * 256;
     const size_t base = (size_t)blockIdx.x * slice + ((size_t)cog * gridDim.y + cig) * TAPS * 256;
     const int ci_l = lane & 15, co4 = (lane >> 4) * 4;
 #pragma unroll
@@ -224,7 +230,8 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
 
 template <int KS>
 static int launch_ws(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,
-                     const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int splits, hipStream_t s) {
+                     const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int splits, hipStream_t s,
+                     int groups, size_t ws_group_stride) {
     using Cfg = WsCfg<KS>;
     const int tiles_x = (W + 31) / 32, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
     const int cogs = (Cout + 15) / 16, cigs = (Cin + 15) / 16;
@@ -233,18 +240,19 @@ static int launch_ws(const float* x, int x_ctot, int x_coff, int Cin, const floa
         (void)hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_split_kernel<KS>), dim3(splits, cigs, cogs), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ctot, x_coff, Cin, in_scale,
-                       in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv_wgrad_split_kernel<KS>), dim3(splits, cigs, cogs * groups), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ctot, x_coff, Cin, in_scale,
+                       in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y, cogs, groups > 1 ? Cin : 0,
+                       groups > 1 ? Cout : 0, ws_group_stride);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
 int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,
                        const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int ks, int splits,
-                       hipStream_t s) {
-    if (ks == 11) return launch_ws<11>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
-    if (ks == 7) return launch_ws<7>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
-    if (ks == 3) return launch_ws<3>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
-    if (ks == 5) return launch_ws<5>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s);
+                       hipStream_t s, int groups, size_t ws_group_stride) {
+    if (ks == 11) return launch_ws<11>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+    if (ks == 7) return launch_ws<7>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+    if (ks == 3) return launch_ws<3>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+    if (ks == 5) return launch_ws<5>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
     return CD_ERR_UNSUPPORTED;
 }
 

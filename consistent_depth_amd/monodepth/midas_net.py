@@ -117,6 +117,13 @@ class MidasNet(nn.Module):
         finally:
             _CONV[0] = nn.Conv2d
         self.backend = backend
+        self._pack_pool = None
+        if backend == "hip":     # every filter of the network is packed by ONE launch per forward (ops/conv_layer.py::PackPool)
+            from ..ops.conv_layer import HipConv2d, PackPool
+            self._pack_pool = PackPool()
+            for m in self.modules():
+                if isinstance(m, HipConv2d):
+                    self._pack_pool.register(m)
         if path:
             self.load_state_dict(torch.load(path, map_location="cpu"))
 
@@ -132,6 +139,8 @@ class MidasNet(nn.Module):
             Conv2d(32, 1, 1, 1, 0), nn.ReLU(True) if non_negative else nn.Identity())
 
     def forward(self, x):
+        if self._pack_pool is not None:
+            self._pack_pool.run()
         l1 = self.pretrained.layer1(x)
         l2 = self.pretrained.layer2(l1)
         l3 = self.pretrained.layer3(l2)

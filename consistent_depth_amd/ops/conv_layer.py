@@ -4,20 +4,70 @@
 Same parameters and state_dict keys as nn.Conv2d (a checkpoint loads unchanged).  Supported: square kernels 1/3/5/7/11,
 "same" padding (k-1)/2, stride 1 or 2, any `groups`:
   * groups (ResNeXt's 32 x 8d 3x3): every group is a dense convolution on a channel slice of the SAME input / output
-    buffers (the kernels address (tensor, channel offset, channels)), one launch per group -- correct and on the matrix
-    cores; a fused grouped kernel is the known next step (at 8 channels per group a 16-wide MFMA tile is half empty);
+    buffers (the kernels address (tensor, channel offset, channels)); ALL groups run in ONE launch per pass
+    (cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped: the group is a grid dimension of the split-bf16 kernels) -- round 2
+    issued one launch per group (32 x 33 bottlenecks x {forward, input gradient, weight gradient + unpack} = 4224 launches
+    per step, which made the MiDaS step host-bound: 222 ms of enqueue for a 243 ms step).  At 8 channels per group a
+    16-wide MFMA column tile is half empty;
   * stride 2: the stride-1 "same" output sampled at even positions (identical values; 4x the MACs of a strided kernel --
     only the stem, 3 bottlenecks and 3 down-sample 1x1 of ResNeXt-101 are strided).
-Filters are re-packed by ONE table launch per forward (weights move under the optimiser), the packed buffers are
-allocated once per layer.
+  * 1x1, dense (the bottleneck entry / exit convolutions: 2/3 of ResNeXt-101's multiply-adds, at 24x24 .. 96x96 images with
+    256 .. 2048 channels): a plain GEMM  Y[n] = W [Cout x Cin] . X[n] [Cin x HW]  -- not a stencil.  The staged fp32-MFMA 1x1
+    kernel of the hourglass (built for 128 -> 208 channels at 384x224) ran them at ~15 TFLOP/s; they go to the GEMM library
+    (rocBLAS / hipBLASLt through torch.matmul: forward, input gradient and ONE weight-gradient GEMM over all images), which is what
+    a plain GEMM is for.  Stride-2 1x1 (the down-sample paths) sub-sample FIRST (exact, 4x fewer multiply-adds).
+    `CD_AMD_MIDAS_1X1=hip` keeps the hand-written 1x1 kernels (A/B).
+Filters are re-packed once per forward (weights move under the optimiser): a `PackPool` shared by the layers of a network
+packs EVERY filter of the network, forward and transposed layouts, in ONE table launch (round 2: two launches of 16 workgroups
+per layer and pass -- 53 ms of a 211 ms MiDaS step); a layer outside a pool packs its own filters.
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 
+import os
+
 from .. import _native
 from . import conv as C
+
+
+class PackPool:
+    """All HipConv2d layers of one network: their filters (forward + transposed layouts, every group) are packed by ONE
+    cd_conv2d_pack_weights_table launch per `run()` -- call it once per forward, before the first layer."""
+
+    def __init__(self):
+        self.layers, self._table, self._key, self.fresh = [], None, None, False
+
+    def register(self, layer):
+        self.layers.append(layer)
+        layer._pool = self
+
+    def run(self):
+        layers = [l for l in self.layers if l._uses_packed()]
+        key = tuple(l.weight.data_ptr() for l in layers)
+        if key != self._key:      # first use, or the optimiser re-homed the parameters: rebuild the descriptors
+            tabs = []
+            for l in layers:
+                w = l.weight
+                if not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32):
+                    raise RuntimeError("HipConv2d: weights must be contiguous fp32 on the HIP device (no CPU path)")
+                l._pk, tab, l._arena = l._build(w, False)
+                l._pkT, tabT, l._arenaT = l._build(w, True)
+                l._wptr = w.data_ptr()
+                tabs += [tab, tabT]
+            self._table = torch.cat(tabs).contiguous()
+            self._n = sum(2 * l.groups for l in layers)
+            self._key = key
+        if self._n > 65535:
+            raise RuntimeError("PackPool: too many filters for one table launch")
+        lib = _native.lib()
+        _native.check(lib.cd_conv2d_pack_weights_table(self._table.data_ptr(), self._n, _native.stream_ptr(self._table.device)),
+                      "cd_conv2d_pack_weights_table")
+        self.fresh = True
+
+    def invalidate(self):
+        self.fresh = False
 
 
 class _HipConvFn(torch.autograd.Function):
@@ -32,11 +82,9 @@ class _HipConvFn(torch.autograd.Function):
         pk, _ = layer._packed(weight)
         y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
         bptr = _native.dev_ptr(bias, "bias") if bias is not None else None
-        for g in range(G):
-            rc = lib.cd_conv2d_fwd(_native.dev_ptr(x, "x"), Cin, g * cin_g, cin_g, pk[g].data_ptr(),
-                                   (bptr + 4 * g * cout_g) if bptr is not None else None, None, None, 0, y.data_ptr(), Cout, g * cout_g,
-                                   cout_g, None, 0, N, H, W, ks, stream)
-            _native.check(rc, "cd_conv2d_fwd")
+        rc = lib.cd_conv2d_fwd_grouped(_native.dev_ptr(x, "x"), Cin, 0, cin_g, pk[0].data_ptr(), layer._pack_stride, bptr, y.data_ptr(), Cout, 0,
+                                       cout_g, G, 0, N, H, W, ks, stream)
+        _native.check(rc, "cd_conv2d_fwd_grouped")
         ctx.layer, ctx.hw = layer, (H, W)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -60,17 +108,15 @@ class _HipConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, pkT = layer._packed(weight, transposed_too=True)
             dx = torch.empty_like(x)
-            for g in range(G):
-                rc = lib.cd_conv2d_fwd(dyf.data_ptr(), Cout, g * cout_g, cout_g, pkT[g].data_ptr(), None, None, None, 0, dx.data_ptr(), Cin,
-                                       g * cin_g, cin_g, None, 0, N, H, W, ks, stream)
-                _native.check(rc, "cd_conv2d_fwd (dgrad)")
+            rc = lib.cd_conv2d_fwd_grouped(dyf.data_ptr(), Cout, 0, cout_g, pkT[0].data_ptr(), layer._pack_strideT, None, dx.data_ptr(), Cin, 0,
+                                           cin_g, G, 0, N, H, W, ks, stream)
+            _native.check(rc, "cd_conv2d_fwd_grouped (dgrad)")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            ws = layer._wgrad_workspace(cout_g, cin_g, ks, x.device)
-            for g in range(G):
-                rc = lib.cd_conv2d_wgrad(_native.dev_ptr(x, "x"), Cin, g * cin_g, cin_g, None, None, 0, dyf.data_ptr(), Cout, g * cout_g, cout_g,
-                                         dw.data_ptr() + 4 * g * cout_g * cin_g * ks * ks, 0, ws.data_ptr(), N, H, W, ks, stream)
-                _native.check(rc, "cd_conv2d_wgrad")
+            ws, ws_stride = layer._wgrad_workspace(cout_g, cin_g, ks, x.device)
+            rc = lib.cd_conv2d_wgrad_grouped(_native.dev_ptr(x, "x"), Cin, 0, cin_g, dyf.data_ptr(), Cout, 0, cout_g, G, dw.data_ptr(), 0,
+                                             ws.data_ptr(), ws_stride, N, H, W, ks, stream)
+            _native.check(rc, "cd_conv2d_wgrad_grouped")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None
@@ -83,7 +129,12 @@ class HipConv2d(torch.nn.Conv2d):
         if not (k[0] == k[1] and k[0] in C.KERNEL_SIZES and s[0] == s[1] and s[0] in (1, 2) and p[0] == p[1] == (k[0] - 1) // 2
                 and self.dilation == (1, 1) and self.padding_mode == "zeros"):
             raise ValueError(f"HipConv2d: unsupported geometry kernel {k} stride {s} padding {p}")
-        self._pk = self._pkT = self._table = self._tableT = self._wptr = self._ws = None
+        self._pk = self._pkT = self._table = self._tableT = self._wptr = self._ws = self._pool = None
+        # dense 1x1: a GEMM (see the module docstring)
+        self._gemm = k[0] == 1 and self.groups == 1 and os.environ.get("CD_AMD_MIDAS_1X1", "gemm") != "hip"
+
+    def _uses_packed(self):
+        return not self._gemm
 
     def _build(self, weight, transposed):
         """Packed buffers of every group (zeroed once: padding elements are never written) + the pack table."""
@@ -99,11 +150,17 @@ class HipConv2d(torch.nn.Conv2d):
         tab = np.zeros(self.groups, dt)
         for g in range(self.groups):
             tab[g] = (weight.data_ptr() + 4 * g * cout_g * cin_g * ks * ks, views[g].data_ptr(), cout_g, cin_g, ks, int(transposed), oc, ic, 0, 0)
+        if transposed:
+            self._pack_strideT = n
+        else:
+            self._pack_stride = n
         return views, torch.from_numpy(tab.view(np.uint8).copy()).to(weight.device), arena
 
     def _packed(self, weight, transposed_too=False):
         if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32):
             raise RuntimeError("HipConv2d: weights must be contiguous fp32 on the HIP device (no CPU path)")
+        if self._pool is not None and self._pool.fresh and self._wptr == weight.data_ptr():
+            return self._pk, self._pkT      # packed by the pool's single launch at the start of this forward
         if self._wptr != weight.data_ptr():       # first use, or the optimiser re-homed the parameter
             self._pk, self._table, self._arena = self._build(weight, False)
             self._pkT = self._tableT = None
@@ -118,9 +175,57 @@ class HipConv2d(torch.nn.Conv2d):
         return self._pk, self._pkT
 
     def _wgrad_workspace(self, cout_g, cin_g, ks, device):
+        """(buffer, floats per group): every group's per-workgroup partial sums side by side."""
         if self._ws is None:
-            self._ws = C.wgrad_workspace(cout_g, cin_g, ks, device)
+            n = (_native.lib().cd_conv2d_wgrad_workspace_floats(cout_g, cin_g, ks) + 63) // 64 * 64
+            self._ws = (torch.empty(self.groups * n, dtype=torch.float32, device=device), n)
         return self._ws
 
     def forward(self, x):
+        if self._gemm:
+            if not x.is_cuda:
+                raise RuntimeError("HipConv2d: no CPU path")
+            return _Gemm1x1Fn.apply(x, self.weight, self.bias, self.stride[0])
         return _HipConvFn.apply(x, self.weight, self.bias, self)
+
+
+class _Gemm1x1Fn(torch.autograd.Function):
+    """1x1 convolution as GEMMs on the library (rocBLAS / hipBLASLt): Y[n] = W X[n]; dX[n] = W^T dY[n]; dW = dY_all X_all^T with the
+    images concatenated along the reduction dimension (ONE GEMM with K = N H W instead of N products and a sum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        ctx.in_hw = tuple(x.shape[2:])
+        if stride > 1:
+            x = x[:, :, ::stride, ::stride]
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.matmul(weight.view(Cout, Cin), x.view(N, Cin, H * W)).view(N, Cout, H, W)
+        if bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(weight.view(Cout, Cin).t(), dy.view(N, Cout, H * W)).view(N, Cin, H, W)
+            if ctx.stride > 1:
+                s = ctx.stride
+                full = torch.zeros((N, Cin) + ctx.in_hw, dtype=dx.dtype, device=dx.device)   # adjoint of the sub-sampling
+                full[:, :, ::s, ::s] = dx
+                dx = full
+        if ctx.needs_input_grad[1]:
+            dyt = dy.view(N, Cout, H * W).transpose(0, 1).reshape(Cout, N * H * W)
+            xt = x.view(N, Cin, H * W).transpose(0, 1).reshape(Cin, N * H * W)
+            dw = torch.matmul(dyt, xt.t()).view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None

@@ -247,6 +247,21 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
                       const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                       float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                       int N, int H, int W, int ks, int tile_rows, int co_tiles, void* stream);
+/* Grouped convolution (nn.Conv2d(groups=G), ResNeXt's 32 x 8d 3x3 of the MiDaS v2 encoder, reference call site
+ * monodepth/midas_v2_model.py:61): group g is a dense convolution of input channels [x_coff + g*cin_g, +cin_g) into output channels
+ * [y_coff + g*cout_g, +cout_g) with its own packed filter at packed_w + g*packed_group_stride (floats; each packed by
+ * cd_conv2d_pack_weights[_table] for (cout_g, cin_g, ks), stride a multiple of 4 and >= cd_conv2d_packed_weight_floats) -- ONE launch
+ * for all groups in the split arithmetic modes (k >= 3, cin_g >= 8), the dense kernels group by group otherwise.  The input gradient
+ * is the same call on the transposed packs with the roles of x / y swapped.  bias: [groups*cout_g] or NULL. */
+int cd_conv2d_fwd_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* packed_w, size_t packed_group_stride,
+                          const float* bias, float* y, int y_ctot, int y_coff, int cout_g, int groups, int accumulate, int N, int H, int W,
+                          int ks, void* stream);
+/* dw [groups*cout_g][cin_g][ks][ks] (+)= the weight gradient of the grouped convolution; workspace: groups * workspace_group_stride
+ * floats, workspace_group_stride >= cd_conv2d_wgrad_workspace_floats(cout_g, cin_g, ks). */
+int cd_conv2d_wgrad_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* dy, int dy_ctot, int dy_coff, int cout_g,
+                            int groups, float* dw, int accumulate, float* workspace, size_t workspace_group_stride, int N, int H, int W,
+                            int ks, void* stream);
+
 /* Arithmetic of the convolutions (forward, input gradient and weight gradient), process-wide; start-up value from
  * CD_AMD_CONV_ARITH = "split" (2, default) | "split3" (1) | "fp32" (0):
  *   1: k = 3, 5, 7, 11 with >= 8 input channels: every fp32 operand is split exactly into three bf16 terms and the six

@@ -56,6 +56,17 @@ def plan(g, flow_fwd, flow_bwd, mask_fwd, mask_bwd):
     return items[:n], lo, hi
 
 
+class FanInTooHigh(RuntimeError):
+    pass
+
+
+def fan_in(g, flow_fwd, flow_bwd, mask_fwd, mask_bwd):
+    """Max number of valid sources that add to one target pixel of ONE pair (what the plan kernel counts)."""
+    c = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
+    ff, fb, mf, mb = c(flow_fwd), c(flow_bwd), c(mask_fwd), c(mask_bwd)
+    return lib().sweep_emul_fan_in(g["_raw"], _p(ff), _p(fb), _p(mf), _p(mb))
+
+
 def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False, order=0):
     c = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
     depth = c(batch["depth"])
@@ -70,6 +81,9 @@ def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False
     fn.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_float, ctypes.c_float] + [ctypes.c_int] * 7 + [ctypes.c_void_p] * 5
     rc = fn(_p(depth), _p(ff), _p(fb), _p(mf), _p(mb), _p(intr), _p(extr), lambda_r, lambda_b, mode, B, H, W, pxt, ring_rows,
             int(force_slow), _p(reproj), _p(disp), _p(total), _p(grad), stats)
+    if rc == -11:
+        raise FanInTooHigh("a target pixel receives more sources than a 32-bit accumulator can take: the product gives such a pair no plan "
+                           "and recomputes it on the exact fallback path")
     if rc != 0:
         raise RuntimeError(f"sweep emulation failed: rc={rc}")
     return {"total": total, "reprojection": reproj, "disparity": disp, "grad_depth": grad,

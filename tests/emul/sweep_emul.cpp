@@ -27,7 +27,7 @@ struct HostEnv {
     long* n_push;
     bool* degen;
     void degenerate() { *degen = true; }
-    static void add64(unsigned long long* p, unsigned long long v) { *p += v; }
+    static void add32(unsigned* p, int v) { *p += (unsigned)v; }
     bool any(bool x) {
         if (x) ++*n_slow;
         return x || force_slow;
@@ -53,13 +53,35 @@ void group_bounds(const Geo& g, const float* flow, const float* mask, short* lo,
         }
 }
 
+// max number of valid sources adding to one target pixel (the fan-in count of sweep_plan_kernel), both directions
+int fan_in_of(const Geo& g, const float* ff, const float* fb, const float* mf, const float* mb) {
+    const int H = g.H, W = g.W, cw = W + 1;
+    int fmax = 0;
+    for (int f = 0; f < 2; ++f) {
+        std::vector<int> cnt((size_t)(H + 1) * cw, 0);
+        const float* fl = f ? fb : ff;
+        const float* mk = f ? mb : mf;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const int p = y * W + x;
+                if (mk[p] == 0.f) continue;
+                int xa, ya;
+                tap_targets((float)x, (float)y, fl[p], fl[H * W + p], W, H, &xa, &ya);
+                for (int dy = 0; dy < 2; ++dy) { ++cnt[(ya + dy) * cw + xa]; ++cnt[(ya + dy) * cw + xa + 1]; }
+            }
+        for (int c : cnt) fmax = c > fmax ? c : fmax;
+    }
+    return fmax;
+}
+
 template <int MODE, bool REPROJ, int PXT>
 int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* fb, const float* mf, const float* mb,
              const PairCam* cams, const Item* raw_items, int n_items, unsigned gbase0, float* grad_p, float* partial,
              HostEnv& env) {
+    const float limit = sweep_limit_scaled(fan_in_of(g, ff, fb, mf, mb));
     const int H = g.H, W = g.W, HW = H * W, ring = g.R * g.RW;
     std::vector<float> D(2 * (size_t)ring, 0.f);
-    std::vector<unsigned long long> A(2 * (size_t)ring, 0ull);
+    std::vector<unsigned> A(2 * (size_t)ring, 0u);
     std::vector<PlanItem> items(n_items);
     expand_plan(g, raw_items, n_items, items.data());
     View vw[2];
@@ -73,6 +95,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
         v.Dj = D.data() + (f ? ring : 0); v.Dk = D.data() + (f ? 0 : ring);
         v.cj = make_cam(cams[f]); v.unit_k_s = cams[1 - f].unit * (1.f / SWEEP_FX_ONE_F);
         v.gbj = gbase0 + (f ? HW : 0); v.gbk = gbase0 + (f ? 0 : HW);
+        v.limit = limit;
     }
     std::vector<Regs<PXT>> regs(kThreads);
     std::vector<Lane<PXT>> lanes(kThreads);
@@ -89,7 +112,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
         for (int t = 0; t < kThreads; ++t) {
             float sv[kStagePasses][PXT];
             load_stage<PXT>(vw[fr[t]], lanes[t], lo, hi, sv);
-            regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], lo, hi, 0, 0, sv) || regs[t].bad;
+            regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], lo, hi, sv) || regs[t].bad;
         }
     }
     int wlast[2] = {0, 0};
@@ -123,13 +146,13 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
                         const Rec& ot = items[it].f[1 - f];
                         Inputs<PXT> in;
                         load_inputs<PXT>(vw[f], lanes[t], me.p, q, in);
-                        process_rows<MODE, REPROJ, PXT>(vw[f], env, regs[t], lanes[t], in, me.p, q, me.w, me.ws, ot.w, ot.ws, ot.nv);
+                        process_rows<MODE, REPROJ, PXT>(vw[f], env, regs[t], lanes[t], in, me.p, q, ot.w, ot.nv);
                     }
             } else {
                 for (int t = 0; t < kThreads; ++t) {
                     const Rec& me = items[it].f[fr[t]];
-                    regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], me.s_lo, me.s_hi, me.w, me.ws, regs[t].sv) || regs[t].bad;
-                    flush_rows<PXT>(vw[fr[t]], lanes[t], me.fl_lo, me.fl_hi, me.fl_slot);
+                    regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], me.s_lo, me.s_hi, regs[t].sv) || regs[t].bad;
+                    flush_rows<PXT>(vw[fr[t]], lanes[t], me.fl_lo, me.fl_hi);
                 }
             }
         }
@@ -141,7 +164,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
     for (int f = 0; f < 2; ++f)
         if (wlast[f] < H) { fprintf(stderr, "emul: rows left in ring %d\n", f); return -5; }
     for (size_t i = 0; i < A.size(); ++i)
-        if (A[i] != 0ull) { fprintf(stderr, "emul: accumulator not drained at %zu\n", i); return -6; }
+        if (A[i] != 0u) { fprintf(stderr, "emul: accumulator not drained at %zu\n", i); return -6; }
     double ar[2] = {0, 0}, ad[2] = {0, 0};
     for (int t = 0; t < kThreads; ++t) { ar[fr[t]] += (float)regs[t].acc_r; ad[fr[t]] += (float)regs[t].acc_d; if (regs[t].bad) env.degenerate(); }
     for (int f = 0; f < 2; ++f) { partial[f * 2] = (float)ar[f]; partial[f * 2 + 1] = (float)ad[f]; }
@@ -169,11 +192,17 @@ int run_pair_m(int mode, bool reproj, const Geo& g, const float* depth_p, const 
 
 extern "C" {
 
+int sweep_emul_fan_in(const int* geo, const float* ff, const float* fb, const float* mf, const float* mb) {
+    Geo g; memcpy(&g, geo, sizeof(g));
+    return fan_in_of(g, ff, fb, mf, mb);
+}
+
 void sweep_emul_set_order(int order) { g_order = order ? 1 : 0; }
 
 // geometry as the kernel would choose it: out[0..11] = the Geo fields; ring_rows > 0 overrides R (to force tiny rings)
 int sweep_emul_geo(int H, int W, int pxt, int ring_rows, int* out) {
     Geo g = make_geo(H, W, pxt);
+    if (ring_rows > 0 && (ring_rows & (ring_rows - 1))) return 0;   // rings are direct mapped: a power of two
     if (ring_rows > 0 && g.CG > 0) {   // same rules as make_geo with a smaller ring
         g.R = ring_rows;
         g.G = kGroupPasses * g.RP < (g.R - 8) / 3 ? kGroupPasses * g.RP : (g.R - 8) / 3;
@@ -228,7 +257,24 @@ int sweep_emul_loss(const float* depth, const float* ff, const float* fb, const 
         fbar[k] = acc / (2.f * (float)B);
     }
     std::vector<PairCam> cams(B * 2);
-    for (int b = 0; b < B; ++b) prep_pair(intr + b * 8, extr + b * 24, msum.data() + b * 2, fbar, lambda_r, lambda_b, B, H, W, cams.data() + b * 2);
+    for (int b = 0; b < B; ++b) {
+        prep_pair(intr + b * 8, extr + b * 24, msum.data() + b * 2, fbar, lambda_r, lambda_b, B, H, W, cams.data() + b * 2);
+        // sweep_units_kernel: the accumulator units from a 16 x 16 grid of sample sources per direction, summed in index order
+        float D[2] = {0.f, 0.f}, S[2] = {0.f, 0.f};
+        int n[2] = {0, 0};
+        for (int j = 0; j < 2; ++j)
+            for (int t = 0; t < kUnitGrid * kUnitGrid; ++t) {
+                const float* dp = depth + (size_t)b * 2 * HW;
+                const float* ffb = ff + (size_t)b * 2 * HW; const float* fbb = fb + (size_t)b * 2 * HW;
+                const float* mfb = mf + (size_t)b * HW; const float* mbb = mb + (size_t)b * HW;
+                UnitSample u;
+                if (mode == kDepthExp) u = unit_sample_at<kDepthExp>(cams.data() + b * 2, dp, ffb, fbb, mfb, mbb, H, W, j, t);
+                else if (mode == kDepthReciprocal) u = unit_sample_at<kDepthReciprocal>(cams.data() + b * 2, dp, ffb, fbb, mfb, mbb, H, W, j, t);
+                else u = unit_sample_at<kDepthIdentity>(cams.data() + b * 2, dp, ffb, fbb, mfb, mbb, H, W, j, t);
+                D[j] += u.direct; S[j] += u.scatter; n[j] += u.valid;
+            }
+        units_from_samples(cams.data() + b * 2, D, S, n);
+    }
     std::vector<unsigned> oidx;
     std::vector<float> oval;
     long n_slow = 0, n_push = 0, n_items_total = 0;
@@ -241,6 +287,7 @@ int sweep_emul_loss(const float* depth, const float* ff, const float* fb, const 
         const float* mfb = mf + (size_t)b * HW; const float* mbb = mb + (size_t)b * HW;
         const int n = sweep_emul_plan(gi, ffb, fbb, mfb, mbb, items_raw.data(), nullptr, nullptr);
         if (n <= 0) return -10;
+        if (fan_in_of(g, ffb, fbb, mfb, mbb) > SWEEP_MAX_FAN_IN) return -11;   // the product takes the exact fallback path for such a pair
         n_items_total += n;
         std::vector<Item> items(n);
         for (int i = 0; i < n; ++i) { items[i].p[0] = items_raw[i * 4]; items[i].p[1] = items_raw[i * 4 + 1]; items[i].w[0] = items_raw[i * 4 + 2]; items[i].w[1] = items_raw[i * 4 + 3]; }

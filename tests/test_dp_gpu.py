@@ -38,9 +38,32 @@ w = eager.opt.flat_param
 ws = [torch.zeros_like(w) for _ in range(world)]
 torch.distributed.all_gather(ws, w)
 same = all(torch.equal(ws[0], x) for x in ws)
+global_batch = None
+if rank == 0:
+    # The same steps as ONE process that owns the global batch: the two ranks' shards evaluated one after the other on the same
+    # weights (BatchNorm statistics stay per shard, like on the ranks), gradients and losses SUMMED, one guarded Adam step with
+    # the 1/world factor -- through the same FineTuneStep pieces.  fp32 addition of two buffers is commutative, so the weights
+    # must come out bit for bit.
+    model1 = get_depth_model("mc")(seed=0); model1.train()
+    one = FineTuneStep(model1, params, world=1)
+    for it in range(%(iters)d):
+        gsum, lsum = torch.zeros_like(one.opt.flat_grad), torch.zeros(1, device=dev)
+        for r in range(world):
+            b = synthetic.make_scene_batch(2, 64, 48, seed=10 * it + r)
+            imgs = torch.rand(2, 2, 3, 64, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(100 * it + r))
+            meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
+                    "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
+            guard, _ = one._grads(imgs, meta)
+            gsum += one.opt.flat_grad
+            lsum += guard.reshape(1)
+        one.opt.flat_grad.copy_(gsum)
+        one.opt.step(grad_scale=1.0 / world, guard_loss=lsum)
+    d = (one.opt.flat_param - w).abs()
+    global_batch = {"bitwise": bool(torch.equal(one.opt.flat_param, w)), "max_abs": float(d.max())}
 if rank == 0:
     print("RESULT " + json.dumps({"world": world, "same_weights": same, "losses": losses, "steps": int(eager.opt.step_dev.item()),
-                                  "graphed": getattr(step, "graphed", None), "capture_error": getattr(step, "capture_error", None)}))
+                                  "graphed": getattr(step, "graphed", None), "capture_error": getattr(step, "capture_error", None),
+                                  "global_batch": global_batch}))
 torch.distributed.barrier(); torch.distributed.destroy_process_group()
 """
 
@@ -62,6 +85,10 @@ def test_two_ranks_share_one_gpu_and_stay_in_sync(tmp_path, graph):
         assert res["graphed"] is True, res["capture_error"]
     assert res["same_weights"], "ranks diverged: the gradient all-reduce / guarded Adam are not in lock-step"
     assert all(l == l for l in res["losses"])
+    # 2 ranks x B pairs == 1 process with the 2B global batch (shards evaluated in turn), through FineTuneStep: same weights
+    gb = res["global_batch"]
+    assert gb["max_abs"] <= 1e-7, gb
+    print("2 ranks vs one process with the global batch:", gb)
 
 
 NCCL_WORKER = r"""

@@ -128,3 +128,42 @@ def test_midas_one_finetune_step():
     with torch.no_grad():
         depth = model.forward(torch.rand(1, 2, 3, 64, 64, device="cuda"))
     assert depth.shape == (1, 2, 64, 64) and torch.isfinite(depth).all() and (depth > 0).all()
+
+
+def test_pack_pool_follows_the_weights():
+    """ops/conv_layer.py::PackPool: ONE pack launch per forward covers every filter of the network (forward and transposed
+    layouts).  The packed copies must track the parameters through in-place updates (what the optimiser does) and through a
+    re-homing of the parameters (FlatAdam moves them into its flat buffer): forward and gradients equal the MIOpen backend's on
+    the same weights, after each."""
+    import torch
+    from consistent_depth_amd.monodepth.midas_net import MidasNet
+    torch.manual_seed(3)
+    hip = MidasNet(backend="hip").cuda().train()
+    rocm = MidasNet(backend="torch").cuda().train()
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+    assert hip._pack_pool is not None and len(hip._pack_pool.layers) > 100
+
+    def check(tag):
+        rocm.load_state_dict(hip.state_dict())
+        outs = []
+        for net in (hip, rocm):
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            (y * y).sum().backward()
+            outs.append((y.detach(), {k: p.grad.detach() for k, p in net.named_parameters() if p.grad is not None}))
+        (ya, ga), (yb, gb) = outs
+        dy = float((ya - yb).abs().max() / yb.abs().max())
+        num = sum(float(((ga[k] - gb[k]) ** 2).sum()) for k in gb)
+        den = sum(float((gb[k] ** 2).sum()) for k in gb)
+        report("midas_pack_pool", state=tag, y=f"{dy:.2e}", grad=f"{(num / den) ** 0.5:.2e}")
+        assert dy < 1e-3 and (num / den) ** 0.5 < 2e-2, (tag, dy, (num / den) ** 0.5)    # (fp32 noise of a 100-layer train-mode-BN net; stale filters give O(1))
+    check("initial")
+    with torch.no_grad():      # an optimiser step: in place, same storage
+        for p in hip.parameters():
+            p.mul_(1.0 + 0.05 * torch.randn_like(p))
+    check("after in-place update")
+    with torch.no_grad():      # FlatAdam: the parameters move to new storage
+        for p in hip.parameters():
+            p.data = p.data.clone()
+    check("after re-homing")

@@ -56,6 +56,25 @@ def test_plan_invariants(gen, kw, max_outside, H, W, pxt):
             assert len(items) <= 1.4 * g["NG"] + 12, "lock-step: about one item per row group"
 
 
+def test_fan_in_count_and_limits():
+    """The plan's fan-in count (sources per target pixel): 1-2 on a consistent scene, H*W when every flow points at one pixel;
+    the per-pair bound of a source's contributions follows it so that a 32-bit accumulator cannot wrap."""
+    from consistent_depth_amd import synthetic
+    H, W = 96, 128
+    g = E.geo(H, W, 2)
+    b = synthetic.make_scene_batch(1, H, W, seed=4)
+    f = E.fan_in(g, b["flows"][0][0], b["flows"][1][0], b["masks"][0][0], b["masks"][1][0])
+    assert 1 <= f <= 12, f
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    one = np.ones((1, H, W), np.float32)
+    to_point = np.stack([40.0 - xx, 30.0 - yy])          # every source samples (40, 30)
+    assert E.fan_in(g, to_point, to_point, one, one) == H * W
+    assert E.fan_in(g, to_point, to_point, 0 * one, 0 * one) == 0
+    zoom = np.stack([-(xx - W / 2) * 0.5, -(yy - H / 2) * 0.5])   # 2x zoom-out: ~4 sources per target pixel, x 4 taps
+    fz = E.fan_in(g, zoom, zoom, one, one)
+    assert 8 <= fz <= 30, fz
+
+
 def test_plan_degenerate_flows():
     """Empty masks, constant-target flows, pure vertical shifts beyond the ring."""
     H, W = 96, 64
@@ -78,9 +97,9 @@ def _dist(oracle, e, ref64):
 
 
 @pytest.mark.parametrize("name", [n for n in golden_loss_cases() if not n.startswith("nodisp")])
-@pytest.mark.parametrize("cfg", [dict(pxt=2), dict(pxt=1), dict(pxt=4), dict(pxt=2, force_slow=True), dict(pxt=2, ring_rows=14),
-                                 dict(pxt=2, order=1), dict(pxt=2, ring_rows=14, order=1)],
-                         ids=["pxt2", "pxt1", "pxt4", "slow", "ring14", "sources_last", "ring14_sources_last"])
+@pytest.mark.parametrize("cfg", [dict(pxt=2), dict(pxt=1), dict(pxt=4), dict(pxt=2, force_slow=True), dict(pxt=2, ring_rows=16),
+                                 dict(pxt=2, order=1), dict(pxt=2, ring_rows=16, order=1)],
+                         ids=["pxt2", "pxt1", "pxt4", "slow", "ring16", "sources_last", "ring16_sources_last"])
 def test_emulated_sweep_matches_reference_goldens(oracle, name, cfg):
     batch, lr, lb, ref64, ref32 = load_loss_case(name)
     if batch["depth"].shape[-1] % cfg.get("pxt", 2):
@@ -88,7 +107,16 @@ def test_emulated_sweep_matches_reference_goldens(oracle, name, cfg):
         # fewer pixels per thread here, and on the tile kernels in the product (sweep_supported)
         assert E.geo(*batch["depth"].shape[-2:], cfg["pxt"]) is None
         cfg = dict(cfg, pxt=1)
-    e = E.loss(batch, lr, lb, **cfg)
+    try:
+        e = E.loss(batch, lr, lb, **cfg)
+    except E.FanInTooHigh:
+        # the `stress` golden: flows that pile hundreds of sources onto single pixels.  Round 3's 32-bit accumulators take at most
+        # 62 sources per pixel (loss_math.h): the plan kernel refuses such a pair and the product recomputes it on the exact v1
+        # path (tests/test_loss_gpu.py runs this golden through the product with the sweep forced)
+        g = E.geo(*batch["depth"].shape[-2:], cfg.get("pxt", 2), cfg.get("ring_rows", 0))
+        assert max(E.fan_in(g, batch["flows"][0][b], batch["flows"][1][b], batch["masks"][0][b], batch["masks"][1][b])
+                   for b in range(batch["depth"].shape[0])) > 62
+        return
     loss_rel, grad = _dist(oracle, e, ref64)
     assert loss_rel < 1e-6
     assert grad < max(4 * oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]), 2e-6)
