@@ -38,11 +38,11 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x2 (fp32), SURVEY.md 8d
-# HBM traffic of the row-sweep gradient kernel per pair at 384x224 from rocprofv3 PMC (profiles/rocprofv3_loss_sweep_b256_r02.txt,
-# separate passes): FETCH_SIZE 346.80 MB x 2 (the guide's gfx950 correction) + WRITE_SIZE 172.04 MB per 256-pair launch
-# = 3.381 MB per pair = 0.98x the algorithmic 3.441 MB (every input read once, every gradient byte written once).  Only
+# HBM traffic of the row-sweep gradient kernel per pair at 384x224 from rocprofv3 PMC (profiles/rocprofv3_loss_sweep_b256_r03.txt,
+# separate passes): FETCH_SIZE 346.63 MB x 2 (the guide's gfx950 correction) + WRITE_SIZE 172.04 MB per 256-pair launch
+# = 3.380 MB per pair = 0.98x the algorithmic 3.441 MB (every input read once, every gradient byte written once).  Only
 # valid for the size and the kernel it was measured on; null otherwise.
-LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = (2 * 346.8037e6 + 172.040e6) / 256
+LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = (2 * 346.6259e6 + 172.040e6) / 256
 # Matrix-core roofs (TFLOP/s, dense; /opt/skills/guides/MI355X_MICROARCH.md).  The split-operand convolutions compute one fp32
 # result from SIX bf16 products, so the roof they run against, in fp32-equivalent flops, is the dense BF16 peak / 6.
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -136,6 +136,9 @@ def parse():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CD_AMD_STEP_GRAPH", "1")),
                     help="1: replay the step from a HIP graph after the eager warm-up steps (GraphedFineTuneStep); 0: eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the short BASELINE configs[4] side measurement (midas2 backbone, 384x384, BS8) that the default N=1 run appends")
+    ap.add_argument("--config5-timeout", type=int, default=150)
     ap.add_argument("--no-loss-microbench", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-timeout", type=int, default=150, help="seconds the CPU-baseline subprocess may take")
@@ -376,7 +379,7 @@ def main():
                                "bound": "hbm", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": (LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 * args.loss_batch if sweep else None),
-                               "traffic_source": "profiles/rocprofv3_loss_sweep_b256_r02.txt (PMC, separate passes; FETCH_SIZE x2 + WRITE_SIZE)",
+                               "traffic_source": "profiles/rocprofv3_loss_sweep_b256_r03.txt (PMC, separate passes; FETCH_SIZE x2 + WRITE_SIZE)",
                                "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
                                "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
         if world == 1 and not args.no_cpu_baseline and args.model == "mc":
@@ -413,6 +416,21 @@ def main():
                 except (subprocess.TimeoutExpired, IndexError, ValueError) as e:
                     out["cpu_baseline"] = {"value": None, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                            "sample": f"not completed within {args.cpu_timeout}s ({type(e).__name__})"}
+        if world == 1 and args.model == "mc" and not args.no_config5:
+            # BASELINE configs[4] on this GPU, as a SIDE measurement in its own process (its own line is `python bench.py --model
+            # midas2 --height 384 --width 384 --batch-size 8`): 5 timed steps of the midas2 plugin, bounded by a timeout
+            log("config 5 side measurement (midas2, 384x384, BS8)")
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--model", "midas2", "--height", "384", "--width", "384", "--batch-size", "8",
+                   "--steps", "5", "--warmup", "2", "--frames", "20", "--no-loss-microbench", "--no-cpu-baseline", "--backend", args.backend]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.config5_timeout)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                c5 = json.loads(line)
+                out["config5"] = {"value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"], "steps": c5["steps"],
+                                  "n_gpus": 1, "workload": c5["config"]["workload"], "roofline_conv": c5.get("roofline_conv")}
+            except (subprocess.TimeoutExpired, IndexError, ValueError, KeyError) as e:
+                out["config5"] = {"value": None, "note": f"not completed within {args.config5_timeout}s ({type(e).__name__})"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

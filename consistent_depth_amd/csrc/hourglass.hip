@@ -8,7 +8,8 @@
 // side streams and timed launch shapes): every inception is ONE buffer [m1|m2|m3 | b0|o1|o2|o3], its four branch-entry 1x1
 // convolutions are one convolution, activations are kept as x_hat (pre-ReLU) and consumers apply ReLU / the stem's affine on
 // load, all filters are re-packed by one launch per forward, all weight gradients leave their per-workgroup slices by one
-// launch per backward.  Single stream; capture it in a hipGraph for launch-bound hosts.
+// launch per backward; BatchNorm never passes over an activation (cd_bn_finalize: consumers apply relu(raw * scale + shift) on
+// load).  Single stream; capture it in a hipGraph for launch-bound hosts.
 //
 // Parameters live in ONE flat buffer laid out like consistent_depth_amd.optimizer.FlatAdam does it: the tensors of
 // HourglassModel.named_parameters() in order, each starting on a 64-float boundary -- so cd_adam_step_flat updates them in
@@ -58,6 +59,7 @@ struct Unit {          // conv [+ BatchNorm + ReLU]
     bool bn = false, affine = false, bn_fused = false;
     size_t gamma = 0, beta = 0;                     // affine BatchNorm parameters (the stem)
     double* stats = nullptr; float* mi = nullptr;   // [16][ctot][2] doubles, [ctot][2] floats of the DESTINATION buffer
+    float* sc = nullptr; float* sh = nullptr;       // [ctot] apply-on-load BatchNorm of the destination buffer (cd_bn_finalize)
     float* rm = nullptr; float* rv = nullptr;       // running statistics (C floats each), engine-owned
     float* pk = nullptr; float* pkT = nullptr;      // packed filters (forward, dgrad twin)
     float* wgrad_ws = nullptr; double* sums = nullptr;
@@ -70,6 +72,7 @@ struct Inception {
     int src = -1, out = -1;                         // Acts
     float* P = nullptr; float* Pg = nullptr;        // [N][M + Co][H][W]
     double* stats = nullptr; float* mi = nullptr;
+    float* sc = nullptr; float* sh = nullptr;       // [M + Co] scale / shift of P: consumers apply relu(raw * scale + shift) while loading
     ConvP entry[4];                                 // m1, m2, m3, b0 (member convolutions of the fused 1x1)
     float* filt = nullptr; float* filtT = nullptr; float* bias = nullptr;   // fused filter (fwd / dgrad), fused bias [ctot_entry]
     float* rm_entry = nullptr; float* rv_entry = nullptr; float* rm_out = nullptr; float* rv_out = nullptr;
@@ -200,6 +203,7 @@ struct Builder {
         I.Pg = e.new_buf(ctot, H, W);
         I.stats = take_stats(ctot);
         I.mi = e.alloc<float>((size_t)ctot * 2, true);
+        I.sc = e.alloc<float>((size_t)ctot, true); I.sh = e.alloc<float>((size_t)ctot, true);
         I.entry[0] = m[0]; I.entry[1] = m[1]; I.entry[2] = m[2]; I.entry[3] = a0;
         I.filt = packed(I.ctot_entry, I.c.cin, 1);
         I.filtT = packed(I.c.cin, I.ctot_entry, 1);
@@ -235,9 +239,10 @@ struct Builder {
             u.cv = o[i];
             I.mid[i] = e.new_act(I.P, ctot, moff, I.c.mid[i], H, W, true, false);
             e.acts[I.mid[i]].gbuf = I.Pg;
+            e.acts[I.mid[i]].scale = I.sc + moff; e.acts[I.mid[i]].shift = I.sh + moff;
             u.src = I.mid[i];
             u.dst = I.P; u.dst_ctot = ctot; u.dst_coff = ooff; u.H = H; u.W = W;
-            u.bn = true; u.bn_fused = true; u.stats = I.stats; u.mi = I.mi;
+            u.bn = true; u.bn_fused = true; u.stats = I.stats; u.mi = I.mi; u.sc = I.sc; u.sh = I.sh;
             u.pk = packed(u.cv.cout, u.cv.cin, u.cv.ks); u.pkT = packed(u.cv.cin, u.cv.cout, u.cv.ks);
             pack_src(u.cv, u.pk, false, u.cv.cout, u.cv.cin, 0, 0);
             pack_src(u.cv, u.pkT, true, u.cv.cin, u.cv.cout, 0, 0);
@@ -250,6 +255,7 @@ struct Builder {
         }
         I.out = e.new_act(I.P, ctot, I.M, I.Co, H, W, true, false);
         e.acts[I.out].gbuf = I.Pg;
+        e.acts[I.out].scale = I.sc + I.M; e.acts[I.out].shift = I.sh + I.M;
         steps.push_back(n);
         return I.out;
     }
@@ -323,26 +329,31 @@ struct Runner {
     void chk(int r) { if (rc == CD_OK && r != CD_OK) rc = r; }
     bool grad_mode(int a) { const bool acc = e.acts[a].grad_written; e.acts[a].grad_written = true; return acc; }
 
-    void bn_forward(float* buf, int ctot, int coff, int C, double* stats, float* mi, float* rm, float* rv, int H, int W) {
+    // BatchNorm WITHOUT a pass over the activation: the statistics become the (scale, shift) the consumers apply while loading
+    void bn_forward(int ctot, int coff, int C, double* stats, float* mi, float* rm, float* rv, float* sc, float* sh, const float* gamma,
+                    const float* beta, int H, int W) {
+        const double count = (double)e.N * H * W;
         if (training) {
-            chk(cd_bn_normalize(buf, ctot, coff, C, stats, kEps, rm, rv, kMomentum, mi, e.N, H, W, s));
+            chk(cd_bn_finalize(stats, ctot, coff, C, count, kEps, gamma, beta, rm, rv, kMomentum, mi, sc, sh, s));
         } else {
-            hipLaunchKernelGGL(eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, ctot, coff, C, rm, rv, (double)e.N * H * W);
-            chk(cd_bn_normalize(buf, ctot, coff, C, stats, kEps, nullptr, nullptr, kMomentum, mi, e.N, H, W, s));
+            hipLaunchKernelGGL(eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, ctot, coff, C, rm, rv, count);
+            chk(cd_bn_finalize(stats, ctot, coff, C, count, kEps, gamma, beta, nullptr, nullptr, kMomentum, mi, sc, sh, s));
         }
     }
     void unit_forward(Unit& u) {
         const Act& a = e.acts[u.src];
         chk(cd_conv2d_fwd(a.buf, a.ctot, a.coff, u.cv.cin, u.pk, e.flat_param + u.cv.b, a.scale, a.shift, a.relu ? 1 : 0, u.dst, u.dst_ctot,
                           u.dst_coff, u.cv.cout, (u.bn && training) ? u.stats : nullptr, 0, e.N, u.H, u.W, u.cv.ks, s));
-        if (u.bn && !u.bn_fused) bn_forward(u.dst, u.dst_ctot, u.dst_coff, u.cv.cout, u.stats, u.mi, u.rm, u.rv, u.H, u.W);
+        if (u.bn && !u.bn_fused)
+            bn_forward(u.dst_ctot, u.dst_coff, u.cv.cout, u.stats, u.mi, u.rm, u.rv, u.sc, u.sh, u.affine ? e.flat_param + u.gamma : nullptr,
+                       u.affine ? e.flat_param + u.beta : nullptr, u.H, u.W);
     }
     void unit_backward(Unit& u) {
         const Act& a = e.acts[u.src];
         if (u.bn_fused) {
         } else if (u.bn) {
             chk(cd_bn_relu_bwd(u.gbuf, u.g_ctot, u.g_coff, u.dst, u.dst_ctot, u.dst_coff, u.cv.cout, u.affine ? e.flat_param + u.gamma : nullptr,
-                               u.affine ? e.flat_param + u.beta : nullptr, u.mi, nullptr, nullptr, u.sums, 1,
+                               u.affine ? e.flat_param + u.beta : nullptr, u.mi, u.sc, u.sh, u.sums, 1,
                                u.affine ? e.flat_grad + u.gamma : nullptr, u.affine ? e.flat_grad + u.beta : nullptr, e.N, u.H, u.W, s));
         } else {
             chk(cd_channel_sum(u.gbuf, u.g_ctot, u.g_coff, u.cv.cout, e.N, u.H, u.W, e.flat_grad + u.cv.b, 1, s));
@@ -363,9 +374,9 @@ struct Runner {
                 const int ctot = I.M + I.Co;
                 chk(cd_conv2d_fwd(a.buf, a.ctot, a.coff, I.c.cin, I.filt, I.bias, a.scale, a.shift, a.relu ? 1 : 0, I.P, ctot, 0, I.ctot_entry,
                                   training ? I.stats : nullptr, 0, e.N, I.H, I.W, 1, s));
-                bn_forward(I.P, ctot, 0, I.ctot_entry, I.stats, I.mi, I.rm_entry, I.rv_entry, I.H, I.W);           // [m1|m2|m3|b0]
+                bn_forward(ctot, 0, I.ctot_entry, I.stats, I.mi, I.rm_entry, I.rv_entry, I.sc, I.sh, nullptr, nullptr, I.H, I.W);           // [m1|m2|m3|b0]
                 for (Unit& u : I.branch) unit_forward(u);
-                bn_forward(I.P, ctot, I.ctot_entry, I.Co - I.c.a0, I.stats, I.mi, I.rm_out, I.rv_out, I.H, I.W);    // [o1|o2|o3]
+                bn_forward(ctot, I.ctot_entry, I.Co - I.c.a0, I.stats, I.mi, I.rm_out, I.rv_out, I.sc, I.sh, nullptr, nullptr, I.H, I.W);    // [o1|o2|o3]
             } else if (n.kind == kPool) {
                 const Act& a = e.acts[n.src];
                 const Act& y = e.acts[n.out];
@@ -392,10 +403,10 @@ struct Runner {
                 const int ctot = I.M + I.Co;
                 // the concat output's gradient is complete: k x k convolutions first (they fill the gradient of the mid
                 // activations), then the fused entry convolution
-                chk(cd_bn_relu_bwd(I.Pg, ctot, I.ctot_entry, I.P, ctot, I.ctot_entry, I.Co - I.c.a0, nullptr, nullptr, I.mi, nullptr, nullptr,
+                chk(cd_bn_relu_bwd(I.Pg, ctot, I.ctot_entry, I.P, ctot, I.ctot_entry, I.Co - I.c.a0, nullptr, nullptr, I.mi, I.sc, I.sh,
                                    I.sums_out, 1, nullptr, nullptr, e.N, I.H, I.W, s));
                 for (Unit& u : I.branch) unit_backward(u);
-                chk(cd_bn_relu_bwd(I.Pg, ctot, 0, I.P, ctot, 0, I.ctot_entry, nullptr, nullptr, I.mi, nullptr, nullptr, I.sums_entry, 1, nullptr,
+                chk(cd_bn_relu_bwd(I.Pg, ctot, 0, I.P, ctot, 0, I.ctot_entry, nullptr, nullptr, I.mi, I.sc, I.sh, I.sums_entry, 1, nullptr,
                                    nullptr, e.N, I.H, I.W, s));
                 chk(cd_conv2d_wgrad(a.buf, a.ctot, a.coff, I.c.cin, a.scale, a.shift, a.relu ? 1 : 0, I.Pg, ctot, 0, I.ctot_entry, nullptr, 4,
                                     I.wgrad_ws, e.N, I.H, I.W, 1, s));
@@ -449,6 +460,7 @@ int cd_hourglass_create(int N, int H, int W, cd_hourglass** out) {
     su.bn = true; su.affine = true;
     su.stats = b.take_stats(128);
     su.mi = e->alloc<float>(256, true);
+    su.sc = e->alloc<float>(128, true); su.sh = e->alloc<float>(128, true);
     su.rm = e->alloc<float>(128, true); su.rv = e->alloc<float>(128);
     e->bns.push_back({su.rm, su.rv, 128});
     su.pk = b.packed(128, 3, 7); su.pkT = nullptr;
@@ -477,8 +489,8 @@ int cd_hourglass_create(int N, int H, int W, cd_hourglass** out) {
     {
         Node& st = e->steps.front();
         st.unit.stats = su.stats;
-        e->acts[a_stem].scale = e->flat_param + st.unit.gamma;
-        e->acts[a_stem].shift = e->flat_param + st.unit.beta;
+        e->acts[a_stem].scale = st.unit.sc;      // gamma * invstd, beta - gamma * mean * invstd: written by cd_bn_finalize
+        e->acts[a_stem].shift = st.unit.sh;
         cd_pack_desc d{off_ptr(st.unit.cv.w), st.unit.pk, 128, 3, 7, 0, 128, 3, 0, 0};
         e->pack_host.push_back(d);
         Node& hd = e->steps.back();

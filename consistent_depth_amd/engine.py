@@ -12,6 +12,8 @@ here the NaN-skip is evaluated inside the Adam kernel and losses are fetched onl
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import optimizer as cd_optimizer
@@ -31,6 +33,29 @@ class FineTuneStep:
         self.opt = cd_optimizer.create(getattr(params, "optimizer", "Adam"), plist, params.learning_rate,
                                        betas=(0.9, 0.999))
         self._plist = plist
+        # Autograd-driven models with a large gradient (MiDaS: 420 MB): bucketed all-reduce overlapped with the backward pass.
+        # The hourglass engine writes its 21 MB of gradients without autograd hooks: one collective after the backward.
+        self.buckets = None
+        n_buckets = int(os.environ.get("CD_AMD_DP_BUCKETS", "4"))
+        if self.world > 1 and n_buckets > 1 and getattr(model, "_engine", None) is None and self.opt.flat_grad.numel() >= (8 << 20):
+            self.buckets = parallel.GradBuckets(self.opt, n_buckets)
+
+    def _backward_and_reduce(self, loss):
+        """backward + the data-parallel exchange; returns the guard scalar (the summed loss with world > 1)."""
+        guard = loss.detach()
+        if self.world == 1:
+            loss.backward()
+            return guard
+        if self.buckets is not None:
+            self.opt.loss_slot.copy_(guard.reshape(1))     # before backward: nothing writes the slot afterwards
+            self.buckets.arm()
+            loss.backward()
+            self.buckets.finish()
+            return self.opt.loss_slot
+        loss.backward()
+        self.opt.loss_slot.copy_(guard.reshape(1))
+        parallel.allreduce_sum_(self.opt.reduce_buffer)
+        return self.opt.loss_slot
 
     def forward_loss(self, images, metadata):
         raw = self.model.estimate_raw(images)
@@ -41,12 +66,7 @@ class FineTuneStep:
         raw = self.model.estimate_raw(images)
         self.opt.zero_grad()
         loss, parts = self.criterion(raw, metadata, parameters=self._plist)
-        loss.backward()
-        guard = loss.detach()
-        if self.world > 1:
-            self.opt.loss_slot.copy_(guard.reshape(1))
-            parallel.allreduce_sum_(self.opt.reduce_buffer)
-            guard = self.opt.loss_slot
+        guard = self._backward_and_reduce(loss)
         self.opt.step(grad_scale=1.0 / self.world, guard_loss=guard)
         return loss.detach(), parts
 

@@ -3,10 +3,13 @@
 Executes the same network as consistent_depth_amd/monodepth/hourglass.py (whose nn.Module stays the
 parameter / state_dict container) on the gfx950 kernels behind the C ABI:
 
-    conv (all 157)      cd_conv2d_fwd_cfg    fp32 MFMA direct convolution; the producer's ReLU (and the stem's
-                                             affine) is applied while loading, the batch statistics of the
+    conv (all 157)      cd_conv2d_fwd_cfg    MFMA direct convolution; the producer's BatchNorm + ReLU
+                                             is applied while loading, the batch statistics of the
                                              raw output are accumulated in the epilogue
-    BatchNorm (train)   cd_bn_normalize      in place -> x_hat (pre-ReLU); running stats updated like PyTorch
+    BatchNorm (train)   cd_bn_finalize       NO pass over the activation: the statistics the conv epilogue accumulated become a
+                                             per-channel (scale, shift); the buffer keeps the RAW conv output and every consumer
+                                             applies relu(raw * scale + shift) while loading (round 2 normalised in place:
+                                             0.93 ms of pure HBM traffic per step); running stats updated like PyTorch
     AvgPool2d(2)        cd_avgpool2_fwd
     Upsample x2 + add   cd_upsample2x_add_fwd   (the residual add of every Channels block is fused in)
     backward            cd_bn_relu_bwd, cd_conv2d_wgrad, cd_conv2d_fwd on transposed filters (dgrad),
@@ -74,13 +77,15 @@ class Act:
 
 
 class ConvUnit:
-    def __init__(self, eng, conv_mod, bn_mod, src: Act, dst_buf, dst_coff, stats, mean_invstd):
+    def __init__(self, eng, conv_mod, bn_mod, src: Act, dst_buf, dst_coff, stats, mean_invstd, bn_scale=None, bn_shift=None):
+        """bn_scale / bn_shift: the (ctot,) apply-on-load arrays of the destination buffer (cd_bn_finalize fills this unit's slice)."""
         self.eng, self.conv, self.bn, self.src = eng, conv_mod, bn_mod, src
         self.ks, self.cin, self.cout = conv_mod.kernel_size[0], conv_mod.in_channels, conv_mod.out_channels
         self.dst_buf, self.dst_coff, self.stats, self.mi = dst_buf, dst_coff, stats, mean_invstd
-        affine = bn_mod is not None and bn_mod.affine
+        self.bn_scale, self.bn_shift = bn_scale, bn_shift
         self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None,
-                       scale=bn_mod.weight if affine else None, shift=bn_mod.bias if affine else None, needs_grad=False)
+                       scale=bn_scale[dst_coff:dst_coff + self.cout] if bn_mod is not None else None,
+                       shift=bn_shift[dst_coff:dst_coff + self.cout] if bn_mod is not None else None, needs_grad=False)
         self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
         self.bn_fused = False             # True: the owning inception runs the BN passes of its three branch outputs jointly
         self.pk, self.pkT = eng.packed(conv_mod)
@@ -97,15 +102,10 @@ class ConvUnit:
                  y_coff=self.dst_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu,
                  stats=self.stats.view(-1) if (self.bn is not None and training) else None, cfg=self.cfg_f)
         if self.bn is not None and not self.bn_fused:
-            if training:
-                L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS, self.bn.running_mean,
-                               self.bn.running_var, BN_MOMENTUM)
-            else:  # eval: normalise with the running statistics (synthesised sums; nothing is updated)
-                cnt = float(self.dst_buf.shape[0] * self.dst_buf.shape[2] * self.dst_buf.shape[3])
-                rm, rv = self.bn.running_mean.double(), self.bn.running_var.double()
-                self.stats[0, self.dst_coff:self.dst_coff + self.cout, 0] = rm * cnt   # slot 0; the others stay zero
-                self.stats[0, self.dst_coff:self.dst_coff + self.cout, 1] = (rv + rm * rm) * cnt
-                L.bn_normalize(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, BN_EPS)
+            affine = self.bn.affine
+            self.eng.bn_forward(self.dst_buf, self.dst_coff, self.cout, self.stats, self.mi, (self.bn.running_mean, self.bn.running_var),
+                                training, self.bn_scale, self.bn_shift, gamma=self.bn.weight if affine else None,
+                                beta=self.bn.bias if affine else None)
 
     def backward(self, gbuf, g_coff):
         """gbuf[:, g_coff:+cout] holds d loss / d (activated output); on return the parameter grads are
@@ -118,7 +118,7 @@ class ConvUnit:
             L.bn_relu_bwd(gbuf, g_coff, self.dst_buf, self.dst_coff, self.cout, self.mi, self.sums,
                           gamma=self.bn.weight if affine else None, beta=self.bn.bias if affine else None,
                           dgamma=_grad_of(self.bn.weight) if affine else None,
-                          dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True)
+                          dbeta=_grad_of(self.bn.bias) if affine else None, sums_prezeroed=True, scale=self.bn_scale, shift=self.bn_shift)
         else:
             L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias), accumulate=True)
         # the partial sums stay packed in the arena; plan["unpack"] writes every weight gradient at the end of the backward
@@ -142,8 +142,9 @@ class _Member:
 class PointwiseGroup:
     """The four branch-entry 1x1 convolutions of an inception as ONE convolution X -> P[:, 0:ctot]."""
 
-    def __init__(self, eng, members, src: Act, P, Pg, stats, mean_invstd, filt, filtT, running):
+    def __init__(self, eng, members, src: Act, P, Pg, stats, mean_invstd, filt, filtT, running, bn_scale, bn_shift):
         self.eng, self.members, self.src, self.P, self.Pg, self.stats, self.mi = eng, members, src, P, Pg, stats, mean_invstd
+        self.bn_scale, self.bn_shift = bn_scale, bn_shift
         self.running = running            # (running_mean, running_var) of the members, contiguous in member order
         self.ctot = sum(m.cout for m in members)
         self.cin = members[0].cin
@@ -171,11 +172,11 @@ class PointwiseGroup:
         C.conv2d(s.buf, pk, self.cin, self.ctot, 1, bias=self._fused_bias(), x_coff=s.coff, out=self.P, y_coff=0,
                  in_scale=s.scale, in_shift=s.shift, in_relu=s.relu, stats=self.stats.view(-1) if training else None,
                  cfg=self.cfg_f)
-        self.eng.bn_forward(self.P, 0, self.ctot, self.stats, self.mi, self.running, training)   # [m1|m2|m3|b0] in one launch
+        self.eng.bn_forward(self.P, 0, self.ctot, self.stats, self.mi, self.running, training, self.bn_scale, self.bn_shift)   # [m1|m2|m3|b0]
 
     def backward(self):
         s = self.src
-        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True)
+        L.bn_relu_bwd(self.Pg, 0, self.P, 0, self.ctot, self.mi, self.sums, sums_prezeroed=True, scale=self.bn_scale, shift=self.bn_shift)
         # ONE weight-gradient GEMM for the four filters (X is read once), then split the rows
         self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
             s.buf, self.Pg, self.cin, self.ctot, 1, None, self.wgrad_ws, x_coff=s.coff, dy_coff=0, in_scale=s.scale,
@@ -291,16 +292,17 @@ class HourglassEngine:
             done.record(st)
             cur.wait_event(done)
 
-    def bn_forward(self, buf, coff, C, stats, mi, running, training):
-        """Train-mode BatchNorm (or eval: normalise with the running statistics) of C adjacent channels in ONE launch."""
+    def bn_forward(self, buf, coff, C, stats, mi, running, training, scale, shift, gamma=None, beta=None):
+        """Train-mode BatchNorm (or eval: the running statistics) of C adjacent channels WITHOUT touching the activation: ONE tiny
+        launch turns the statistics into the (scale, shift) the consumers apply while loading the raw convolution output."""
         rm, rv = running
+        cnt = float(buf.shape[0] * buf.shape[2] * buf.shape[3])
         if training:
-            L.bn_normalize(buf, coff, C, stats, mi, BN_EPS, rm, rv, BN_MOMENTUM)
+            L.bn_finalize(stats, coff, C, cnt, mi, scale, shift, BN_EPS, gamma, beta, rm, rv, BN_MOMENTUM)
         else:   # synthesised sums in slot 0 (the others stay zero); nothing is updated
-            cnt = float(buf.shape[0] * buf.shape[2] * buf.shape[3])
             stats[0, coff:coff + C, 0] = rm.double() * cnt
             stats[0, coff:coff + C, 1] = (rv.double() + rm.double() * rm.double()) * cnt
-            L.bn_normalize(buf, coff, C, stats, mi, BN_EPS)
+            L.bn_finalize(stats, coff, C, cnt, mi, scale, shift, BN_EPS, gamma, beta)
 
     def on_wgrad_stream(self, job):
         """Run `job` (a weight-gradient launch sequence) on the wgrad stream, ordered after everything enqueued so far
@@ -359,6 +361,7 @@ class HourglassEngine:
         Pg = torch.empty_like(P)
         stats = self._stats(plan, M + Co)
         mi = torch.zeros(M + Co, 2, device=self.device)
+        sc, sh = torch.ones(M + Co, device=self.device), torch.zeros(M + Co, device=self.device)   # apply-on-load BatchNorm of P
         members, moff = [], 0
         for i, br in enumerate(list(mod.convs)[1:]):
             members.append(_Member(br[0], br[1], moff))
@@ -366,18 +369,18 @@ class HourglassEngine:
         members.append(_Member(mod.convs[0][0], mod.convs[0][1], M))
         filt, filtT = self._group_filters[id(mod)]
         run_entry, run_out = self._bn_flat[id(mod)]
-        group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT, run_entry)
+        group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT, run_entry, sc, sh)
         units, ooff, moff = [], M + a0, 0
         for i, br in enumerate(list(mod.convs)[1:]):
-            mid = Act(P, moff, mids[i], relu=True, needs_grad=False)
+            mid = Act(P, moff, mids[i], relu=True, scale=sc[moff:moff + mids[i]], shift=sh[moff:moff + mids[i]], needs_grad=False)
             mid.gbuf = Pg
-            units.append((ConvUnit(self, br[3], br[4], mid, P, ooff, stats, mi), Pg, ooff))
+            units.append((ConvUnit(self, br[3], br[4], mid, P, ooff, stats, mi, sc, sh), Pg, ooff))
             units[-1][0].bn_fused = True
             ooff += outs[i + 1]
             moff += mids[i]
-        out = Act(P, M, Co, relu=True, needs_grad=False)
+        out = Act(P, M, Co, relu=True, scale=sc[M:M + Co], shift=sh[M:M + Co], needs_grad=False)
         out.gbuf = Pg
-        steps.append(_Node("inception", group=group, units=units, out=out, src=x, P=P, Pg=Pg, stats=stats, mi=mi,
+        steps.append(_Node("inception", group=group, units=units, out=out, src=x, P=P, Pg=Pg, stats=stats, mi=mi, bn_scale=sc, bn_shift=sh,
                            bn_coff=M + a0, bn_C=sum(outs[1:]), bn_running=run_out, bn_sums=None))
         plan["convs"] += [group] + [u for u, _, _ in units]
         return out
@@ -427,7 +430,8 @@ class HourglassEngine:
         plan["x"] = self._new(N, 3, H, W)
         x_in = Act(plan["x"], 0, 3, needs_grad=False)
         stem_buf = self._new(N, 128, H, W)
-        stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, self._stats(plan, 128), torch.zeros(128, 2, device=self.device))
+        stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, self._stats(plan, 128), torch.zeros(128, 2, device=self.device),
+                        torch.ones(128, device=self.device), torch.zeros(128, device=self.device))
         stem.out.gbuf = torch.empty_like(stem_buf)
         plan["steps"].append(_Node("conv", unit=stem, gbuf=stem.out.gbuf, g_coff=0))
         plan["convs"].append(stem)
@@ -494,7 +498,7 @@ class HourglassEngine:
             elif step.kind == "inception":
                 step.group.forward(training)
                 self._fork_join([(lambda u=u: u.forward(training)) for u, _, _ in step.units])
-                self.bn_forward(step.P, step.bn_coff, step.bn_C, step.stats, step.mi, step.bn_running, training)   # [o1|o2|o3]
+                self.bn_forward(step.P, step.bn_coff, step.bn_C, step.stats, step.mi, step.bn_running, training, step.bn_scale, step.bn_shift)   # [o1|o2|o3]
             elif step.kind == "pool":
                 s = step.src
                 L.avgpool2_fwd(s.buf, s.coff, s.C, step.out.buf, 0, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
@@ -514,7 +518,8 @@ class HourglassEngine:
             elif step.kind == "inception":
                 # the concat output's gradient is complete: k x k convolutions first (they fill the gradient of the
                 # mid activations), then the fused entry convolution
-                L.bn_relu_bwd(step.Pg, step.bn_coff, step.P, step.bn_coff, step.bn_C, step.mi, step.bn_sums, sums_prezeroed=True)
+                L.bn_relu_bwd(step.Pg, step.bn_coff, step.P, step.bn_coff, step.bn_C, step.mi, step.bn_sums, sums_prezeroed=True,
+                              scale=step.bn_scale, shift=step.bn_shift)
                 self._fork_join([(lambda u=u, g=gbuf, o=g_coff: u.backward(g, o)) for u, gbuf, g_coff in step.units])
                 step.group.backward()
             elif step.kind == "pool":
@@ -596,8 +601,8 @@ class BlockRunner:
         self.plan["stats_arena"].zero_()
         self.eng._pack.run()
         self.eng._run_forward(self.plan["steps"], training)
-        o = self.out
-        return torch.relu(o.buf[:, o.coff:o.coff + o.C])
+        o = self.out      # the buffer holds the raw convolution output: apply the BatchNorm like every consumer does
+        return torch.relu(torch.addcmul(o.shift.view(1, -1, 1, 1), o.buf[:, o.coff:o.coff + o.C], o.scale.view(1, -1, 1, 1)))
 
     @torch.no_grad()
     def backward(self, dy: torch.Tensor) -> torch.Tensor:

@@ -157,7 +157,9 @@ def test_pack_pool_follows_the_weights():
         num = sum(float(((ga[k] - gb[k]) ** 2).sum()) for k in gb)
         den = sum(float((gb[k] ** 2).sum()) for k in gb)
         report("midas_pack_pool", state=tag, y=f"{dy:.2e}", grad=f"{(num / den) ** 0.5:.2e}")
-        assert dy < 1e-3 and (num / den) ** 0.5 < 2e-2, (tag, dy, (num / den) ** 0.5)    # (fp32 noise of a 100-layer train-mode-BN net; stale filters give O(1))
+        # fp32 noise of this 100-layer train-mode-BN net between two correct back ends: ~3e-4 in y, ~1e-1 in the gradients (the
+        # chaos test_midas_network_hip_backend_matches_fp64 documents); filters that are 5 % stale move y by >= 1e-1
+        assert dy < 2e-3 and (num / den) ** 0.5 < 0.5, (tag, dy, (num / den) ** 0.5)
     check("initial")
     with torch.no_grad():      # an optimiser step: in place, same storage
         for p in hip.parameters():

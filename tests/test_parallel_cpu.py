@@ -131,3 +131,70 @@ def test_eval_chunks_are_the_single_process_batches_and_frames_have_one_owner():
                         if first[f] == c:
                             owners.setdefault(f, set()).add(r)
         assert set(owners) == set(first) and all(len(v) == 1 for v in owners.values())
+
+
+class _FlatStandIn:
+    """The part of optimizer.FlatAdam that parallel.GradBuckets uses (flat_grad, loss_slot, _params, _offsets), on the CPU."""
+
+    def __init__(self, params, align=4):
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + align - 1) // align * align
+        self._store = torch.zeros(n + align)
+        self.flat_grad, self.loss_slot = self._store[:n], self._store[n:n + 1]
+        self._params, self._offsets = list(params), offs
+        for p, o in zip(params, offs):
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    unused = torch.nn.Parameter(torch.zeros(5))                 # never receives a gradient (like the hourglass' confidence head)
+    params = [unused] + list(net.parameters())                   # (in the first bucket: the one that completes last anyway)
+    opt = _FlatStandIn(params)
+    buckets = parallel.GradBuckets(opt, n_buckets=3)
+    assert len(buckets.ranges) == 3 and buckets.ranges[0][0] == 0 and buckets.ranges[-1][1] == opt.flat_grad.numel()
+    assert all(a[1] == b[0] for a, b in zip(buckets.ranges, buckets.ranges[1:]))
+    data = torch.randn(8, 12, generator=torch.Generator().manual_seed(3))
+    launches = []
+    orig = buckets._launch
+    buckets._launch = lambda b: (launches.append(b), orig(b))[1]
+    ok = True
+    for it in range(2):                                          # two steps: the buckets re-arm
+        ids = list(range(rank * 4, rank * 4 + 4))
+        opt._store.zero_()
+        loss = net(data[ids]).pow(2).mean()
+        opt.loss_slot.copy_(loss.detach().reshape(1))
+        buckets.arm()
+        loss.backward()
+        n_during = len(launches)                                 # buckets of the LAST layers were reduced while backward ran
+        buckets.finish()
+        ref = torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+        ref.load_state_dict(net.state_dict())
+        ref_loss = ref(data).pow(2).mean()                       # the global batch in one process
+        ref_loss.backward()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            ok = ok and torch.allclose(p.grad / world, q.grad, rtol=1e-5, atol=1e-7)
+        ok = ok and abs(opt.loss_slot.item() / world - ref_loss.item()) < 1e-6 and bool((unused.grad == 0).all())
+        ok = ok and n_during >= 2 + 3 * it and sorted(launches[3 * it:]) == [0, 1, 2]     # buckets 2 and 1 went out during backward
+        ok = ok and launches[3 * it] == 2                        # reverse layer order: the last bucket goes first
+    buckets.close()
+    out[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_overlaps_backward_and_matches_the_global_batch():
+    """parallel.GradBuckets (the MiDaS-sized gradient: 420 MB in 4 buckets): ranges tile the flat buffer, buckets go out in
+    reverse layer order WHILE autograd is still running, parameters without a gradient do not block their bucket, and the reduced
+    gradient / loss equal the single-process global batch."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}

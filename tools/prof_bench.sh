@@ -10,8 +10,8 @@ cd /tmp
 export CD_AMD_CONV_TUNE_CACHE=$OUT/conv_tune.json
 # first an unprofiled run that measures the convolution launch shapes into the cache, so the profiled runs below contain
 # only the kernels of real steps; the profiled runs are eager (--graph 0): same kernels, individually traceable
-python $REPO/bench.py --no-cpu-baseline --no-loss-microbench --steps 2 --warmup 3 > $OUT/tune.log 2>&1
-CMD="python $REPO/bench.py --no-cpu-baseline --graph 0 --steps 10 --warmup 3"
+python $REPO/bench.py --no-cpu-baseline --no-config5 --no-loss-microbench --steps 2 --warmup 3 > $OUT/tune.log 2>&1
+CMD="python $REPO/bench.py --no-cpu-baseline --no-config5 --graph 0 --steps 10 --warmup 3"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 for pass in "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-32)

@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of the full fine-tuning step.  usage: bash tools/prof_step.sh <tag> [bench args...]
 set -u
 TAG=${1:-step}; shift || true
-ARGS=${@:---backend hip --steps 3 --warmup 2 --no-cpu-baseline --no-loss-microbench}
+ARGS=${@:---backend hip --steps 3 --warmup 2 --no-cpu-baseline --no-config5 --no-loss-microbench}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
