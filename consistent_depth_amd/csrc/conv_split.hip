@@ -212,7 +212,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     const int abase = li + COFF;   // LDS slot of this lane's pixel in tile row 0 at tap (0, 0)
 
     // staging of one unit = (tile row r, 4-pixel quad) x the 8 channels of a chunk, in two halves: raw loads, then transform + split
-    auto stage_load = [&](int chunk, int u, float (&v)[8][4], unsigned (&keep)[4]) {
+    // (the producer's BatchNorm scale / shift of the chunk's 8 channels are loaded HERE, with the data: fetched in stage_finish they
+    // started a second memory round trip per unit once every activation of the network is applied on load -- forward convolutions
+    // +20 % in round 3's first apply-on-load build)
+    auto stage_load = [&](int chunk, int u, float (&v)[8][4], unsigned (&keep)[4], float (&sc)[8], float (&sh)[8]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ci = chunk * 8 + c;
+            sc[c] = in_scale ? in_scale[ci < Cin ? ci : Cin - 1] : 1.f;
+            sh[c] = in_scale ? in_shift[ci < Cin ? ci : Cin - 1] : 0.f;
+        }
         const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
         const int gy = Y0 - P + r, gx = X0 - PADL + q4;
         const bool row_in = (unsigned)gy < (unsigned)H;
@@ -241,18 +250,17 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
             }
         }
     };
-    auto stage_finish = [&](int chunk, int u, float (&v)[8][4], const unsigned (&keep)[4], int gbase) {
+    auto stage_finish = [&](int chunk, int u, float (&v)[8][4], const unsigned (&keep)[4], const float (&sc)[8], const float (&sh)[8],
+                            int gbase) {
         const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int ci = chunk * 8 + c;
             const unsigned kc = ci < Cin ? 0xffffffffu : 0u;
-            float sc = 1.f, sh = 0.f;
-            if (in_scale) { sc = in_scale[ci < Cin ? ci : Cin - 1]; sh = in_shift[ci < Cin ? ci : Cin - 1]; }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 float t = v[c][p];
-                if (in_scale) t = __fmaf_rn(t, sc, sh);
+                if (in_scale) t = __fmaf_rn(t, sc[c], sh[c]);
                 if (in_relu) t = fmaxf(t, 0.f);
                 v[c][p] = __uint_as_float(__float_as_uint(t) & keep[p] & kc);   // zero padding (pixels and channels) stays an exact zero
             }
@@ -280,10 +288,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
         // under a divergent branch is followed by s_waitcnt vmcnt(0), which serialised the 8 channels.
         for (int uu = threadIdx.x; uu < CGS * UNITS; uu += kBlock) {
             const int g2 = uu / UNITS, u = uu - g2 * UNITS;
-            float v[8][4];
+            float v[8][4], sc[8], sh[8];
             unsigned keep[4];
-            stage_load(round * CGS + g2, u, v, keep);     // (a chunk beyond the last one: channels >= Cin, zeroed)
-            stage_finish(round * CGS + g2, u, v, keep, g2 * 3 * PLANE);
+            stage_load(round * CGS + g2, u, v, keep, sc, sh);     // (a chunk beyond the last one: channels >= Cin, zeroed)
+            stage_finish(round * CGS + g2, u, v, keep, sc, sh, g2 * 3 * PLANE);
         }
         __syncthreads();
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
             const int total = 16 * rows * quads;
             constexpr int BATCH = 4;
             for (int i0 = threadIdx.x; i0 < total; i0 += NT * BATCH) {
-                float v[BATCH][4];
+                float v[BATCH][4], asc[BATCH], ash[BATCH];
                 unsigned keep[BATCH][4];
 #pragma unroll
                 for (int b = 0; b < BATCH; ++b) {
@@ -153,6 +153,9 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
                     const int ch = ch0 + c, gy = y0 + r, gx = x0 + 4 * q;
                     const bool base_ok = i < total && ch < ch_n && (unsigned)gy < (unsigned)H;
                     const float* row = src_n + (size_t)(ch < ch_n ? ch : ch_n - 1) * HW + (size_t)((unsigned)gy < (unsigned)H ? gy : 0) * W;
+                    // the producer's BatchNorm scale / shift travel WITH the data loads (not as a second round trip afterwards)
+                    asc[b] = (affine && in_scale) ? in_scale[ch < ch_n ? ch : ch_n - 1] : 1.f;
+                    ash[b] = (affine && in_scale) ? in_shift[ch < ch_n ? ch : ch_n - 1] : 0.f;
                     if (vec) {   // W % 4 == 0: an aligned quad is inside or outside the image as a whole
                         const bool in = base_ok && (unsigned)gx < (unsigned)W;
                         const float4 f = *reinterpret_cast<const float4*>(row + ((unsigned)gx < (unsigned)W ? gx : 0));
@@ -175,9 +178,8 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
                     if (affine) {
                         const int ch = ch0 + c < ch_n ? ch0 + c : ch_n - 1;
                         if (in_scale) {
-                            const float sc = in_scale[ch], sh = in_shift[ch];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[b][e] = __fmaf_rn(v[b][e], sc, sh);   // same fma as the BN backward's mask
+                            for (int e = 0; e < 4; ++e) v[b][e] = __fmaf_rn(v[b][e], asc[b], ash[b]);   // same fma as the BN backward's mask
                         }
                         if (in_relu) {
 #pragma unroll

@@ -83,9 +83,13 @@ class ConvUnit:
         self.ks, self.cin, self.cout = conv_mod.kernel_size[0], conv_mod.in_channels, conv_mod.out_channels
         self.dst_buf, self.dst_coff, self.stats, self.mi = dst_buf, dst_coff, stats, mean_invstd
         self.bn_scale, self.bn_shift = bn_scale, bn_shift
-        self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None,
-                       scale=bn_scale[dst_coff:dst_coff + self.cout] if bn_mod is not None else None,
-                       shift=bn_shift[dst_coff:dst_coff + self.cout] if bn_mod is not None else None, needs_grad=False)
+        if bn_mod is not None and bn_scale is not None:      # apply-on-load: the buffer keeps the raw convolution output
+            sc, sh = bn_scale[dst_coff:dst_coff + self.cout], bn_shift[dst_coff:dst_coff + self.cout]
+        elif bn_mod is not None and bn_mod.affine:            # normalise-in-place mode (CD_AMD_BN_APPLY=0): x_hat in the buffer, the stem's affine on load
+            sc, sh = bn_mod.weight, bn_mod.bias
+        else:
+            sc = sh = None
+        self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None, scale=sc, shift=sh, needs_grad=False)
         self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
         self.bn_fused = False             # True: the owning inception runs the BN passes of its three branch outputs jointly
         self.pk, self.pkT = eng.packed(conv_mod)
@@ -245,6 +249,9 @@ class HourglassEngine:
         self._wgrad_stream = torch.cuda.Stream(device=self.device) \
             if mode != "none" and os.environ.get("CD_AMD_ENGINE_WGRAD_STREAM", "0") == "1" else None
         self._wgrad_pending = False
+        # BatchNorm as (scale, shift) applied by the consumers while loading (default), or round 2's in-place normalisation pass
+        # (CD_AMD_BN_APPLY=0: kept for A/B measurements on one box)
+        self.bn_apply = os.environ.get("CD_AMD_BN_APPLY", "1") != "0"
         # nn.BatchNorm2d counts its train-mode forwards (training steps AND the reference's train-mode validation batches);
         # momentum is fixed so nothing reads the counters, but they are part of the checkpoint the reference writes
         self._batch_counters = [m.num_batches_tracked for m in net.modules()
@@ -297,11 +304,14 @@ class HourglassEngine:
         launch turns the statistics into the (scale, shift) the consumers apply while loading the raw convolution output."""
         rm, rv = running
         cnt = float(buf.shape[0] * buf.shape[2] * buf.shape[3])
-        if training:
-            L.bn_finalize(stats, coff, C, cnt, mi, scale, shift, BN_EPS, gamma, beta, rm, rv, BN_MOMENTUM)
-        else:   # synthesised sums in slot 0 (the others stay zero); nothing is updated
+        if not training:   # synthesised sums in slot 0 (the others stay zero); nothing is updated
             stats[0, coff:coff + C, 0] = rm.double() * cnt
             stats[0, coff:coff + C, 1] = (rv.double() + rm.double() * rm.double()) * cnt
+        if scale is None:  # CD_AMD_BN_APPLY=0 (A/B): round 2's in-place normalisation, x_hat in the buffer
+            L.bn_normalize(buf, coff, C, stats, mi, BN_EPS, rm if training else None, rv if training else None, BN_MOMENTUM)
+        elif training:
+            L.bn_finalize(stats, coff, C, cnt, mi, scale, shift, BN_EPS, gamma, beta, rm, rv, BN_MOMENTUM)
+        else:
             L.bn_finalize(stats, coff, C, cnt, mi, scale, shift, BN_EPS, gamma, beta)
 
     def on_wgrad_stream(self, job):
@@ -361,7 +371,10 @@ class HourglassEngine:
         Pg = torch.empty_like(P)
         stats = self._stats(plan, M + Co)
         mi = torch.zeros(M + Co, 2, device=self.device)
-        sc, sh = torch.ones(M + Co, device=self.device), torch.zeros(M + Co, device=self.device)   # apply-on-load BatchNorm of P
+        sc = sh = None
+        if self.bn_apply:
+            sc, sh = torch.ones(M + Co, device=self.device), torch.zeros(M + Co, device=self.device)   # apply-on-load BatchNorm of P
+        sl = (lambda t, a, n: t[a:a + n]) if self.bn_apply else (lambda t, a, n: None)
         members, moff = [], 0
         for i, br in enumerate(list(mod.convs)[1:]):
             members.append(_Member(br[0], br[1], moff))
@@ -372,13 +385,13 @@ class HourglassEngine:
         group = PointwiseGroup(self, members, x, P, Pg, stats, mi, filt, filtT, run_entry, sc, sh)
         units, ooff, moff = [], M + a0, 0
         for i, br in enumerate(list(mod.convs)[1:]):
-            mid = Act(P, moff, mids[i], relu=True, scale=sc[moff:moff + mids[i]], shift=sh[moff:moff + mids[i]], needs_grad=False)
+            mid = Act(P, moff, mids[i], relu=True, scale=sl(sc, moff, mids[i]), shift=sl(sh, moff, mids[i]), needs_grad=False)
             mid.gbuf = Pg
             units.append((ConvUnit(self, br[3], br[4], mid, P, ooff, stats, mi, sc, sh), Pg, ooff))
             units[-1][0].bn_fused = True
             ooff += outs[i + 1]
             moff += mids[i]
-        out = Act(P, M, Co, relu=True, scale=sc[M:M + Co], shift=sh[M:M + Co], needs_grad=False)
+        out = Act(P, M, Co, relu=True, scale=sl(sc, M, Co), shift=sl(sh, M, Co), needs_grad=False)
         out.gbuf = Pg
         steps.append(_Node("inception", group=group, units=units, out=out, src=x, P=P, Pg=Pg, stats=stats, mi=mi, bn_scale=sc, bn_shift=sh,
                            bn_coff=M + a0, bn_C=sum(outs[1:]), bn_running=run_out, bn_sums=None))
@@ -431,7 +444,8 @@ class HourglassEngine:
         x_in = Act(plan["x"], 0, 3, needs_grad=False)
         stem_buf = self._new(N, 128, H, W)
         stem = ConvUnit(self, net.seq[0], net.seq[1], x_in, stem_buf, 0, self._stats(plan, 128), torch.zeros(128, 2, device=self.device),
-                        torch.ones(128, device=self.device), torch.zeros(128, device=self.device))
+                        torch.ones(128, device=self.device) if self.bn_apply else None,
+                        torch.zeros(128, device=self.device) if self.bn_apply else None)
         stem.out.gbuf = torch.empty_like(stem_buf)
         plan["steps"].append(_Node("conv", unit=stem, gbuf=stem.out.gbuf, g_coff=0))
         plan["convs"].append(stem)
@@ -602,7 +616,8 @@ class BlockRunner:
         self.eng._pack.run()
         self.eng._run_forward(self.plan["steps"], training)
         o = self.out      # the buffer holds the raw convolution output: apply the BatchNorm like every consumer does
-        return torch.relu(torch.addcmul(o.shift.view(1, -1, 1, 1), o.buf[:, o.coff:o.coff + o.C], o.scale.view(1, -1, 1, 1)))
+        v = o.buf[:, o.coff:o.coff + o.C]
+        return torch.relu(v if o.scale is None else torch.addcmul(o.shift.view(1, -1, 1, 1), v, o.scale.view(1, -1, 1, 1)))
 
     @torch.no_grad()
     def backward(self, dy: torch.Tensor) -> torch.Tensor:
