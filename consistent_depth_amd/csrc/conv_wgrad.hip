@@ -453,7 +453,9 @@ static int launch_wgrad_fewcin(const float* x, int x_ctot, int x_coff, int Cin, 
 
 
 static int g_wgrad_wide = 1;  // cd_debug_set_wgrad_mode bit 2 switches the wide 1x1 plan off (A/B measurements, tests)
-static int g_wgrad_dbg = 0;   // measurement hook: bit 0 skip the atomic flush, bit 1 skip the MFMAs (results are then wrong)
+// measurement hooks: bit 0 skip the atomic flush, bit 1 skip the MFMAs (results are then wrong); bit 4 (CD_AMD_WGRAD_COT1=1, read once:
+// workspace sizes depend on it) 16 x 16-channel blocks for every split-bf16 gradient (A/B of the 32 x 16 block of the 3x3 gradient)
+static int g_wgrad_dbg = [] { const char* e = getenv("CD_AMD_WGRAD_COT1"); return (e && e[0] == '1') ? 16 : 0; }();
 
 // The same for MANY gradients in one launch (blockIdx.y = descriptor): a network's backward leaves every partial-sum
 // buffer packed (cd_conv2d_wgrad accumulate bit 2) and unpacks them all at the end; one descriptor may take only the
@@ -531,7 +533,7 @@ static int launch_wgrad_t(const float* x, int x_ctot, int x_coff, int Cin, const
 
 // Packed layout and launch shape of one weight gradient -- ONE definition for the launchers, the workspace size,
 // cd_conv2d_wgrad_plan and the unpack descriptors.
-struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide, split_arith, split1x1, blocks_x; size_t slice; };
+struct WgLayout { int cob, cib, cogs, cigs, splits, max_splits, fewcin, wide, split_arith, split1x1, blocks_x, cot; size_t slice; };
 
 // the split-bf16 kernel (wgrad_split.hip) takes the k = 3, 5, 7, 11 gradients when that arithmetic is selected (cd_set_conv_arith),
 // except the RGB stem (3 input channels would pad a 16-wide tile 5-fold: the few-input-channel fp32 kernel stays)
@@ -558,8 +560,19 @@ static WgLayout wgrad_layout_split(int Cout, int Cin, int ks, int N, int H, int 
     L.cogs = (Cout + 15) / 16; L.cigs = (Cin + 15) / 16;
     L.slice = (size_t)L.cogs * L.cigs * ks * ks * 256;
     const int per_cu = wgrad_split_blocks_per_cu(ks);
-    L.max_splits = wgrad_splits(L.cogs * L.cigs, per_cu, 1 << 30);
-    L.splits = N > 0 ? wgrad_splits(L.cogs * L.cigs, per_cu, wgrad_items(N, H, W, wgrad_split_tile_rows(ks))) : L.max_splits;
+    // 16-channel output groups per block (the packed tiles stay 16 x 16): two for the 3x3 gradient when that still fills the chip
+    // -- measured (profiles/wgrad3x3_r03.txt): 64 -> 32 @192x112 122 -> 99 us, 64 -> 64 @96x56 59 -> 47 us, but 32 -> 32 @96x56
+    // 30 -> 38 us with only 320 blocks left
+    const int zg1 = L.cogs * L.cigs, zg2 = ((L.cogs + 1) / 2) * L.cigs;
+    const bool may2 = !(g_wgrad_dbg & 16) && wgrad_split_cot(ks, Cout) == 2;
+    L.cot = 1;
+    if (may2 && N > 0) {
+        const int items = wgrad_items(N, H, W, wgrad_split_tile_rows(ks));
+        if (zg2 * wgrad_splits(zg2, per_cu, items) >= 384) L.cot = 2;
+    }
+    const int zgroups = L.cot == 2 ? zg2 : zg1;
+    L.max_splits = wgrad_splits(may2 ? zg2 : zg1, per_cu, 1 << 30);      // (workspace: room for either choice)
+    L.splits = N > 0 ? wgrad_splits(zgroups, per_cu, wgrad_items(N, H, W, wgrad_split_tile_rows(ks))) : L.max_splits;
     return L;
 }
 
@@ -590,7 +603,7 @@ static WgLayout wgrad_layout(int Cout, int Cin, int ks, int N, int H, int W, int
 extern "C" {
 
 int cd_debug_set_wgrad_mode(int bits) {
-    cd::g_wgrad_dbg = bits & 11;   // bit 3: generic kernel for the few-input-channel (stem) case
+    cd::g_wgrad_dbg = (bits & 11) | (cd::g_wgrad_dbg & 16);   // bit 3: generic kernel for the few-input-channel (stem) case; bit 4 is process-wide (below)
     cd::g_wgrad_wide = (bits & 4) ? 0 : 1;
     return CD_OK;
 }
@@ -661,7 +674,7 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     }
     if (L.split_arith) {
         rc = cd::launch_wgrad_split(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, workspace, N, H, W, ks,
-                                    L.splits, s);
+                                    L.splits, s, 1, 0, L.cot);
         if (rc != CD_OK || (accumulate & 4)) return rc;
         const int total = Cout * Cin * ks * ks;
         hipLaunchKernelGGL(cd::unpack_wgrad_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s, workspace,
@@ -720,7 +733,7 @@ int cd_conv2d_wgrad_grouped(const float* x, int x_ctot, int x_coff, int cin_g, c
     const cd::WgLayout L = cd::wgrad_layout(cout_g, cin_g, ks, N, H, W);
     if (L.split_arith && groups <= 65535 / L.cogs) {   // ONE launch for all groups (+ one unpack)
         const int rc = cd::launch_wgrad_split(x, x_ctot, x_coff, cin_g, nullptr, nullptr, 0, dy, dy_ctot, dy_coff, cout_g, workspace, N, H, W, ks,
-                                              L.splits, s, groups, workspace_group_stride);
+                                              L.splits, s, groups, workspace_group_stride, L.cot);
         if (rc != CD_OK) return rc;
         const int total = cout_g * cin_g * ks * ks;
         const int bx = (total + 255) / 256 > 64 ? 64 : (total + 255) / 256;

@@ -9,10 +9,17 @@ __host__ __device__ constexpr int wgrad_split_tile_rows(int ks) { return ks == 1
 // resident blocks per CU (k = 11: one 8-wave block with a 109 KB tile; else two 4-wave blocks)
 __host__ __device__ constexpr int wgrad_split_blocks_per_cu(int ks) { return ks == 11 ? 1 : 2; }
 
+// 16-channel OUTPUT groups per block: k = 3 with >= 32 output channels takes TWO (a 32 x 16 channel block).  With one, the 9 taps
+// are shared by three of the four waves (3 accumulator tiles each, the fourth wave idle) and the input tile with its halo -- 2/3 of
+// the staged bytes -- is staged once per 16 output channels; with two, every wave has a sub-tile's 4-5 taps and the input tile
+// serves twice the multiply-adds (profiles/wgrad3x3_r03.txt).  The packed result keeps its 16 x 16 tiles: same unpack, same bits.
+__host__ __device__ constexpr int wgrad_split_cot(int ks, int Cout) { return (ks == 3 && Cout >= 32) ? 2 : 1; }
+
 // partial sums into packed[split][co group][ci group][tap][16][16]; `splits` blocks per channel-group pair
 int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,
                        const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int ks, int splits,
-                       hipStream_t s, int groups = 1, size_t ws_group_stride = 0);   // groups > 1: Cin / Cout per group, slices g * Cin / g * Cout
+                       hipStream_t s, int groups = 1, size_t ws_group_stride = 0, int cot = 1);   // groups > 1: Cin / Cout per group, slices g * Cin / g * Cout;
+                                                                                                  // cot: 16-channel output groups per block (the layout's choice)
 
 // ---- 1x1 weight gradient (wgrad1x1_split.hip): a wave owns a 64 x 128 (co x ci) patch of dW
 constexpr int WGRAD1X1_COB = 64, WGRAD1X1_CIB = 128;

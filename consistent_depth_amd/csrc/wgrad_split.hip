@@ -41,29 +41,30 @@ __device__ __forceinline__ void ws_split_pair(float a, float b, unsigned& h, uns
 
 constexpr int ws_pad(int words) { return words + ((4 - words % 8) + 8) % 8; }   // == 4 (mod 8): 16 channel planes tile the 64 banks
 
-template <int KS> struct WsCfg {
+template <int KS, int COT = 1> struct WsCfg {
     static constexpr int TY = wgrad_split_tile_rows(KS);
     static constexpr int NW = KS == 11 ? 8 : 4;               // waves per block (k = 11: 8 x 16 taps = 64 accumulator registers each)
-    static constexpr int P = (KS - 1) / 2, TAPS = KS * KS, TPW = (TAPS + NW - 1) / NW;
+    static constexpr int WPS = NW / COT;                      // waves per 16 x 16 sub-tile (COT output-channel groups per block)
+    static constexpr int P = (KS - 1) / 2, TAPS = KS * KS, TPW = (TAPS + WPS - 1) / WPS;
     static constexpr int ROWS = TY + KS - 1;
     static constexpr int XW = 48;                              // pixels per LDS row of X: [X0 - 8, X0 + 40)
     static constexpr int PSX = ws_pad(ROWS * XW / 2);          // 32-bit words per channel plane
     static constexpr int PSD = ws_pad(TY * 32 / 2);
-    static constexpr int SPX = 16 * PSX, SPD = 16 * PSD;       // words per split plane set
+    static constexpr int SPX = 16 * PSX, SPD = 16 * COT * PSD;   // words per split plane set
     static constexpr size_t LDS = (size_t)3 * (SPX + SPD) * 4;
 };
 
-// One wave's share of a staged tile: taps [WV * TPW, (WV+1) * TPW) of the flattened index.
-template <int KS, int WV>
-__device__ __forceinline__ void ws_wave(const unsigned* __restrict__ s_x, const unsigned* __restrict__ s_dy, f32x4 (&acc)[WsCfg<KS>::TPW],
+// One wave's share of a staged tile: output-channel sub-tile WV / WPS, taps [(WV % WPS) * TPW, + TPW) of the flattened index.
+template <int KS, int WV, int COT>
+__device__ __forceinline__ void ws_wave(const unsigned* __restrict__ s_x, const unsigned* __restrict__ s_dy, f32x4 (&acc)[WsCfg<KS, COT>::TPW],
                                         int lane) {
-    using Cfg = WsCfg<KS>;
+    using Cfg = WsCfg<KS, COT>;
     constexpr int TY = Cfg::TY, P = Cfg::P, TAPS = Cfg::TAPS, TPW = Cfg::TPW, PSX = Cfg::PSX, PSD = Cfg::PSD, SPX = Cfg::SPX, SPD = Cfg::SPD;
-    constexpr int T0 = WV * TPW, T1 = (T0 + TPW < TAPS) ? T0 + TPW : TAPS;
+    constexpr int SUB = WV / Cfg::WPS, T0 = (WV % Cfg::WPS) * TPW, T1 = (T0 + TPW < TAPS) ? T0 + TPW : TAPS;
     if constexpr (T0 < T1) {
         constexpr int KY0 = T0 / KS, KY1 = (T1 - 1) / KS;
         const int li = lane & 15, g = lane >> 4;
-        const unsigned* a_ptr = s_dy + li * PSD + 4 * g;
+        const unsigned* a_ptr = s_dy + (SUB * 16 + li) * PSD + 4 * g;
         const unsigned* w_ptr = s_x + li * PSX + 4 * g;
 #pragma unroll 1
         for (int y = 0; y < TY; ++y) {
@@ -101,23 +102,24 @@ __device__ __forceinline__ void ws_wave(const unsigned* __restrict__ s_x, const 
     }
 }
 
-template <int KS>
-__global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel(
+template <int KS, int COT>
+__global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split_kernel(
     const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
     const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
-    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y, int cogs, int g_xc, int g_dyc, size_t g_ws) {
-    using Cfg = WsCfg<KS>;
+    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y, int cogs, int zpg, int g_xc, int g_dyc, size_t g_ws) {
+    using Cfg = WsCfg<KS, COT>;
     constexpr int TY = Cfg::TY, P = Cfg::P, TAPS = Cfg::TAPS, TPW = Cfg::TPW, ROWS = Cfg::ROWS, PSX = Cfg::PSX, PSD = Cfg::PSD;
     constexpr int SPX = Cfg::SPX, SPD = Cfg::SPD, NT = Cfg::NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned ws_smem[];
     unsigned* s_x = ws_smem;               // [3][16 ci][PSX]
-    unsigned* s_dy = ws_smem + 3 * SPX;    // [3][16 co][PSD]
+    unsigned* s_dy = ws_smem + 3 * SPX;    // [3][16 * COT co][PSD]
 
-    // blockIdx.z = group * cogs + cog: a grouped convolution is `groups` independent gradients on channel slices, each with its
-    // own packed workspace (g_ws floats apart); dense launches have one group
-    const int grp = blockIdx.z / cogs;
-    const int cig = blockIdx.y, cog = blockIdx.z - grp * cogs;
+    // blockIdx.z = group * zpg + cog: a grouped convolution is `groups` independent gradients on channel slices, each with its
+    // own packed workspace (g_ws floats apart); dense launches have one group.  cog counts blocks of 16 * COT output channels
+    // (zpg per group), `cogs` the 16-channel tiles of the packed layout.
+    const int grp = blockIdx.z / zpg;
+    const int cig = blockIdx.y, cog = blockIdx.z - grp * zpg;
     x_coff += grp * g_xc;
     dy_coff += grp * g_dyc;
     dw_packed += (size_t)grp * g_ws;
@@ -138,10 +140,10 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
         // ---- staging: fp32 -> (affine, relu) -> three bf16 planes, pixels contiguous.  Elements go in batches of 4 per thread whose
         // loads are UNCONDITIONAL (clamped address, padding zeroed with an AND afterwards): all loads of a batch are in flight before
         // the first wait (a load under a divergent branch is followed by s_waitcnt vmcnt(0): one full latency per element).
-        // One element = 4 consecutive pixels of one channel row.  `stage(rows, quads, ...)` covers a [16 ch][rows][quads] tile.
-        auto stage = [&](const float* __restrict__ src_n, int ch0, int ch_n, int rows, int quads, int y0, int x0, unsigned* __restrict__ dst,
+        // One element = 4 consecutive pixels of one channel row.  `stage(nch, rows, quads, ...)` covers a [nch][rows][quads] tile.
+        auto stage = [&](const float* __restrict__ src_n, int ch0, int ch_n, int nch, int rows, int quads, int y0, int x0, unsigned* __restrict__ dst,
                          int plane_words, int row_words, int split_words, bool affine) {
-            const int total = 16 * rows * quads;
+            const int total = nch * rows * quads;
             constexpr int BATCH = 4;
             for (int i0 = threadIdx.x; i0 < total; i0 += NT * BATCH) {
                 float v[BATCH][4], asc[BATCH], ash[BATCH];
@@ -200,28 +202,31 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
         };
         // dY tile (zero outside the image / beyond Cout), then the activated input tile with halo: rows [Y0 - P, Y0 + TY + P),
         // pixels [X0 - 8, X0 + 40)
-        stage(dy + ((size_t)n * dy_ctot + dy_coff) * HW, cog * 16, Cout, TY, 8, Y0, X0, s_dy, PSD, 16, SPD, false);
-        stage(x + ((size_t)n * x_ctot + x_coff) * HW, cig * 16, Cin, ROWS, 12, Y0 - P, X0 - 8, s_x, PSX, 24, SPX, true);
+        stage(dy + ((size_t)n * dy_ctot + dy_coff) * HW, cog * 16 * COT, Cout, 16 * COT, TY, 8, Y0, X0, s_dy, PSD, 16, SPD, false);
+        stage(x + ((size_t)n * x_ctot + x_coff) * HW, cig * 16, Cin, 16, ROWS, 12, Y0 - P, X0 - 8, s_x, PSX, 24, SPX, true);
         __syncthreads();
-        if (wid == 0) ws_wave<KS, 0>(s_x, s_dy, acc, lane);
-        else if (wid == 1) ws_wave<KS, 1>(s_x, s_dy, acc, lane);
-        else if (wid == 2) ws_wave<KS, 2>(s_x, s_dy, acc, lane);
-        else if (wid == 3) ws_wave<KS, 3>(s_x, s_dy, acc, lane);
+        if (wid == 0) ws_wave<KS, 0, COT>(s_x, s_dy, acc, lane);
+        else if (wid == 1) ws_wave<KS, 1, COT>(s_x, s_dy, acc, lane);
+        else if (wid == 2) ws_wave<KS, 2, COT>(s_x, s_dy, acc, lane);
+        else if (wid == 3) ws_wave<KS, 3, COT>(s_x, s_dy, acc, lane);
         else if constexpr (Cfg::NW == 8) {
-            if (wid == 4) ws_wave<KS, 4>(s_x, s_dy, acc, lane);
-            else if (wid == 5) ws_wave<KS, 5>(s_x, s_dy, acc, lane);
-            else if (wid == 6) ws_wave<KS, 6>(s_x, s_dy, acc, lane);
-            else ws_wave<KS, 7>(s_x, s_dy, acc, lane);
+            if (wid == 4) ws_wave<KS, 4, COT>(s_x, s_dy, acc, lane);
+            else if (wid == 5) ws_wave<KS, 5, COT>(s_x, s_dy, acc, lane);
+            else if (wid == 6) ws_wave<KS, 6, COT>(s_x, s_dy, acc, lane);
+            else ws_wave<KS, 7, COT>(s_x, s_dy, acc, lane);
         }
     }
 
-    // ---- flush: this block's slice, packed [split][cog][cig][tap][16 co][16 ci]
+    // ---- flush: this block's slice, packed [split][cog16][cig][tap][16 co][16 ci]; the wave's sub-tile is 16-channel group
+    // cog * COT + sub of the packed layout (absent when Cout is not a multiple of 16 * COT)
+    const int sub = wid / Cfg::WPS, cog16 = cog * COT + sub;
+    if (cog16 >= cogs) return;
     const size_t slice = (size_t)cogs * gridDim.y * TAPS * 256;
-    const size_t base = (size_t)blockIdx.x * slice + ((size_t)cog * gridDim.y + cig) * TAPS * 256;
+    const size_t base = (size_t)blockIdx.x * slice + ((size_t)cog16 * gridDim.y + cig) * TAPS * 256;
     const int ci_l = lane & 15, co4 = (lane >> 4) * 4;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int tap = wid * TPW + t;
+        const int tap = (wid % Cfg::WPS) * TPW + t;
         if (tap < TAPS) {
             float* dst = dw_packed + base + ((size_t)tap * 16 + co4) * 16 + ci_l;
             const f32x4 v = acc[t];
@@ -230,31 +235,32 @@ __global__ __launch_bounds__(WsCfg<KS>::NW * 64, 2) void conv_wgrad_split_kernel
     }
 }
 
-template <int KS>
+template <int KS, int COT>
 static int launch_ws(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,
                      const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int splits, hipStream_t s,
                      int groups, size_t ws_group_stride) {
-    using Cfg = WsCfg<KS>;
+    using Cfg = WsCfg<KS, COT>;
     const int tiles_x = (W + 31) / 32, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
-    const int cogs = (Cout + 15) / 16, cigs = (Cin + 15) / 16;
+    const int cogs = (Cout + 15) / 16, cigs = (Cin + 15) / 16, zpg = (cogs + COT - 1) / COT;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<KS, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_split_kernel<KS>), dim3(splits, cigs, cogs * groups), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ctot, x_coff, Cin, in_scale,
-                       in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y, cogs, groups > 1 ? Cin : 0,
+    hipLaunchKernelGGL((conv_wgrad_split_kernel<KS, COT>), dim3(splits, cigs, zpg * groups), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ctot, x_coff, Cin,
+                       in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y, cogs, zpg, groups > 1 ? Cin : 0,
                        groups > 1 ? Cout : 0, ws_group_stride);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
 int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,
                        const float* dy, int dy_ctot, int dy_coff, int Cout, float* packed, int N, int H, int W, int ks, int splits,
-                       hipStream_t s, int groups, size_t ws_group_stride) {
-    if (ks == 11) return launch_ws<11>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
-    if (ks == 7) return launch_ws<7>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
-    if (ks == 3) return launch_ws<3>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
-    if (ks == 5) return launch_ws<5>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+                       hipStream_t s, int groups, size_t ws_group_stride, int cot) {
+    if (ks == 11) return launch_ws<11, 1>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+    if (ks == 7) return launch_ws<7, 1>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+    if (ks == 3 && cot == 2) return launch_ws<3, 2>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+    if (ks == 3) return launch_ws<3, 1>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
+    if (ks == 5) return launch_ws<5, 1>(x, x_ctot, x_coff, Cin, in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, splits, s, groups, ws_group_stride);
     return CD_ERR_UNSUPPORTED;
 }
 
