@@ -352,7 +352,9 @@ def main():
             "flops_per_pair": flops_per_pair, "per": "GPU, whole step time (BatchNorm, loss, Adam and launch gaps included: a lower bound "
                                                      "of what the convolution kernels reach while they run)",
             "peak_note": ("fp32-equivalent roof of the split-operand kernels = dense BF16 peak 2500 / 6 products" if split else
-                          "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)"),
+                          ("fp32 matrix instruction (v_mfma_f32_16x16x4_f32); a mixture for midas2 -- the dense 1x1 run as fp32 library GEMMs, "
+                           "the k >= 3 convolutions on the split-operand kernels (roof 416.7) -- priced against the lower peak"
+                           if args.model == "midas2" and args.backend == "hip" else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)")),
             "frac_of_fp32_mfma_peak": round(ach_tf / MFMA_FP32_PEAK_TFLOPS, 4),
             "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r03.txt (SQ_INSTS_VALU_MFMA_MOPS / SQ_BUSY_CU_CYCLES per kernel family), "
                                 "profiles/conv_roofline_r03.txt (per launch)"}
