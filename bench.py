@@ -244,8 +244,8 @@ def main():
     log(f"rank {rank}/{world} building {args.model} model, conv backend {args.backend}")
     model = model_cls(backend=args.backend, seed=0)
     model.train()
-    if args.model == "midas2" and args.graph:
-        log("midas2: the step runs eager (its layers are autograd functions over torch's allocator, not a static plan)")
+    if args.model == "midas2" and args.graph and os.environ.get("CD_AMD_MIDAS_GRAPH", "1") == "0":
+        log("midas2: CD_AMD_MIDAS_GRAPH=0 -> eager steps")
         args.graph = 0
     eager_step = FineTuneStep(model, params, world=world)
     step = GraphedFineTuneStep(eager_step, eager_steps=max(1, min(2, args.warmup - 1))) if args.graph else eager_step
@@ -254,11 +254,29 @@ def main():
     store = PairStore.synthetic(args.frames, H, W, seed=0, device=device, max_pairs=args.max_pairs or None)
     plans = EpochPlans(len(store), rank, world, B, device, seed=0)
     log(f"pair store: {args.frames} frames, {len(store)} pairs, {store.nbytes / 1e9:.2f} GB resident")
+    scene_scale = 1.0
+    if args.model == "midas2":
+        # The reference's scale-calibration stage (scale_calibration.py:305-313) rescales the camera translations so that the
+        # geometry agrees with the network's INITIAL depth; the synthetic scene is in [0.5, 4] while a MiDaS-style network
+        # predicts inverse depth of order 1e2..1e3.  Same here: median initial depth / median scene depth, decided by rank 0.
+        with torch.no_grad():
+            sel = torch.arange(0, store.color.shape[0], max(1, store.color.shape[0] // 8), device=device)[:8]
+            d0 = model.estimate_depth(store.color[sel])
+            gt = torch.as_tensor(store.gt_depth[sel.cpu().numpy()], dtype=torch.float32, device=device)
+            factor = (d0.median() / gt.median()).reshape(1)
+        if world > 1:
+            dist.broadcast(factor, 0)
+        scene_scale = float(factor.item())
+        store.scale_scene_(scene_scale)
+        log(f"scale calibration: scene scaled by {scene_scale:.5g} to the network's initial depth")
+
+    step_losses = []
 
     def run(n):
         last = None
         for _ in range(n):
             last, _, _ = step.step_from_store(store, plans.next())
+            step_losses.append(last)
         return last
 
     for i in range(args.warmup):
@@ -282,6 +300,7 @@ def main():
     if not graphed:   # event records of the in-step loss profiler are not captured into graphs: eager only
         assert lib.cd_profile_begin(args.steps + 8) == 0
     t0 = time.perf_counter()
+    step_losses.clear()
     last_loss = run(args.steps)
     t_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (no sync inside the loop)
     torch.cuda.synchronize()
@@ -289,6 +308,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # A non-finite loss makes the device-side guard skip the Adam update of that step (the reference skips NaN steps too,
+    # depth_fine_tuning.py:372-376): such a step is not a full step, and a timed region containing one is not a measurement.
+    # (graph replays return a clone of the static loss buffer: one tensor per step here too)
+    finite_steps = int(torch.isfinite(torch.stack([l.reshape(()) for l in step_losses])).sum().item())
+    if finite_steps != args.steps:
+        sys.exit(f"bench.py: {args.steps - finite_steps} of {args.steps} timed steps had a non-finite loss (Adam update skipped): "
+                 f"not a valid measurement")
     # With graph replay the in-step loss kernel is timed in 3 eager steps after the timed region.  Those steps contain the
     # gradient all-reduce, so the decision to run them must be the same on every rank (capture could fail on a single one).
     extra = graphed
@@ -328,7 +354,7 @@ def main():
                                if args.model == "mc" else
                                (f"midas2 plugin: MiDaS-v2-shaped backbone (ResNeXt-101 32x8d + feature-fusion decoder restated, random init, "
                                 f"seed 0), fine-tuning steps over a synthetic {args.frames}-frame {H}x{W} clip ({len(store)} pairs), BS{B} pairs/GPU, "
-                                f"lambda_r 1.0 lambda_b 1e-4, Adam lr 1e-4, eager steps (BASELINE configs[4] shape on {world} GPU(s); convolutions: "
+                                f"lambda_r 1.0 lambda_b 1e-4, Adam lr 1e-4 (BASELINE configs[4] shape on {world} GPU(s); convolutions: "
                                 + ("hand-written HIP kernels through ops/conv_layer.py)" if args.backend == "hip" else "PyTorch-ROCm/MIOpen)")),
                    "model": args.model,
                    "conv_backend": args.backend,
@@ -338,7 +364,8 @@ def main():
                    if args.backend == "hip" else "MIOpen fp32",
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "hip_graph": graphed, "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),
-                   "last_loss": float(last_loss.item())},
+                   "last_loss": float(last_loss.item()), "finite_loss_steps": finite_steps,
+                   **({"scene_scale": round(scene_scale, 6)} if scene_scale != 1.0 else {})},
     }
 
     if rank == 0:

@@ -89,6 +89,16 @@ class PairStore:
         self._refresh_constants()
         return self
 
+    def scale_scene_(self, factor: float):
+        """Multiply the scene's metric scale by `factor`: camera translations (and the synthetic ground-truth depth, if any)
+        scale, flows/masks/intrinsics do not depend on it.  This is what the reference's scale-calibration stage does to the
+        COLMAP cameras so that the geometry matches the depth network's initial prediction (scale_calibration.py:305-313:
+        `extrinsics[..., -1] /= mean_scale`)."""
+        self.extrinsics[..., 3] *= float(factor)
+        if getattr(self, "gt_depth", None) is not None:
+            self.gt_depth = self.gt_depth * float(factor)
+        return self
+
     def __len__(self):
         return self.flows.shape[0]
 

@@ -22,6 +22,8 @@ class MidasV2Model(DepthModel):
     lambda_view_baseline = 0.0001
     depth_mode = DEPTH_RECIPROCAL  # depth = 1 / disparity, :67
 
+    RANDOM_INIT_DISPARITY = 300.0
+
     def __init__(self, support_cpu: bool = False, pretrained: bool = False, seed: int = 0, backend: str = None):
         super().__init__()
         if not torch.cuda.is_available():
@@ -39,12 +41,15 @@ class MidasV2Model(DepthModel):
         if self.pretrained:
             self.model.load_state_dict(torch.load(weights, map_location="cpu"))
         else:
-            # random-init stand-in (no network for model-f46da743.pt): keep the predicted inverse depth strictly
-            # positive so depth = 1/out is finite -- the final ReLU would otherwise zero about half the pixels
+            # random-init stand-in (no network for model-f46da743.pt): the predicted inverse depth starts at the magnitude of
+            # real MiDaS-v2 outputs (1e2..1e3) instead of straddling zero.  The final ReLU would otherwise zero about half the
+            # pixels (depth = 1/0), and with an O(1) output the first Adam steps (+-lr on each of 105 M weights, no
+            # normalisation layer in the decoder) move the prediction by ~0.7 per step and push pixels through zero within a
+            # handful of steps: a NaN loss that the guard then skips forever (measured: tools/exp/diag_midas_nan.py)
             with torch.no_grad():
                 head = self.model.scratch.output_conv[4]
                 head.weight.mul_(0.1)
-                head.bias.fill_(1.0)
+                head.bias.fill_(self.RANDOM_INIT_DISPARITY)
         self.model.to(self.device)
         self.register_buffer("norm_mean", torch.tensor([0.485, 0.456, 0.406]).reshape(1, -1, 1, 1).to(self.device))
         self.register_buffer("norm_stdev", torch.tensor([0.229, 0.224, 0.225]).reshape(1, -1, 1, 1).to(self.device))
