@@ -457,9 +457,12 @@ def main():
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
                 c5 = json.loads(line)
                 out["config5"] = {"value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"], "steps": c5["steps"],
-                                  "n_gpus": 1, "workload": c5["config"]["workload"], "roofline_conv": c5.get("roofline_conv")}
+                                  "n_gpus": 1, "finite_loss_steps": c5["config"].get("finite_loss_steps"),
+                                  "last_loss": c5["config"].get("last_loss"), "hip_graph": c5["config"].get("hip_graph"),
+                                  "workload": c5["config"]["workload"], "roofline_conv": c5.get("roofline_conv")}
             except (subprocess.TimeoutExpired, IndexError, ValueError, KeyError) as e:
-                out["config5"] = {"value": None, "note": f"not completed within {args.config5_timeout}s ({type(e).__name__})"}
+                out["config5"] = {"value": None, "note": f"no line within {args.config5_timeout}s ({type(e).__name__}): "
+                                                         + (getattr(e, "stderr", None) or getattr(locals().get("r"), "stderr", "") or "")[-300:]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -32,6 +32,10 @@
 #include "cd_common.h"
 #include "conv_split.h"
 
+#ifndef CD_SP_DBG        // measurement builds (tools/exp/build_variants.sh): 1 = no MFMA phase, 2 = no staging (profiles/conv_phases_r03.txt)
+#define CD_SP_DBG 0
+#endif
+
 namespace cd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -286,7 +290,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
         // ---- stage: global fp32 -> (affine, relu) -> three bf16 planes, channels-last.  The 8 loads of a unit are UNCONDITIONAL
         // (clamped address; padding zeroed with an AND afterwards) so that they are all in flight before the first wait: a load
         // under a divergent branch is followed by s_waitcnt vmcnt(0), which serialised the 8 channels.
-        for (int uu = threadIdx.x; uu < CGS * UNITS; uu += kBlock) {
+        // (Fetching a thread's unit for round r + 1 BEFORE the MFMA phase of round r was tried in round 3 and is slower: the weight
+        // fragments below are global loads too, vmcnt retires in order, so the first fragment wait of the phase also waits for the
+        // whole prefetch -- nothing overlaps; profiles/conv_phases_r03.txt.)
+        for (int uu = threadIdx.x; uu < ((CD_SP_DBG & 2) ? 0 : CGS * UNITS); uu += kBlock) {
             const int g2 = uu / UNITS, u = uu - g2 * UNITS;
             float v[8][4], sc[8], sh[8];
             unsigned keep[4];
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
                             acc[mg + m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[p]], bcur[t][PB[p]], acc[mg + m][t], 0, 0, 0);
             }
         };
+        if (CD_SP_DBG & 1) { lin += ((lin_end - lin + 3) / 4) * 4; continue; }
 #pragma unroll 1
         for (; lin + 4 < lin_end; lin += 8) {   // two steps per trip: the buffers swap roles without a register copy
             step(bA, bB, lin);

@@ -19,6 +19,13 @@
 #include "cd_common.h"
 #include "wgrad_split.h"
 
+#ifndef CD_WGRAD_AHEAD11
+#define CD_WGRAD_AHEAD11 0
+#endif
+#ifndef CD_WS_DBG        // measurement builds (tools/exp/build_variants.sh): 1 = no MFMA phase, 2 = no staging (fetch / commit)
+#define CD_WS_DBG 0
+#endif
+
 namespace cd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,10 +58,16 @@ template <int KS, int COT = 1> struct WsCfg {
     static constexpr int PSX = ws_pad(ROWS * XW / 2);          // 32-bit words per channel plane
     static constexpr int PSD = ws_pad(TY * 32 / 2);
     static constexpr int SPX = 16 * PSX, SPD = 16 * COT * PSD;   // words per split plane set
-    static constexpr size_t LDS = (size_t)3 * (SPX + SPD) * 4;
+    static constexpr size_t LDS = (size_t)3 * (SPX + SPD) * 4 + 128;   // + scale / shift of the block's 16 input channels
 };
 
-// One wave's share of a staged tile: output-channel sub-tile WV / WPS, taps [(WV % WPS) * TPW, + TPW) of the flattened index.
+// One wave's share of a staged tile: output-channel sub-tile WV / WPS, taps [(WV % WPS) * TPW, + TPW) of the flattened index
+// (13 at k = 7, 16 at k = 11: they span two or three filter rows).  Per output row y and B split the windows of ALL the wave's filter
+// rows are loaded (three ds_read_b128 = 12 registers each) and the MFMAs walk over all the wave's taps before the next dY split
+// revisits an accumulator: v_mfma_f32_16x16x32_bf16 needs many independent accumulators in flight (profiles/mfma_rate_exp_r02.txt:
+// 55 % of its rate with 4-8, the full rate with 16); the round-robin over the 5-11 taps of ONE filter row (rounds 2/3) ran the MFMA
+// phase at ~60 % even with the operand work and the LDS reads removed (profiles/wgrad_phases_r03.txt).  Every accumulator still
+// receives its six products per row in the same order -- lo x hi; mid x mid, mid x hi; hi x lo, hi x mid, hi x hi -- same bits.
 template <int KS, int WV, int COT>
 __device__ __forceinline__ void ws_wave(const unsigned* __restrict__ s_x, const unsigned* __restrict__ s_dy, f32x4 (&acc)[WsCfg<KS, COT>::TPW],
                                         int lane) {
@@ -62,7 +75,7 @@ __device__ __forceinline__ void ws_wave(const unsigned* __restrict__ s_x, const 
     constexpr int TY = Cfg::TY, P = Cfg::P, TAPS = Cfg::TAPS, TPW = Cfg::TPW, PSX = Cfg::PSX, PSD = Cfg::PSD, SPX = Cfg::SPX, SPD = Cfg::SPD;
     constexpr int SUB = WV / Cfg::WPS, T0 = (WV % Cfg::WPS) * TPW, T1 = (T0 + TPW < TAPS) ? T0 + TPW : TAPS;
     if constexpr (T0 < T1) {
-        constexpr int KY0 = T0 / KS, KY1 = (T1 - 1) / KS;
+        constexpr int KY0 = T0 / KS, KY1 = (T1 - 1) / KS, NKY = KY1 - KY0 + 1;
         const int li = lane & 15, g = lane >> 4;
         const unsigned* a_ptr = s_dy + (SUB * 16 + li) * PSD + 4 * g;
         const unsigned* w_ptr = s_x + li * PSX + 4 * g;
@@ -72,31 +85,29 @@ __device__ __forceinline__ void ws_wave(const unsigned* __restrict__ s_x, const 
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_ptr + sp * SPD + y * 16));
 #pragma unroll
-            for (int ky = KY0; ky <= KY1; ++ky) {
-                const int kxa = (T0 - ky * KS > 0) ? T0 - ky * KS : 0, kxb = (T1 - ky * KS < KS) ? T1 - ky * KS : KS;   // folded: ky is unrolled
-                // one B split at a time (its window is 23 registers): lo with dY hi; mid with dY mid, hi; hi with dY lo, mid, hi
+            for (int sp = 2; sp >= 0; --sp) {
+                __builtin_amdgcn_sched_barrier(0);   // keep the windows of later splits / rows out of this group's registers
+                unsigned w[NKY][12];
 #pragma unroll
-                for (int sp = 2; sp >= 0; --sp) {
-                    __builtin_amdgcn_sched_barrier(0);   // keep the windows of later splits / rows out of this group's registers
-                    unsigned w[12];
+                for (int r = 0; r < NKY; ++r)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(w_ptr + sp * SPX + (y + ky) * 24 + 4 * q);
-                        w[4 * q] = v[0]; w[4 * q + 1] = v[1]; w[4 * q + 2] = v[2]; w[4 * q + 3] = v[3];
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(w_ptr + sp * SPX + (y + KY0 + r) * 24 + 4 * q);
+                        w[r][4 * q] = v[0]; w[r][4 * q + 1] = v[1]; w[r][4 * q + 2] = v[2]; w[r][4 * q + 3] = v[3];
                     }
 #pragma unroll
-                    for (int pa = 2 - sp; pa >= 0; --pa)   // dY splits paired with this B split, smallest product first
+                for (int pa = 2 - sp; pa >= 0; --pa)   // dY splits paired with this B split, smallest product first
 #pragma unroll
-                        for (int kx = 0; kx < KS; ++kx) {   // round-robin over the taps of the row: a dependent MFMA never follows its producer
-                            if (kx < kxa || kx >= kxb) continue;
-                            const int t = ky * KS + kx - T0, s = 8 - P + kx, r0 = s >> 1;
-                            u32x4 bv;   // pixels [s, s + 8) of the window: a register range, or (odd s) funnel-shifted by one pixel
-                            if (s & 1) bv = u32x4{__builtin_amdgcn_alignbit(w[r0 + 1], w[r0], 16), __builtin_amdgcn_alignbit(w[r0 + 2], w[r0 + 1], 16),
-                                                  __builtin_amdgcn_alignbit(w[r0 + 3], w[r0 + 2], 16), __builtin_amdgcn_alignbit(w[r0 + 4], w[r0 + 3], 16)};
-                            else bv = u32x4{w[r0], w[r0 + 1], w[r0 + 2], w[r0 + 3]};
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa], __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
-                        }
-                }
+                    for (int t = 0; t < T1 - T0; ++t) {   // all taps of the wave: a dependent MFMA is T1 - T0 instructions behind its producer
+                        const int ky = (T0 + t) / KS, kx = T0 + t - ky * KS, s = 8 - P + kx, r0 = s >> 1;
+                        const unsigned (&wc)[12] = w[ky - KY0];
+                        u32x4 bv;   // pixels [s, s + 8) of the window: a register range, or (odd s) funnel-shifted by one pixel
+                        if (CD_WS_DBG & 4) bv = u32x4{wc[r0 & ~1], wc[(r0 & ~1) + 1], wc[(r0 & ~1) + 2], wc[(r0 & ~1) + 3]};   // (what-if: no operand alignment work)
+                        else if (s & 1) bv = u32x4{__builtin_amdgcn_alignbit(wc[r0 + 1], wc[r0], 16), __builtin_amdgcn_alignbit(wc[r0 + 2], wc[r0 + 1], 16),
+                                                   __builtin_amdgcn_alignbit(wc[r0 + 3], wc[r0 + 2], 16), __builtin_amdgcn_alignbit(wc[r0 + 4], wc[r0 + 3], 16)};
+                        else bv = u32x4{wc[r0], wc[r0 + 1], wc[r0 + 2], wc[r0 + 3]};
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa], __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+                    }
             }
         }
     }
@@ -132,79 +143,108 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    // ---- staging: fp32 -> (affine, relu) -> three bf16 planes, pixels contiguous.  One element ("quad") = 4 consecutive pixels of
+    // one channel row; a tile is QDY quads of dY (zero outside the image / beyond Cout) followed by QX quads of the activated input
+    // with its halo, rows [Y0 - P, Y0 + TY + P), pixels [X0 - 8, X0 + 40); thread t owns the quads t + j * NT, j < NQ (QDY is a
+    // multiple of NT: the dY / X decision is per j, compile-time).  Staging is split in two halves around the MFMA phase:
+    //   fetch(item)  -- the raw global loads of a tile into NQ x 4 registers, UNCONDITIONAL (clamped address; padding is zeroed with
+    //                   an AND in the second half) so that all of them are in flight at once;
+    //   commit()     -- transform + split + LDS writes of the fetched tile.
+    // The fetch of tile i + 1 is issued BEFORE the MFMAs of tile i and committed after them: the memory latency of a tile (three
+    // serialised batches of loads in round 2/3's kernel, as long as its MFMA phase at k <= 7) is hidden behind the matrix cores;
+    // between two MFMA phases a block only pays the commit's vector ALU work.
+    constexpr int QDY = 16 * COT * TY * 8, QX = 16 * ROWS * 12, QT = QDY + QX, NQ = (QT + NT - 1) / NT, JDY = QDY / NT;
+    static_assert(QDY % NT == 0, "dY quads fill whole rounds of the block");
+    static_assert(NQ * 4 <= 64, "one keep bit per fetched pixel");
+    float* s_aff = reinterpret_cast<float*>(ws_smem + 3 * (SPX + SPD));   // [16][2]: scale, shift of this block's input channels
+    if (threadIdx.x < 16) {
+        const int ch = cig * 16 + (int)threadIdx.x < Cin ? cig * 16 + (int)threadIdx.x : Cin - 1;
+        s_aff[2 * threadIdx.x] = in_scale ? in_scale[ch] : 1.f;
+        s_aff[2 * threadIdx.x + 1] = in_scale ? in_shift[ch] : 0.f;
+    }
+    float4 pv[NQ];
+    unsigned long long pkeep = 0;
+    auto fetch = [&](int item) {
         const int n = item / (tiles_x * tiles_y), tile = item - n * (tiles_x * tiles_y);
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int X0 = tx * 32, Y0 = ty * TY;
-        __syncthreads();   // the previous tile is consumed
-        // ---- staging: fp32 -> (affine, relu) -> three bf16 planes, pixels contiguous.  Elements go in batches of 4 per thread whose
-        // loads are UNCONDITIONAL (clamped address, padding zeroed with an AND afterwards): all loads of a batch are in flight before
-        // the first wait (a load under a divergent branch is followed by s_waitcnt vmcnt(0): one full latency per element).
-        // One element = 4 consecutive pixels of one channel row.  `stage(nch, rows, quads, ...)` covers a [nch][rows][quads] tile.
-        auto stage = [&](const float* __restrict__ src_n, int ch0, int ch_n, int nch, int rows, int quads, int y0, int x0, unsigned* __restrict__ dst,
-                         int plane_words, int row_words, int split_words, bool affine) {
-            const int total = nch * rows * quads;
-            constexpr int BATCH = 4;
-            for (int i0 = threadIdx.x; i0 < total; i0 += NT * BATCH) {
-                float v[BATCH][4], asc[BATCH], ash[BATCH];
-                unsigned keep[BATCH][4];
+        const float* dy_n = dy + ((size_t)n * dy_ctot + dy_coff) * HW;
+        const float* x_n = x + ((size_t)n * x_ctot + x_coff) * HW;
+        pkeep = 0;
 #pragma unroll
-                for (int b = 0; b < BATCH; ++b) {
-                    const int i = i0 + b * NT;
-                    const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
-                    const int ch = ch0 + c, gy = y0 + r, gx = x0 + 4 * q;
-                    const bool base_ok = i < total && ch < ch_n && (unsigned)gy < (unsigned)H;
-                    const float* row = src_n + (size_t)(ch < ch_n ? ch : ch_n - 1) * HW + (size_t)((unsigned)gy < (unsigned)H ? gy : 0) * W;
-                    // the producer's BatchNorm scale / shift travel WITH the data loads (not as a second round trip afterwards)
-                    asc[b] = (affine && in_scale) ? in_scale[ch < ch_n ? ch : ch_n - 1] : 1.f;
-                    ash[b] = (affine && in_scale) ? in_shift[ch < ch_n ? ch : ch_n - 1] : 0.f;
-                    if (vec) {   // W % 4 == 0: an aligned quad is inside or outside the image as a whole
-                        const bool in = base_ok && (unsigned)gx < (unsigned)W;
-                        const float4 f = *reinterpret_cast<const float4*>(row + ((unsigned)gx < (unsigned)W ? gx : 0));
-                        v[b][0] = f.x; v[b][1] = f.y; v[b][2] = f.z; v[b][3] = f.w;
-                        keep[b][0] = keep[b][1] = keep[b][2] = keep[b][3] = in ? 0xffffffffu : 0u;
-                    } else {
+        for (int j = 0; j < NQ; ++j) {
+            const bool is_dy = j < JDY;
+            int i = (int)threadIdx.x + j * NT - (is_dy ? 0 : QDY);
+            const int rows = is_dy ? TY : ROWS, quads = is_dy ? 8 : 12;
+            const bool live = is_dy || i < QX;
+            if (!live) i = QX - 1;
+            const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
+            const int ch = (is_dy ? cog * 16 * COT : cig * 16) + c, ch_n = is_dy ? Cout : Cin;
+            const int gy = (is_dy ? Y0 : Y0 - P) + r, gx = (is_dy ? X0 : X0 - 8) + 4 * q;
+            const bool base_ok = live && ch < ch_n && (unsigned)gy < (unsigned)H;
+            const float* row = (is_dy ? dy_n : x_n) + (size_t)(ch < ch_n ? ch : ch_n - 1) * HW + (size_t)((unsigned)gy < (unsigned)H ? gy : 0) * W;
+            if (vec) {   // W % 4 == 0: an aligned quad is inside or outside the image as a whole
+                pv[j] = *reinterpret_cast<const float4*>(row + ((unsigned)gx < (unsigned)W ? gx : 0));
+                if (base_ok && (unsigned)gx < (unsigned)W) pkeep |= 15ull << (4 * j);
+            } else {
+                float e[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bool in = base_ok && (unsigned)(gx + e) < (unsigned)W;
-                            v[b][e] = row[(unsigned)(gx + e) < (unsigned)W ? gx + e : 0];
-                            keep[b][e] = in ? 0xffffffffu : 0u;
-                        }
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    e[k] = row[(unsigned)(gx + k) < (unsigned)W ? gx + k : 0];
+                    if (base_ok && (unsigned)(gx + k) < (unsigned)W) pkeep |= 1ull << (4 * j + k);
                 }
+                pv[j] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+    auto commit = [&]() {
 #pragma unroll
-                for (int b = 0; b < BATCH; ++b) {
-                    const int i = i0 + b * NT;
-                    if (i >= total) break;
-                    const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
-                    if (affine) {
-                        const int ch = ch0 + c < ch_n ? ch0 + c : ch_n - 1;
-                        if (in_scale) {
+        for (int j = 0; j < NQ; ++j) {
+            const bool is_dy = j < JDY;
+            const int i = (int)threadIdx.x + j * NT - (is_dy ? 0 : QDY);
+            const int rows = is_dy ? TY : ROWS, quads = is_dy ? 8 : 12;
+            if (!is_dy && i >= QX) break;
+            const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
+            float v[4] = {pv[j].x, pv[j].y, pv[j].z, pv[j].w};
+            if (!is_dy) {
+                if (in_scale) {
+                    const float2 a = *reinterpret_cast<const float2*>(s_aff + 2 * c);
+                    // One v_fma_f32 per pixel, spelled out: left to the compiler the four fmas become two v_pk_fma_f32 that broadcast
+                    // scale / shift out of the loaded register PAIR with op_sel (dst overlapping the pair) -- and on gfx950 that form
+                    // returned wrong sums NON-deterministically (the shift term only; 1e-3 relative on dW of the 32 x 16-channel 3x3
+                    // blocks, found by tests/test_hourglass_engine_gpu.py's per-block test; tools/exp/wgrad_dbg.py bisects it:
+                    // plain v_fma_f32, or the same packed fma on registers that are not the loaded pair, are exact).
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[b][e] = __fmaf_rn(v[b][e], asc[b], ash[b]);   // same fma as the BN backward's mask
-                        }
-                        if (in_relu) {
+                    for (int e = 0; e < 4; ++e) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v[e]) : "v"(v[e]), "v"(a.x), "v"(a.y));   // = fmaf: the BN backward's mask sees the same bits
+                }
+                if (in_relu) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[b][e] = __uint_as_float(__float_as_uint(v[b][e]) & keep[b][e]);   // zero padding stays an exact zero
-                    unsigned h0, m0, l0, h1, m1, l1;
-                    ws_split_pair(v[b][0], v[b][1], h0, m0, l0);
-                    ws_split_pair(v[b][2], v[b][3], h1, m1, l1);
-                    unsigned* d = dst + c * plane_words + r * row_words + 2 * q;
-                    *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-                    *reinterpret_cast<u32x2*>(d + split_words) = u32x2{m0, m1};
-                    *reinterpret_cast<u32x2*>(d + 2 * split_words) = u32x2{l0, l1};
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
             }
-        };
-        // dY tile (zero outside the image / beyond Cout), then the activated input tile with halo: rows [Y0 - P, Y0 + TY + P),
-        // pixels [X0 - 8, X0 + 40)
-        stage(dy + ((size_t)n * dy_ctot + dy_coff) * HW, cog * 16 * COT, Cout, 16 * COT, TY, 8, Y0, X0, s_dy, PSD, 16, SPD, false);
-        stage(x + ((size_t)n * x_ctot + x_coff) * HW, cig * 16, Cin, 16, ROWS, 12, Y0 - P, X0 - 8, s_x, PSX, 24, SPX, true);
+            const unsigned kb = (unsigned)(pkeep >> (4 * j));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (0u - ((kb >> e) & 1u)));   // zero padding stays an exact zero
+            unsigned h0, m0, l0, h1, m1, l1;
+            ws_split_pair(v[0], v[1], h0, m0, l0);
+            ws_split_pair(v[2], v[3], h1, m1, l1);
+            unsigned* d = (is_dy ? s_dy + c * PSD + r * 16 : s_x + c * PSX + r * 24) + 2 * q;
+            const int split_words = is_dy ? SPD : SPX;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + split_words) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 2 * split_words) = u32x2{l0, l1};
+        }
+    };
+
+    constexpr bool AHEAD = KS != 11 || CD_WGRAD_AHEAD11;   // (k = 11: 64 accumulator registers + the 23-register windows; see the header)
+    if (AHEAD && !(CD_WS_DBG & 2) && (int)blockIdx.x < items) fetch(blockIdx.x);
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        if (!AHEAD && !(CD_WS_DBG & 2)) fetch(item);   // all loads of the tile in flight at once, landing while the slower waves finish the previous tile
+        __syncthreads();   // the previous tile is consumed (first trip: s_aff is written)
+        if (!(CD_WS_DBG & 2)) commit();
         __syncthreads();
+        if (AHEAD && !(CD_WS_DBG & 2) && item + (int)gridDim.x < items) fetch(item + gridDim.x);   // in flight during the MFMAs below
+        if (CD_WS_DBG & 1) continue;
         if (wid == 0) ws_wave<KS, 0, COT>(s_x, s_dy, acc, lane);
         else if (wid == 1) ws_wave<KS, 1, COT>(s_x, s_dy, acc, lane);
         else if (wid == 2) ws_wave<KS, 2, COT>(s_x, s_dy, acc, lane);

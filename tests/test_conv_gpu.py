@@ -245,3 +245,29 @@ def test_weight_gradient_is_bit_reproducible(ks, Cin, Cout, N, H, W):
     tab.add(ws, lambda: g, Cin, ks, conv.wgrad_plan(Cout, Cin, ks, N, H, W))
     tab.run()
     assert torch.equal(g, a)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [(8, 64, 64, 96, 56, 3), (8, 64, 32, 192, 112, 3), (8, 32, 64, 96, 56, 3), (8, 64, 16, 96, 56, 3),
+                                               (4, 32, 32, 48, 28, 5), (2, 64, 64, 96, 56, 7), (2, 64, 64, 48, 28, 11), (3, 40, 48, 30, 24, 3)])
+@pytest.mark.parametrize("mode", ["scale", "shift", "both"])
+def test_weight_gradient_with_the_producers_affine(N, Cin, Cout, H, W, ks, mode):
+    """dW of relu(x * scale + shift) -- the BatchNorm-apply-on-load form every weight gradient of the hourglass uses -- against fp64,
+    for every block shape of the split-bf16 kernel (16 x 16 channels, the 32 x 16 block of the 3x3 gradient, 8-wave k = 11), scale and
+    shift separately: round 3's first fetch-ahead build was exact without the affine and with a scale, and 1e-3 off -- a different
+    amount on every run -- with a shift on the 32 x 16 block only (a packed-fma form the compiler chose there; wgrad_split.hip).
+    Repeated launches must also agree bit for bit."""
+    import torch
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g)
+    dy = torch.randn(N, Cout, H, W, device="cuda", generator=g)
+    sc = torch.rand(Cin, device="cuda", generator=g) + 0.5 if mode != "shift" else torch.ones(Cin, device="cuda")
+    sh = torch.randn(Cin, device="cuda", generator=g) * 0.3 if mode != "scale" else torch.zeros(Cin, device="cuda")
+    ws = conv.wgrad_workspace(Cout, Cin, ks, "cuda")
+    outs = [conv.conv2d_wgrad(x, dy, Cin, Cout, ks, torch.empty(Cout, Cin, ks, ks, device="cuda"), ws, in_scale=sc, in_shift=sh, in_relu=True).clone()
+            for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    xa = (x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).clamp_min(0)
+    ref = torch.nn.grad.conv2d_weight(xa.cpu(), (Cout, Cin, ks, ks), dy.double().cpu(), padding=ks // 2)
+    err = ((outs[0].double().cpu() - ref).abs().sum() / ref.abs().sum()).item()
+    assert err < 2e-6, err

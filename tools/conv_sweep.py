@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--levels", default="0,1,2,3,4")
     ap.add_argument("--no-pipe-axis", action="store_true", help="only sweep with the pipeline on")
+    ap.add_argument("--heur-only", action="store_true", help="time the dispatcher's own choice only (A/B of two builds: CD_AMD_LIB)")
     args = ap.parse_args()
     from consistent_depth_amd import _native
     from consistent_depth_amd.ops import conv
@@ -93,6 +94,10 @@ def main():
 
         lib.cd_debug_force_conv_tile_rows(0); lib.cd_debug_force_conv_co_tiles(0); lib.cd_debug_set_conv_pipeline(1)
         t_h = timeit()
+        if args.heur_only:
+            tot_h += t_h * cnt
+            print(json.dumps({"shape": [H, W, ks, Cin, Cout, kind], "n": cnt, "heur_us": round(t_h, 1), "TFLOPs": round(flops / t_h / 1e6, 1)}), flush=True)
+            continue
         pack_cot = lib.cd_conv2d_packed_co_tiles(Cout, ks)
         res = {}
         for ty in (4, 8, 16):
@@ -112,7 +117,7 @@ def main():
         tot_b += ok[best] * cnt
         print(json.dumps({"shape": [H, W, ks, Cin, Cout, kind], "n": cnt, "heur_us": round(t_h, 1), "best": best, "best_us": ok[best],
                           "best_TFLOPs": round(flops / ok[best] / 1e6, 1), "all": res}), flush=True)
-    print(json.dumps({"per_step_ms_heuristic": round(tot_h / 1e3, 3), "per_step_ms_best": round(tot_b / 1e3, 3)}))
+    print(json.dumps({"per_step_ms_heuristic": round(tot_h / 1e3, 3), **({} if args.heur_only else {"per_step_ms_best": round(tot_b / 1e3, 3)})}))
 
 
 if __name__ == "__main__":
