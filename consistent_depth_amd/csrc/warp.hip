@@ -58,14 +58,30 @@ __device__ __forceinline__ TapsB taps_border_grid(double idx_x, double idx_y, in
     return t;
 }
 
-__device__ __forceinline__ float tap_sum(const float* __restrict__ src, int W, const TapsB& t) {
+// The four tap offsets of a pixel, shared by every channel sampled at that position.  Taps outside the image are CLAMPED to a
+// valid address (and their product replaced by an exact 0 afterwards): every gather of a pixel is an unconditional load, so the
+// 20 loads (2 flow + 3 colour channels x 4 taps) are all in flight before the first wait.  Round 1's version loaded the optional
+// taps under their conditions -- a load under a divergent branch is followed by s_waitcnt vmcnt(0): twenty serialised round trips
+// per pixel, 8 % of the HBM rate.
+struct TapIdx { int nw, ne, sw, se; };
+__device__ __forceinline__ TapIdx tap_offsets(const TapsB& t, int W) {
+    const int xe = t.in_x1 ? t.x1 : t.x0, ys = t.in_y1 ? t.y1 : t.y0;
+    return TapIdx{t.y0 * W + t.x0, t.y0 * W + xe, ys * W + t.x0, ys * W + xe};
+}
+struct TapVals { float nw, ne, sw, se; };
+__device__ __forceinline__ TapVals tap_load(const float* __restrict__ src, const TapIdx& i) {
+    return TapVals{src[i.nw], src[i.ne], src[i.sw], src[i.se]};
+}
+__device__ __forceinline__ float tap_sum(const TapVals& v, const TapsB& t) {
     // ((nw + ne) + sw) + se, each term rounded, taps outside the image contribute nothing
-    float o = __fmul_rn(src[t.y0 * W + t.x0], t.wnw);
-    o = __fadd_rn(o, t.in_x1 ? __fmul_rn(src[t.y0 * W + t.x1], t.wne) : 0.f);
-    o = __fadd_rn(o, t.in_y1 ? __fmul_rn(src[t.y1 * W + t.x0], t.wsw) : 0.f);
-    o = __fadd_rn(o, (t.in_x1 && t.in_y1) ? __fmul_rn(src[t.y1 * W + t.x1], t.wse) : 0.f);
+    float o = __fmul_rn(v.nw, t.wnw);
+    o = __fadd_rn(o, t.in_x1 ? __fmul_rn(v.ne, t.wne) : 0.f);
+    o = __fadd_rn(o, t.in_y1 ? __fmul_rn(v.sw, t.wsw) : 0.f);
+    o = __fadd_rn(o, (t.in_x1 && t.in_y1) ? __fmul_rn(v.se, t.wse) : 0.f);
     return o;
 }
+
+constexpr int kMaskMaxC = 3;   // colour channels held in registers at once (RGB: one batch)
 
 __global__ __launch_bounds__(kBlock) void flow_consistency_mask_kernel(
     const float* __restrict__ flow_fwd, const float* __restrict__ flow_bwd, const float* __restrict__ color0,
@@ -80,16 +96,31 @@ __global__ __launch_bounds__(kBlock) void flow_consistency_mask_kernel(
     const float* cr = (k == 0 ? color0 : color1) + (size_t)b * C * HW;
     const float* ct = (k == 0 ? color1 : color0) + (size_t)b * C * HW;
     const float u = fl[p], v = fl[HW + p];
+    // the reference pixel's own colours do not depend on the flow: requested before the tap arithmetic (first kMaskMaxC channels)
+    float own[kMaskMaxC];
+#pragma unroll
+    for (int c = 0; c < kMaskMaxC; ++c) own[c] = cr[(size_t)(c < C ? c : C - 1) * HW + p];
     const double idx_x = (double)u + (double)x, idx_y = (double)v + (double)y;
     const bool inside = idx_x >= 0.0 && idx_x <= (double)(W - 1) && idx_y >= 0.0 && idx_y <= (double)(H - 1);
     const TapsB t = taps_border_grid(idx_x, idx_y, W, H);
+    const TapIdx ti = tap_offsets(t, W);
+    const TapVals fu = tap_load(fo, ti), fv = tap_load(fo + HW, ti);
+    TapVals cv[kMaskMaxC];
+#pragma unroll
+    for (int c = 0; c < kMaskMaxC; ++c) cv[c] = tap_load(ct + (size_t)(c < C ? c : C - 1) * HW, ti);
     // flow test: flow_k - (-(flow_{1-k} warped)) = flow_k + warped   (negation commutes exactly with the weighted sum)
-    const float du = __fadd_rn(u, tap_sum(fo, W, t)), dv = __fadd_rn(v, tap_sum(fo + HW, W, t));
+    const float du = __fadd_rn(u, tap_sum(fu, t)), dv = __fadd_rn(v, tap_sum(fv, t));
     const float sse_f = __fadd_rn(__fmul_rn(du, du), __fmul_rn(dv, dv));
     float sse_c = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float d = __fsub_rn(cr[(size_t)c * HW + p], tap_sum(ct + (size_t)c * HW, W, t));
-        sse_c = c == 0 ? __fmul_rn(d, d) : __fadd_rn(sse_c, __fmul_rn(d, d));
+#pragma unroll
+    for (int c = 0; c < kMaskMaxC; ++c)
+        if (c < C) {
+            const float d = __fsub_rn(own[c], tap_sum(cv[c], t));
+            sse_c = c == 0 ? __fmul_rn(d, d) : __fadd_rn(sse_c, __fmul_rn(d, d));
+        }
+    for (int c = kMaskMaxC; c < C; ++c) {   // (more than three colour channels: one at a time, same order of the sum)
+        const float d = __fsub_rn(cr[(size_t)c * HW + p], tap_sum(tap_load(ct + (size_t)c * HW, ti), t));
+        sse_c = __fadd_rn(sse_c, __fmul_rn(d, d));
     }
     const bool m = inside && sse_f < thr_flow && sse_c < thr_color;
     (k == 0 ? mask_fwd : mask_bwd)[(size_t)b * HW + p] = m ? 1.f : 0.f;
