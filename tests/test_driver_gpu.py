@@ -176,3 +176,32 @@ def test_validation_sweep_values_match_cpu_reference(tmp_path):
             ref = 1.0 / ft.model.forward(ft.store.color[fr][None]).float().cpu().numpy().squeeze()
             raw = image_io.load_raw_float32_image(os.path.join(ft.out_dir, "depth", f"frame_{fr:06d}.raw"))
             np.testing.assert_allclose(raw, ref, rtol=1e-5)
+
+
+def test_scene_scale_is_the_reference_scale_calibration():
+    """PairStore.scale_scene_(s) multiplies the camera translations (scale_calibration.py:305-313 divides them by the calibrated
+    scale); flows, masks and intrinsics do not depend on the scene's metric scale.  A size-independent property of the loss pins it:
+    with depth and scene scaled together every reprojected pixel stays where it was -- the reprojection term is unchanged -- and
+    every disparity is divided by s.  Checked at the headline shape on the fused HIP loss."""
+    import torch
+    from consistent_depth_amd.loaders.pair_store import PairStore
+    from consistent_depth_amd.loss.consistency_loss import ConsistencyLoss
+
+    class Opt:
+        lambda_reprojection, lambda_view_baseline = 1.0, 1.0
+    store = PairStore.synthetic(6, 384, 224, seed=5, device="cuda")
+    ids = torch.arange(4, device="cuda")
+    _, meta = store.batch(ids)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    depth = torch.as_tensor(store.gt_depth, dtype=torch.float32, device="cuda")[store.pair_frames[ids]] * \
+        (1.0 + 0.05 * torch.randn(4, 2, 384, 224, device="cuda", generator=g))
+    crit = ConsistencyLoss(Opt())
+    _, p0 = crit(depth, meta)
+    s = 0.0123
+    ext0 = store.extrinsics.clone()
+    store.scale_scene_(s)
+    assert torch.equal(store.extrinsics[..., :3], ext0[..., :3]) and torch.allclose(store.extrinsics[..., 3], ext0[..., 3] * s, rtol=1e-7, atol=0)
+    _, meta_s = store.batch(ids)
+    _, p1 = crit(depth * s, meta_s)
+    np.testing.assert_allclose(p1["reprojection"].cpu().numpy(), p0["reprojection"].cpu().numpy(), rtol=2e-4)
+    np.testing.assert_allclose(p1["disparity"].cpu().numpy() * s, p0["disparity"].cpu().numpy(), rtol=2e-4)
