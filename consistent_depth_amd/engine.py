@@ -137,7 +137,13 @@ class GraphedFineTuneStep:
     forward, fused loss, CNN backward and (single GPU) the guarded Adam update, including the engine's side streams
     -- into one graph with static input buffers, and every later call copies its batch into those buffers and
     replays.  The training trajectory is that of the eager step (capturing executes nothing).  With world > 1 the
-    graph ends before the gradient all-reduce; the collective and the one Adam launch stay eager.
+    graph ends before the gradient all-reduce by default: the collective and the one Adam launch stay eager.
+    CD_AMD_DP_GRAPH_COLLECTIVE=1 captures them too -- RCCL's all-reduce is an ordinary kernel launch on the capturing
+    stream (torch's ProcessGroupNCCL supports capture), the step is then ONE replay per rank.  Exercised with a one-rank
+    RCCL group on one GPU (tests/test_dp_gpu.py::test_rccl_collective_inside_the_step_graph); opt-in until it has run on
+    a multi-GPU node: a collective inside a graph cannot time out rank by rank, so a rank that falls back to eager steps
+    (capture failure) while the others replay would desynchronise the call sequence -- the opt-in therefore makes a
+    capture failure fatal instead of falling back.
 
     If capture fails (a torch / HIP runtime without stream capture) the step stays eager and `self.graphed` is False.
     """
@@ -147,6 +153,7 @@ class GraphedFineTuneStep:
         self._seen, self._graphs, self._store_sig = {}, {}, {}
         self.graphed = None      # None: nothing captured yet; True / False after the first attempt
         self.capture_error = None
+        self.graph_collective = step.world > 1 and os.environ.get("CD_AMD_DP_GRAPH_COLLECTIVE", "0") == "1"
 
     @staticmethod
     def _signature(images, metadata):
@@ -162,7 +169,7 @@ class GraphedFineTuneStep:
             # thread_local: other threads (RCCL's watchdog) may touch the runtime while this thread captures
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 guard, parts = self.step._grads(st_images, st_meta)
-                if self.step.world == 1:
+                if self.step.world == 1 or self.graph_collective:
                     self.step._update(guard)
         torch.cuda.current_stream(dev).wait_stream(side)
         return {"graph": graph, "images": st_images, "meta": st_meta, "flat": [t for _, t in _flatten(st_meta)],
@@ -179,6 +186,9 @@ class GraphedFineTuneStep:
             try:
                 g = self._capture(images, metadata)
             except Exception as e:   # noqa: BLE001 -- stay on the (equally native) eager path
+                if self.graph_collective:
+                    raise RuntimeError("CD_AMD_DP_GRAPH_COLLECTIVE=1: capturing the step with its all-reduce failed; not falling back "
+                                       "(the other ranks would replay a graph with the collective inside)") from e
                 self.graphed, self.capture_error = False, f"{type(e).__name__}: {e}"
                 torch.cuda.synchronize()
                 return self.step(images, metadata)
@@ -187,7 +197,7 @@ class GraphedFineTuneStep:
         for dst, (_, src) in zip(g["flat"], _flatten(metadata)):
             dst.copy_(src)
         g["graph"].replay()
-        if self.step.world > 1:
+        if self.step.world > 1 and not self.graph_collective:
             self.step._update(g["guard"])
         return g["guard"].clone(), {k: v.clone() for k, v in g["parts"].items()}
 
@@ -206,7 +216,7 @@ class GraphedFineTuneStep:
         self._seen[key] = self._seen.get(key, 0) + 1
         store.gather_into(pair_ids, g["images"], g["meta"])
         g["graph"].replay()
-        if self.step.world > 1:
+        if self.step.world > 1 and not self.graph_collective:
             self.step._update(g["guard"])
         return g["guard"].clone(), {k: v.clone() for k, v in g["parts"].items()}, g["meta"]
 

@@ -55,8 +55,10 @@ def world_size() -> int:
 
 
 def allreduce_sum_(buf: torch.Tensor):
-    """In-place sum over ranks of one flat fp32 buffer (no-op for a single process)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    """In-place sum over ranks of one flat fp32 buffer (no-op without a process group).  With a one-rank group the collective
+    still runs (the callers decide with their own `world`): that is how the RCCL launch inside a captured step is exercised on a
+    one-GPU box (tests/test_dp_gpu.py)."""
+    if dist.is_initialized():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 

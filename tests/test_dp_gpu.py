@@ -175,3 +175,55 @@ def test_c_abi_allreduce_on_a_raw_rccl_communicator():
     assert lib.cd_allreduce_mean_f32(buf.data_ptr(), buf.numel(), None, 1, _native.stream_ptr()) == 0
     rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+COLLECTIVE_GRAPH_WORKER = r"""
+import argparse, json, os, sys
+import torch
+sys.path.insert(0, %(repo)r)
+import torch.distributed as dist
+from consistent_depth_amd import synthetic
+from consistent_depth_amd.engine import FineTuneStep, GraphedFineTuneStep
+from consistent_depth_amd.monodepth.depth_model_registry import get_depth_model
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=0.1, lambda_parameter=0, learning_rate=4e-4, optimizer="Adam")
+t = lambda a: torch.tensor(a, device=dev)
+b = synthetic.make_scene_batch(2, 64, 48, seed=1)
+imgs = torch.rand(2, 2, 3, 64, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+meta = {"intrinsics": t(b["intrinsics"]), "extrinsics": t(b["extrinsics"]),
+        "geometry_consistency": {"flows": [t(f) for f in b["flows"]], "masks": [t(m) for m in b["masks"]]}}
+
+def run(graph_collective):
+    os.environ["CD_AMD_DP_GRAPH_COLLECTIVE"] = "1" if graph_collective else "0"
+    model = get_depth_model("mc")(seed=0); model.train()
+    # world = 2 on a ONE-rank communicator: the step takes its multi-rank branch (loss slot, RCCL all-reduce of [grads | loss],
+    # 1/world in Adam); the sum over the one rank is the buffer itself
+    step = GraphedFineTuneStep(FineTuneStep(model, params, world=2), eager_steps=1)
+    losses = [step(imgs, meta)[0].item() for _ in range(5)]
+    torch.cuda.synchronize()
+    return losses, step.graphed, step.graph_collective, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+
+l0, g0, c0, p0 = run(False)
+l1, g1, c1, p1 = run(True)
+print("RESULT " + json.dumps({"losses_eager_collective": l0, "losses_graphed_collective": l1, "graphed": [g0, g1], "collective_in_graph": [c0, c1],
+                              "params_equal": bool(torch.equal(p0, p1))}))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_rccl_collective_inside_the_step_graph(tmp_path):
+    """CD_AMD_DP_GRAPH_COLLECTIVE=1: the gradient all-reduce (RCCL, backend "nccl") and the Adam launch are captured INTO the step's HIP
+    graph, so a data-parallel step is one replay per rank.  On this one-GPU box the communicator has one rank while the step runs
+    its multi-rank branch (world = 2 in FineTuneStep): the trajectory must equal, bit for bit, the default (collective + Adam launched
+    eagerly after the replay)."""
+    script = tmp_path / "collective_graph_worker.py"
+    script.write_text(COLLECTIVE_GRAPH_WORKER % {"repo": REPO})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert lines, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads(lines[-1][len("RESULT "):])
+    assert res["graphed"] == [True, True] and res["collective_in_graph"] == [False, True], res
+    assert res["losses_eager_collective"] == res["losses_graphed_collective"] and res["params_equal"], res
