@@ -19,10 +19,10 @@
 #include "cd_common.h"
 #include "wgrad_split.h"
 
-#ifndef CD_WGRAD_AHEAD11
+#ifndef CD_WGRAD_AHEAD11   // 1: fetch the next tile ahead at k = 11 too (27 spilled registers: measured slower than all-loads-at-once)
 #define CD_WGRAD_AHEAD11 0
 #endif
-#ifndef CD_WS_DBG        // measurement builds (tools/exp/build_variants.sh): 1 = no MFMA phase, 2 = no staging (fetch / commit)
+#ifndef CD_WS_DBG        // measurement builds (tools/exp/build_variants.sh), bits: 1 = no MFMA phase, 2 = no staging (fetch / commit), 4 = no operand alignment work (wrong results)
 #define CD_WS_DBG 0
 #endif
 
