@@ -383,7 +383,7 @@ def main():
                            "the k >= 3 convolutions on the split-operand kernels (roof 416.7) -- priced against the lower peak"
                            if args.model == "midas2" and args.backend == "hip" else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)")),
             "frac_of_fp32_mfma_peak": round(ach_tf / MFMA_FP32_PEAK_TFLOPS, 4),
-            "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r03.txt (SQ_INSTS_VALU_MFMA_MOPS / SQ_BUSY_CU_CYCLES per kernel family), "
+            "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r03.txt (SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES per kernel family), "
                                 "profiles/conv_roofline_r03.txt (per launch)"}
         in_step_ms = float(np.mean(ms_step)) if len(ms_step) else None
         if in_step_ms:
