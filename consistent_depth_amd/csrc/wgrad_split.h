@@ -1,11 +1,10 @@
 // Interface between conv_wgrad.hip (layout, dispatch, unpack) and wgrad_split.hip (the split-bf16 weight gradient).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wgrad_stage_map.h"   // wgrad_split_tile_rows, WsCfg, the staging map (host-testable)
 
 namespace cd {
 
-// image-tile rows per work item of the split-bf16 weight-gradient kernel (16 x 16 channels per block, 32-pixel rows)
-__host__ __device__ constexpr int wgrad_split_tile_rows(int ks) { return ks == 11 ? 8 : 6; }
 // resident blocks per CU (k = 11: one 8-wave block with a 109 KB tile; else two 4-wave blocks)
 __host__ __device__ constexpr int wgrad_split_blocks_per_cu(int ks) { return ks == 11 ? 1 : 2; }
 

@@ -46,21 +46,6 @@ __device__ __forceinline__ void ws_split_pair(float a, float b, unsigned& h, uns
     l = ws_cvt_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
 }
 
-constexpr int ws_pad(int words) { return words + ((4 - words % 8) + 8) % 8; }   // == 4 (mod 8): 16 channel planes tile the 64 banks
-
-template <int KS, int COT = 1> struct WsCfg {
-    static constexpr int TY = wgrad_split_tile_rows(KS);
-    static constexpr int NW = KS == 11 ? 8 : 4;               // waves per block (k = 11: 8 x 16 taps = 64 accumulator registers each)
-    static constexpr int WPS = NW / COT;                      // waves per 16 x 16 sub-tile (COT output-channel groups per block)
-    static constexpr int P = (KS - 1) / 2, TAPS = KS * KS, TPW = (TAPS + WPS - 1) / WPS;
-    static constexpr int ROWS = TY + KS - 1;
-    static constexpr int XW = 48;                              // pixels per LDS row of X: [X0 - 8, X0 + 40)
-    static constexpr int PSX = ws_pad(ROWS * XW / 2);          // 32-bit words per channel plane
-    static constexpr int PSD = ws_pad(TY * 32 / 2);
-    static constexpr int SPX = 16 * PSX, SPD = 16 * COT * PSD;   // words per split plane set
-    static constexpr size_t LDS = (size_t)3 * (SPX + SPD) * 4 + 128;   // + scale / shift of the block's 16 input channels
-};
-
 // One wave's share of a staged tile: output-channel sub-tile WV / WPS, taps [(WV % WPS) * TPW, + TPW) of the flattened index
 // (13 at k = 7, 16 at k = 11: they span two or three filter rows).  Per output row y and B split the windows of ALL the wave's filter
 // rows are loaded (three ds_read_b128 = 12 registers each) and the MFMAs walk over all the wave's taps before the next dY split
@@ -153,9 +138,8 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
     // The fetch of tile i + 1 is issued BEFORE the MFMAs of tile i and committed after them: the memory latency of a tile (three
     // serialised batches of loads in round 2/3's kernel, as long as its MFMA phase at k <= 7) is hidden behind the matrix cores;
     // between two MFMA phases a block only pays the commit's vector ALU work.
-    constexpr int QDY = 16 * COT * TY * 8, QX = 16 * ROWS * 12, QT = QDY + QX, NQ = (QT + NT - 1) / NT, JDY = QDY / NT;
-    static_assert(QDY % NT == 0, "dY quads fill whole rounds of the block");
-    static_assert(NQ * 4 <= 64, "one keep bit per fetched pixel");
+    // (the map thread / slot -> tile element -> LDS word is ws_stage_quad of wgrad_stage_map.h: tests/test_wgrad_map_cpu.py runs it on the host)
+    constexpr int NQ = Cfg::NQ;
     float* s_aff = reinterpret_cast<float*>(ws_smem + 3 * (SPX + SPD));   // [16][2]: scale, shift of this block's input channels
     if (threadIdx.x < 16) {
         const int ch = cig * 16 + (int)threadIdx.x < Cin ? cig * 16 + (int)threadIdx.x : Cin - 1;
@@ -173,12 +157,9 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
         pkeep = 0;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const bool is_dy = j < JDY;
-            int i = (int)threadIdx.x + j * NT - (is_dy ? 0 : QDY);
-            const int rows = is_dy ? TY : ROWS, quads = is_dy ? 8 : 12;
-            const bool live = is_dy || i < QX;
-            if (!live) i = QX - 1;
-            const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
+            const WsQuad sq = ws_stage_quad<KS, COT>((int)threadIdx.x, j);
+            const bool is_dy = sq.is_dy, live = sq.live;
+            const int c = sq.c, r = sq.r, q = sq.q;
             const int ch = (is_dy ? cog * 16 * COT : cig * 16) + c, ch_n = is_dy ? Cout : Cin;
             const int gy = (is_dy ? Y0 : Y0 - P) + r, gx = (is_dy ? X0 : X0 - 8) + 4 * q;
             const bool base_ok = live && ch < ch_n && (unsigned)gy < (unsigned)H;
@@ -200,11 +181,10 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const bool is_dy = j < JDY;
-            const int i = (int)threadIdx.x + j * NT - (is_dy ? 0 : QDY);
-            const int rows = is_dy ? TY : ROWS, quads = is_dy ? 8 : 12;
-            if (!is_dy && i >= QX) break;
-            const int c = i / (rows * quads), rem = i - c * (rows * quads), r = rem / quads, q = rem - r * quads;
+            const WsQuad sq = ws_stage_quad<KS, COT>((int)threadIdx.x, j);
+            if (!sq.live) break;
+            const bool is_dy = sq.is_dy;
+            const int c = sq.c;
             float v[4] = {pv[j].x, pv[j].y, pv[j].z, pv[j].w};
             if (!is_dy) {
                 if (in_scale) {
@@ -228,8 +208,8 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
             unsigned h0, m0, l0, h1, m1, l1;
             ws_split_pair(v[0], v[1], h0, m0, l0);
             ws_split_pair(v[2], v[3], h1, m1, l1);
-            unsigned* d = (is_dy ? s_dy + c * PSD + r * 16 : s_x + c * PSX + r * 24) + 2 * q;
-            const int split_words = is_dy ? SPD : SPX;
+            unsigned* d = ws_smem + sq.lds_word;
+            const int split_words = sq.split_words;
             *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(d + split_words) = u32x2{m0, m1};
             *reinterpret_cast<u32x2*>(d + 2 * split_words) = u32x2{l0, l1};
