@@ -452,8 +452,10 @@ def main():
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--model", "midas2", "--height", "384", "--width", "384", "--batch-size", "8",
                    "--steps", "5", "--warmup", "2", "--frames", "20", "--no-loss-microbench", "--no-cpu-baseline", "--backend", args.backend]
+            stderr_tail = ""
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.config5_timeout)
+                stderr_tail = (r.stderr or "")[-300:]      # (a run that refuses its own timed region -- non-finite losses -- says so here)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
                 c5 = json.loads(line)
                 out["config5"] = {"value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"], "steps": c5["steps"],
@@ -461,8 +463,7 @@ def main():
                                   "last_loss": c5["config"].get("last_loss"), "hip_graph": c5["config"].get("hip_graph"),
                                   "workload": c5["config"]["workload"], "roofline_conv": c5.get("roofline_conv")}
             except (subprocess.TimeoutExpired, IndexError, ValueError, KeyError) as e:
-                out["config5"] = {"value": None, "note": f"no line within {args.config5_timeout}s ({type(e).__name__}): "
-                                                         + (getattr(e, "stderr", None) or getattr(locals().get("r"), "stderr", "") or "")[-300:]}
+                out["config5"] = {"value": None, "note": f"no line within {args.config5_timeout}s ({type(e).__name__}): {stderr_tail}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
