@@ -125,3 +125,35 @@ def test_bench_cli_contract():
         assert f'"{flag}"' in src
     assert spec is not None and '"cpu_baseline"' in src and '"roofline"' in src and "higher_is_better" in src
     del sys
+
+
+def test_bench_flop_count_matches_the_convolutions_a_forward_pass_executes(monkeypatch):
+    """`roofline_conv` in the bench line prices bench.mc_conv_macs(H, W) multiply-adds per image.  Counted here from the
+    convolutions an actual forward pass of the restated hourglass executes (every F.conv2d call of oracle/hourglass_ref.forward,
+    at a small size; the count is proportional to H W): the table walk must give the same number, minus the confidence head the
+    fine-tuning path never runs, and 52.78 GMAC at the headline 384 x 224."""
+    import importlib.util
+    import os
+    import torch.nn.functional as F
+    from consistent_depth_amd.monodepth.hourglass import HourglassModel
+    from oracle import hourglass_ref as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    H, W = 64, 32
+    macs = [0]
+    real = F.conv2d
+
+    def counting(x, w, *a, **k):
+        y = real(x, w, *a, **k)
+        macs[0] += y.shape[0] * y.shape[2] * y.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+        return y
+    monkeypatch.setattr(R.F, "conv2d", counting)
+    torch.manual_seed(0)
+    state = {k: v.double() for k, v in HourglassModel().state_dict().items()}
+    R.forward(state, torch.rand(1, 3, H, W, dtype=torch.float64), training=True)
+    head = H * W * 64 * 9            # the confidence head: run by the oracle's forward, not by the fine-tuning path
+    assert macs[0] == R.conv_macs(H, W)
+    assert bench.mc_conv_macs(H, W) == macs[0] - head
+    assert abs(bench.mc_conv_macs(384, 224) / 1e9 - 52.783) < 1e-3
