@@ -157,3 +157,44 @@ def test_bench_flop_count_matches_the_convolutions_a_forward_pass_executes(monke
     assert macs[0] == R.conv_macs(H, W)
     assert bench.mc_conv_macs(H, W) == macs[0] - head
     assert abs(bench.mc_conv_macs(384, 224) / 1e9 - 52.783) < 1e-3
+
+
+def test_a_captured_collective_does_not_fall_back(monkeypatch):
+    """CD_AMD_DP_GRAPH_COLLECTIVE=1 puts the gradient all-reduce inside the step graph.  A rank whose capture fails must not
+    quietly run eager steps while the others replay a graph with the collective inside (their call sequences would diverge): the
+    wrapper raises.  Without the opt-in (or with one rank) the eager fallback stays."""
+    from consistent_depth_amd import engine
+
+    class _Step:
+        def __init__(self, world):
+            self.world, self.calls, self.updates = world, 0, 0
+
+        def __call__(self, images, metadata):
+            self.calls += 1
+            return torch.tensor(float(self.calls)), {}
+
+        def _update(self, guard):
+            self.updates += 1
+
+    def broken_capture(images, metadata):
+        raise RuntimeError("stream capture unsupported")
+
+    img, m = torch.zeros(1, 2, 3, 8, 12), _meta(B=1)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setenv("CD_AMD_DP_GRAPH_COLLECTIVE", "1")
+    g = engine.GraphedFineTuneStep(_Step(world=2), eager_steps=1)
+    assert g.graph_collective is True
+    g._capture = broken_capture
+    g(img, m)                                  # the eager step
+    with pytest.raises(RuntimeError, match="not falling back"):
+        g(img, m)
+    one = engine.GraphedFineTuneStep(_Step(world=1), eager_steps=1)
+    assert one.graph_collective is False       # nothing to put inside with one rank
+    monkeypatch.setenv("CD_AMD_DP_GRAPH_COLLECTIVE", "0")
+    st = _Step(world=2)
+    g = engine.GraphedFineTuneStep(st, eager_steps=1)
+    assert g.graph_collective is False
+    g._capture = broken_capture
+    for expected in (1.0, 2.0, 3.0):
+        assert g(img, m)[0].item() == expected
+    assert g.graphed is False and st.calls == 3
