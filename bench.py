@@ -311,7 +311,10 @@ def main():
     # A non-finite loss makes the device-side guard skip the Adam update of that step (the reference skips NaN steps too,
     # depth_fine_tuning.py:372-376): such a step is not a full step, and a timed region containing one is not a measurement.
     # (graph replays return a clone of the static loss buffer: one tensor per step here too)
-    finite_steps = int(torch.isfinite(torch.stack([l.reshape(()) for l in step_losses])).sum().item())
+    finite = torch.isfinite(torch.stack([l.reshape(()) for l in step_losses])).sum().float().reshape(1)
+    if world > 1:     # every rank takes the same decision (a rank leaving alone would hang the others in the next collective)
+        dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+    finite_steps = int(finite.item())
     if finite_steps != args.steps:
         sys.exit(f"bench.py: {args.steps - finite_steps} of {args.steps} timed steps had a non-finite loss (Adam update skipped): "
                  f"not a valid measurement")
