@@ -198,3 +198,28 @@ def test_bucketed_allreduce_overlaps_backward_and_matches_the_global_batch():
     out = mgr.dict()
     mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_bench_epoch_plans_deal_disjoint_full_batches_to_the_ranks():
+    """bench.py's schedule (EpochPlans over parallel.shard_indices): at every step the ranks hold disjoint pairs of ONE shared
+    permutation, all batches are full (one graph signature), and every rank sees the same number of steps per epoch -- so the ranks
+    issue the same sequence of collectives."""
+    import importlib.util
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_plans", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n_pairs, world, bs = 715, 4, 4
+    plans = [bench.EpochPlans(n_pairs, r, world, bs, torch.device("cpu"), seed=0) for r in range(world)]
+    seen_epoch0 = []
+    for step in range(2 * (n_pairs // (world * bs)) + 3):          # runs into the third epoch
+        batches = [p.next() for p in plans]
+        assert all(len(b) == bs for b in batches)
+        assert len({p.epoch for p in plans}) == 1 and len({p.pos for p in plans}) == 1       # same epoch, same step on every rank
+        flat = torch.cat([torch.as_tensor(b).reshape(-1) for b in batches]).tolist()
+        assert len(set(flat)) == world * bs and all(0 <= i < n_pairs for i in flat)
+        if plans[0].epoch == 0:
+            seen_epoch0 += flat
+    assert len(set(seen_epoch0)) == len(seen_epoch0) == (n_pairs // (world * bs)) * world * bs    # no pair twice within an epoch
