@@ -38,11 +38,11 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 LOSS_BYTES_PER_PAIR_PX = 10 * 4  # read depth x2, flow x4, mask x2, write grad x2 (fp32), SURVEY.md 8d
-# HBM traffic of the row-sweep gradient kernel per pair at 384x224 from rocprofv3 PMC (profiles/rocprofv3_loss_sweep_b256_r03.txt,
-# separate passes): FETCH_SIZE 346.63 MB x 2 (the guide's gfx950 correction) + WRITE_SIZE 172.04 MB per 256-pair launch
-# = 3.380 MB per pair = 0.98x the algorithmic 3.441 MB (every input read once, every gradient byte written once).  Only
-# valid for the size and the kernel it was measured on; null otherwise.
-LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 = (2 * 346.6259e6 + 172.040e6) / 256
+# `roofline.traffic` is MEASURED IN THIS RUN (rank 0, N = 1): two bounded `rocprofv3 --pmc` subprocess passes (FETCH_SIZE, then
+# WRITE_SIZE -- they do not fit one pass; no trace option next to them) over tools/loss_bench.py at the same launch size, read back
+# from the rocpd database, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: the counters are in KiB and,
+# on gfx950, FETCH_SIZE reports half the bytes of a wide coalesced streaming read (x 2).  null when rocprofv3 is unavailable or a
+# pass fails -- never a number copied from an older build (round 3 printed a constant from profiles/).
 # Matrix-core roofs (TFLOP/s, dense; /opt/skills/guides/MI355X_MICROARCH.md).  The split-operand convolutions compute one fp32
 # result from SIX bf16 products, so the roof they run against, in fp32-equivalent flops, is the dense BF16 peak / 6.
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -129,7 +129,9 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("CD_AMD_MC_BACKEND", "hip"), choices=["torch", "hip"],
                     help="convolutions: hip = hand-written gfx950 engine (BASELINE configs[2]); "
                          "torch = PyTorch-ROCm/MIOpen (configs[1], ~2 min of MIOpen start-up)")
-    ap.add_argument("--frames", type=int, default=244, help="frames of the synthetic clip (BASELINE configs[2]: 244 -> 715 pairs; configs[3]: 1000 -> 2979)")
+    ap.add_argument("--frames", type=int, default=244,
+                    help="frames of the synthetic clip, resident on every GPU (BASELINE configs[2]: 244 -> 715 pairs, the default at every "
+                         "--gpus; configs[3] is --frames 1000 -> 2979 pairs, 7.2 GB per GPU and ~2 min of synthetic-data generation per rank)")
     ap.add_argument("--max-pairs", type=int, default=0, help="keep only the first N pairs of the clip (quick runs)")
     ap.add_argument("--loss-batch", type=int, default=256, help="pairs per launch of the roofline micro-benchmark")
     ap.add_argument("--loss-iters", type=int, default=20)
@@ -140,6 +142,8 @@ def parse():
                     help="skip the short BASELINE configs[4] side measurement (midas2 backbone, 384x384, BS8) that the default N=1 run appends")
     ap.add_argument("--config5-timeout", type=int, default=150)
     ap.add_argument("--no-loss-microbench", action="store_true")
+    ap.add_argument("--no-loss-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--traffic-timeout", type=int, default=90, help="seconds each PMC pass may take")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-timeout", type=int, default=150, help="seconds the CPU-baseline subprocess may take")
     ap.add_argument("--miopen-find", action="store_true",
@@ -214,6 +218,42 @@ def loss_microbench(lib, B, H, W, iters, device):
     torch.cuda.synchronize()
     ms, _ = profile_collect(lib, iters)
     return ms
+
+
+def loss_traffic_pmc(B, H, W, timeout, kernel_substr="loss_sweep_kernel"):
+    """HBM bytes per launch of the loss gradient kernel from rocprofv3 PMC counters, measured now on this GPU: one subprocess pass
+    per counter (`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, nothing else on the command line) around tools/loss_bench.py at
+    B pairs.  Returns (bytes or None, note)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [rp, "--pmc", counter, "-d", td, "-o", "pmc", "--", sys.executable, os.path.join(REPO, "tools", "loss_bench.py"),
+                   "--batches", str(B), "--iters", "3", "--height", str(H), "--width", str(W)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return None, f"{counter} pass exceeded {timeout}s"
+            per_dispatch = {}
+            for db in glob.glob(os.path.join(td, "**", "*.db"), recursive=True):
+                try:
+                    rows = sqlite3.connect(db).execute("select name, counter_name, counter_value, dispatch_id from pmc_events").fetchall()
+                except sqlite3.Error:
+                    continue
+                for name, cn, cv, did in rows:       # counters come per instance (XCD): sum per dispatch
+                    if cn == counter and kernel_substr in name:
+                        per_dispatch[did] = per_dispatch.get(did, 0.0) + cv
+            if not per_dispatch:
+                return None, f"no {kernel_substr} dispatch in the {counter} pass"
+            got[counter] = 1024.0 * sum(per_dispatch.values()) / len(per_dispatch)
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], "rocprofv3 --pmc, separate passes, this run: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB -> bytes"
 
 
 def main():
@@ -352,7 +392,12 @@ def main():
         "config": {"workload": (f"mc hourglass (random init, seed 0) test-time fine-tuning steps over a synthetic {args.frames}-frame "
                                 f"{H}x{W} clip ({len(store)} pairs, hierarchical sampling, HBM-resident pair store, shared-seed shards; full "
                                 f"batches only -- the epoch's short last batch is left out so that ONE graph signature is timed), "
-                                f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 (BASELINE configs[{(3 if world > 1 else 2) if args.backend == 'hip' else 1}]: "
+                                f"BS{B} pairs/GPU, lambda_r 1.0 lambda_b 0.1, Adam lr 4e-4 ("
+                                + (("BASELINE configs[3]: " if args.frames == 1000 else "BASELINE configs[2]'s clip resident on every GPU, "
+                                    "configs[3]'s data parallelism -- the literal configs[3] clip is --frames 1000: ")
+                                   + f"DP over {world} GPUs, one flat RCCL all-reduce of the gradients per step, " if world > 1 else
+                                   ("BASELINE configs[2]: " if args.frames == 244 and not args.max_pairs else "")
+                                   if args.backend == "hip" else "BASELINE configs[1]: ")
                                 + ("full HIP conv+loss path)" if args.backend == "hip" else "HIP loss+Adam, convs on PyTorch-ROCm/MIOpen)"))
                                if args.model == "mc" else
                                (f"midas2 plugin: MiDaS-v2-shaped backbone (ResNeXt-101 32x8d + feature-fusion decoder restated, random init, "
@@ -366,7 +411,11 @@ def main():
                                   "tests/test_conv_gpu.py); RGB stem and small-image 1x1 on the fp32 MFMA" if lib.cd_get_conv_arith() >= 1 else "fp32 MFMA (CD_AMD_CONV_ARITH=fp32)")
                    if args.backend == "hip" else "MIOpen fp32",
                    "global_batch": B * world, "parallelism": f"dp{world}",
-                   "hip_graph": graphed, "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),
+                   "hip_graph": graphed,
+                   **({"dp_exchange": ("all-reduce + Adam inside the step graph (CD_AMD_DP_GRAPH_COLLECTIVE=1)" if getattr(step, "graph_collective", False)
+                                       else "one flat all-reduce of [gradients | loss] + one Adam launch per step, eager, after the graph replay")}
+                      if world > 1 else {}),
+                   "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),
                    "last_loss": float(last_loss.item()), "finite_loss_steps": finite_steps,
                    **({"scene_scale": round(scene_scale, 6)} if scene_scale != 1.0 else {})},
     }
@@ -405,15 +454,20 @@ def main():
         if not args.no_loss_microbench and len(ms):
             avg = float(np.mean(ms))
             ach = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch / (avg * 1e-3) / 1e9
-            sweep = (H, W) == (384, 224) and args.loss_batch >= 96     # the default dispatch of cd_consistency_loss_fwd_bwd
+            sweep = (H, W) == (384, 224) and args.loss_batch >= 96     # the default dispatch of cd_consistency_loss_fwd_bwd (loss_sweep.hip::sweep_preferred)
+            traffic, traffic_note = (None, "not measured (--no-loss-traffic)")
+            if sweep and world == 1 and not args.no_loss_traffic:
+                log("loss kernel HBM traffic (2 rocprofv3 --pmc passes)")
+                traffic, traffic_note = loss_traffic_pmc(args.loss_batch, H, W, args.traffic_timeout)
+            alg = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch
             out["roofline"] = {"kernel": "loss_sweep_kernel (row sweep: one workgroup per pair, one gradient launch)" if sweep else
                                          "loss_source_kernel + loss_gather4_kernel (one gradient launch)",
                                "bound": "hbm", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": (LOSS_TRAFFIC_BYTES_PER_PAIR_384x224 * args.loss_batch if sweep else None),
-                               "traffic_source": "profiles/rocprofv3_loss_sweep_b256_r03.txt (PMC, separate passes; FETCH_SIZE x2 + WRITE_SIZE)",
-                               "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5),
-                               "algorithmic_bytes_per_launch": LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch}
+                               "traffic": traffic, "traffic_source": traffic_note,
+                               "traffic_over_algorithmic": round(traffic / alg, 4) if traffic else None,
+                               "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5), "algorithmic_bytes_per_launch": alg,
+                               "lib": lib.cd_build_info().decode()}
         if world == 1 and not args.no_cpu_baseline and args.model == "mc":
             # the reference step restated on the host (oracle/cpu_step.py), in a bounded subprocess so a slow
             # host can never stall the benchmark: 1 warm-up + --cpu-steps timed steps of the same BS4 workload

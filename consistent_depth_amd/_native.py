@@ -13,7 +13,7 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # CD_AMD_LIB: load another build of the SAME library (A/B measurements of kernel variants, tools/exp/build_variants.sh); not a fallback
 SO_PATH = os.environ.get("CD_AMD_LIB") or os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 
 _lib = None

@@ -128,6 +128,8 @@ class DepthFineTuner:
         store = self.store
         if self.world > 1:   # identical replicas by construction, not by seed: rank 0's parameters and buffers everywhere
             parallel.broadcast_([q.data for q in self.model.parameters()] + [b for b in self.model.buffers() if b.is_floating_point()])
+        if getattr(self, "_step", None) is not None:
+            self._step.close()               # a second fine_tune() on this object: drop the first step's parameter hooks
         step = FineTuneStep(self.model, p, world=self.world)
         if os.environ.get("CD_AMD_STEP_GRAPH", "1") != "0":   # replay the step from a HIP graph after 2 eager steps
             step = GraphedFineTuneStep(step)
@@ -152,18 +154,25 @@ class DepthFineTuner:
             # per-step losses of the epoch stay on the device (one 4-byte copy per step, no sync): read ONCE at the end of
             # the epoch to learn which steps the device-side NaN guard skipped
             epoch_losses = torch.zeros(max(1, len(plan)), dtype=torch.float32, device=store.device)
+            sizes = self._global_step_sizes(epoch, len(plan))
+            # The reference advances total_iters BEFORE it logs a step (:285-288), so every training point has its own global
+            # step.  The authoritative counter is corrected for NaN steps once per epoch (below, no per-step sync); the logging
+            # position runs along on the host and leaves out the NaN steps it gets to see (the print steps, whose loss is read).
+            log_iters = total_iters
             for it, ids in enumerate(plan):
                 loss, loss_meta, metadata = step.step_from_store(store, plan_dev[it])
                 epoch_losses[it:it + 1].copy_(loss.reshape(1))
+                log_iters += sizes[it]
                 if p.print_freq > 0 and (it % max(1, p.print_freq) == 0) and self.rank == 0:
                     pairs = metadata["geometry_consistency"]["indices"].tolist()
                     lv = loss.item()  # the only host sync, every print_freq steps
                     print(f"Epoch = {epoch}, pairs = {pairs}, loss = {lv}")
                     if lv != lv:
                         print("Loss is NaN. Skipping.")  # already skipped on the device
-                    if writer is not None:
-                        writer.add_scalar("Train/loss", lv, total_iters)
-                        log_loss_stats(writer, "Train/loss", loss_meta, total_iters)
+                        log_iters -= sizes[it]           # the reference's `continue` comes before its `total_iters +=`
+                    elif writer is not None:
+                        writer.add_scalar("Train/loss", lv, log_iters)
+                        log_loss_stats(writer, "Train/loss", loss_meta, log_iters)
             torch.cuda.synchronize()
             # the reference's `continue` on a NaN loss also skips `total_iters += batch` (:278-285); total_iters counts pairs
             # over all ranks and names the validation files.  (With world > 1 the guard acts on the all-reduced loss: a NaN on
@@ -172,7 +181,6 @@ class DepthFineTuner:
             if self.world > 1 and len(plan):
                 parallel.allreduce_sum_(bad)
             bad = bad.cpu().numpy() > 0
-            sizes = self._global_step_sizes(epoch, len(plan))
             total_iters += int(sum(n for n, b in zip(sizes, bad) if not b))
             self.epoch_losses = epoch_losses[:len(plan)].cpu().numpy()
             if self.rank == 0:
@@ -207,7 +215,10 @@ class DepthFineTuner:
         store, p = self.store, self.params
         chunks = parallel.eval_chunks(len(store), self.rank, self.world, p.batch_size)   # whole sequential batches of the reference's sweep
         plan = [ids for _, ids in chunks]
-        names = ["reprojection", "disparity"]   # the per-pair entries of ConsistencyLoss (consistency_loss.py:206), on every rank
+        # the per-pair entries of ConsistencyLoss (consistency_loss.py:206); JointLoss adds that term only when one of its two
+        # weights is positive (joint_loss.py:20-24), so a parameter-only configuration has no per-pair entries.  Decided from the
+        # parameters, i.e. identically on every rank (the gather below needs equal column counts).
+        names = ["reprojection", "disparity"] if max(p.lambda_view_baseline, p.lambda_reprojection) > 0 else []
         rows = []
         plan_dev = parallel.plan_to_device(plan, store.device)
         frames_of = store.pair_indices()    # host copy of the pair list: no device sync to learn which frames a batch holds

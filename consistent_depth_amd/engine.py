@@ -40,6 +40,13 @@ class FineTuneStep:
         if self.world > 1 and n_buckets > 1 and getattr(model, "_engine", None) is None and self.opt.flat_grad.numel() >= (8 << 20):
             self.buckets = parallel.GradBuckets(self.opt, n_buckets)
 
+    def close(self):
+        """Release what the step hooked into the model (the bucketed all-reduce's parameter hooks); call when a step object is
+        replaced by another one on the same model."""
+        if self.buckets is not None:
+            self.buckets.close()
+            self.buckets = None
+
     def _backward_and_reduce(self, loss):
         """backward + the data-parallel exchange; returns the guard scalar (the summed loss with world > 1)."""
         guard = loss.detach()
@@ -57,6 +64,13 @@ class FineTuneStep:
         parallel.allreduce_sum_(self.opt.reduce_buffer)
         return self.opt.loss_slot
 
+    def _weights_updated(self):
+        """Tell the model that the optimiser moved its weights (it writes through raw pointers, so tensor version counters do
+        not change): derived copies -- the MiDaS backbone's packed filters (ops/conv_layer.py::PackPool) -- are stale."""
+        hook = getattr(self.model, "weights_updated", None)
+        if hook is not None:
+            hook()
+
     def forward_loss(self, images, metadata):
         raw = self.model.estimate_raw(images)
         return self.criterion(raw, metadata, parameters=self._plist)
@@ -68,6 +82,7 @@ class FineTuneStep:
         loss, parts = self.criterion(raw, metadata, parameters=self._plist)
         guard = self._backward_and_reduce(loss)
         self.opt.step(grad_scale=1.0 / self.world, guard_loss=guard)
+        self._weights_updated()
         return loss.detach(), parts
 
     def step_from_store(self, store, pair_ids: torch.Tensor):
@@ -93,6 +108,7 @@ class FineTuneStep:
             parallel.allreduce_sum_(self.opt.reduce_buffer)
             guard = self.opt.loss_slot
         self.opt.step(grad_scale=1.0 / self.world, guard_loss=guard)
+        self._weights_updated()
 
     @torch.no_grad()
     def evaluate(self, images, metadata):
@@ -199,6 +215,8 @@ class GraphedFineTuneStep:
         g["graph"].replay()
         if self.step.world > 1 and not self.graph_collective:
             self.step._update(g["guard"])
+        else:
+            self.step._weights_updated()     # the update ran inside the replay
         return g["guard"].clone(), {k: v.clone() for k, v in g["parts"].items()}
 
     def step_from_store(self, store, pair_ids: torch.Tensor):
@@ -218,7 +236,12 @@ class GraphedFineTuneStep:
         g["graph"].replay()
         if self.step.world > 1 and not self.graph_collective:
             self.step._update(g["guard"])
+        else:
+            self.step._weights_updated()
         return g["guard"].clone(), {k: v.clone() for k, v in g["parts"].items()}, g["meta"]
 
     def evaluate(self, images, metadata):
         return self.step.evaluate(images, metadata)
+
+    def close(self):
+        self.step.close()

@@ -65,5 +65,11 @@ class MidasV2Model(DepthModel):
     def estimate_depth(self, images):
         return self.estimate_raw(images).reciprocal()
 
+    def weights_updated(self):
+        """Called by the fine-tuning step after every optimiser update: the packed copies of the filters are stale."""
+        pool = getattr(self.model, "_pack_pool", None)
+        if pool is not None:
+            pool.invalidate()
+
     def save(self, file_name):
         torch.save(self.model.state_dict(), file_name)

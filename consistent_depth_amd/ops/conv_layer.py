@@ -67,6 +67,7 @@ class PackPool:
         self.fresh = True
 
     def invalidate(self):
+        """The weights moved (an optimiser step): the packed copies are stale until the next run()."""
         self.fresh = False
 
 
@@ -159,8 +160,13 @@ class HipConv2d(torch.nn.Conv2d):
     def _packed(self, weight, transposed_too=False):
         if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32):
             raise RuntimeError("HipConv2d: weights must be contiguous fp32 on the HIP device (no CPU path)")
-        if self._pool is not None and self._pool.fresh and self._wptr == weight.data_ptr():
-            return self._pk, self._pkT      # packed by the pool's single launch at the start of this forward
+        if self._pool is not None:
+            # packed by the pool's single launch at the start of this forward.  The pool is fresh from that launch until the
+            # optimiser moves the weights (engine.FineTuneStep -> model.weights_updated() -> PackPool.invalidate()); a pooled layer
+            # called outside the network's forward after an update (a sub-module, a feature extractor, a test) re-packs the pool.
+            if not (self._pool.fresh and self._wptr == weight.data_ptr()):
+                self._pool.run()
+            return self._pk, self._pkT
         if self._wptr != weight.data_ptr():       # first use, or the optimiser re-homed the parameter
             self._pk, self._table, self._arena = self._build(weight, False)
             self._pkT = self._tableT = None

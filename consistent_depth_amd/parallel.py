@@ -54,11 +54,17 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def collective_active() -> bool:
+    """ONE predicate for every data-parallel exchange (flat all-reduce, bucketed all-reduce, loss slot): a process group exists.
+    The callers decide with their own `world` whether there is anything to exchange; with a one-rank group the collective still
+    runs -- that is how the RCCL launch inside a captured step, flat or bucketed, is exercised on a one-GPU box
+    (tests/test_dp_gpu.py)."""
+    return dist.is_initialized()
+
+
 def allreduce_sum_(buf: torch.Tensor):
-    """In-place sum over ranks of one flat fp32 buffer (no-op without a process group).  With a one-rank group the collective
-    still runs (the callers decide with their own `world`): that is how the RCCL launch inside a captured step is exercised on a
-    one-GPU box (tests/test_dp_gpu.py)."""
-    if dist.is_initialized():
+    """In-place sum over ranks of one flat fp32 buffer (no-op without a process group; see collective_active)."""
+    if collective_active():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
@@ -115,7 +121,7 @@ class GradBuckets:
     def _launch(self, b):
         lo, hi = self.ranges[b]
         self._launched[b] = True
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if collective_active():
             self._work.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _on_grad(self, p):
@@ -131,15 +137,17 @@ class GradBuckets:
         for b in range(len(self.ranges)):
             if not self._launched[b]:
                 self._launch(b)
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if collective_active():
             self._work.append(dist.all_reduce(self.opt.loss_slot, op=dist.ReduceOp.SUM, async_op=True))
         for w in self._work:
             w.wait()
         self._work, self._armed = [], False
 
     def close(self):
+        """Remove the parameter hooks (FineTuneStep.close() calls this when the step is discarded)."""
         for h in self._handles:
             h.remove()
+        self._handles = []
 
 
 def broadcast_(tensors, src: int = 0):

@@ -44,7 +44,10 @@ typedef enum cd_depth_mode {
     CD_DEPTH_RECIPROCAL = 2
 } cd_depth_mode;
 
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any change of an exported signature, of the meaning of an argument, or of the export list
+ * (6: cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped added, cd_bn_relu_bwd's last argument became a flags bitfield).
+ * The loader (consistent_depth_amd/_native.py) refuses a library whose cd_abi_version() differs from this constant. */
+#define CD_ABI_VERSION 6
 int cd_abi_version(void);
 
 /* Batch-statistics buffers (the `stats` arguments below) hold CD_BN_STAT_SLOTS partial copies:
