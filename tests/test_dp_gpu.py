@@ -227,3 +227,25 @@ def test_rccl_collective_inside_the_step_graph(tmp_path):
     res = json.loads(lines[-1][len("RESULT "):])
     assert res["graphed"] == [True, True] and res["collective_in_graph"] == [False, True], res
     assert res["losses_eager_collective"] == res["losses_graphed_collective"] and res["params_equal"], res
+
+
+def test_bench_main_two_ranks_end_to_end(tmp_path):
+    """bench.py's own main() with --gpus 2, end to end on this box's one GPU (gloo transport between the two ranks, because RCCL
+    refuses two ranks on one device): the self-launch under torch.distributed.run, the shared-seed shards of EpochPlans, graph
+    replay + eager all-reduce + Adam, barrier-bracketed timing with the maximum over ranks, the finite-loss decision taken on the
+    minimum over ranks, rank 0 printing ONE line -- the path the driver's multi-GPU tier runs (over RCCL)."""
+    env = dict(os.environ, CD_AMD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--frames", "10",
+                        "--height", "64", "--width", "48", "--no-loss-microbench", "--no-cpu-baseline", "--no-config5"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["global_batch"] == 8 and cfg["parallelism"] == "dp2" and cfg["finite_loss_steps"] == 3 and cfg["hip_graph"] is True
+    assert "DP over 2 GPUs" in cfg["workload"] and "configs[3]:" not in cfg["workload"]      # a 10-frame clip is not configs[3]
+    assert "eager, after the graph replay" in cfg["dp_exchange"]
+    assert out["value"] == pytest.approx(8 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-3)

@@ -205,3 +205,50 @@ def test_scene_scale_is_the_reference_scale_calibration():
     _, p1 = crit(depth * s, meta_s)
     np.testing.assert_allclose(p1["reprojection"].cpu().numpy(), p0["reprojection"].cpu().numpy(), rtol=2e-4)
     np.testing.assert_allclose(p1["disparity"].cpu().numpy() * s, p0["disparity"].cpu().numpy(), rtol=2e-4)
+
+
+class _ScalarLog:
+    def __init__(self):
+        self.points = []
+
+    def add_scalar(self, tag, value, n):
+        self.points.append((tag, int(n)))
+
+
+def test_training_scalars_are_logged_at_the_running_pair_count(tmp_path):
+    """The reference advances total_iters by the batch BEFORE it logs the step (depth_fine_tuning.py:285-288): every step of an
+    epoch lands on its own global position, in pairs.  (Round 3 logged a whole epoch at the epoch-start value.)"""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_dataset as msd
+    from consistent_depth_amd.depth_fine_tuning import DepthFineTuner
+    from consistent_depth_amd.params import Video3dParamsParser
+    path = str(tmp_path / "clip")
+    range_dir, pairs = msd.write_dataset(path, n_frames=6, H=64, W=48, seed=3)
+    params = Video3dParamsParser().parse(["--path", path, "--num_epochs", "2", "--batch_size", "4", "--print_freq", "1"])
+    log = _ScalarLog()
+    DepthFineTuner(range_dir, list(range(6)), params).fine_tune(writer=log)
+    got = [n for tag, n in log.points if tag == "Train/loss"]
+    n, want, pos = len(pairs), [], 0
+    for _epoch in range(2):
+        for s in range(0, n, 4):
+            pos += min(4, n - s)
+            want.append(pos)
+    assert got == want, (got, want)
+
+
+def test_parameter_only_objective_validates_without_per_pair_entries(tmp_path):
+    """lambda_reprojection = lambda_view_baseline = 0, lambda_parameter > 0: JointLoss has no ConsistencyLoss term
+    (joint_loss.py:20-24), so the validation sweep has no per-pair entries to index (round 3 raised KeyError)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_dataset as msd
+    from consistent_depth_amd.depth_fine_tuning import DepthFineTuner
+    from consistent_depth_amd.params import Video3dParamsParser
+    path = str(tmp_path / "clip")
+    range_dir, pairs = msd.write_dataset(path, n_frames=4, H=64, W=48, seed=5)
+    params = Video3dParamsParser().parse(["--path", path, "--num_epochs", "1", "--batch_size", "4", "--lambda_reprojection", "0",
+                                          "--lambda_view_baseline", "0", "--lambda_parameter", "1.0"])
+    ft = DepthFineTuner(range_dir, list(range(4)), params)
+    ft.fine_tune()
+    with open(os.path.join(ft.out_dir, "eval", f"loss_e0001_iter{len(pairs):06d}.json")) as f:
+        assert json.load(f) == {"mean": {}}
+    assert os.path.exists(os.path.join(ft.out_dir, "eval", f"depth_000000_e0001_iter{len(pairs):06d}.raw"))

@@ -169,3 +169,32 @@ def test_pack_pool_follows_the_weights():
         for p in hip.parameters():
             p.data = p.data.clone()
     check("after re-homing")
+
+
+def test_pooled_layer_outside_the_network_forward_sees_updated_weights():
+    """A pooled HipConv2d called on its own (a sub-module call, a feature extractor) after the optimiser moved the weights: the
+    fine-tuning step tells the model (`weights_updated()` -> PackPool.invalidate()), and the layer re-packs the pool instead of
+    returning the buffers packed at the start of the last network forward (round 3: `fresh` was never cleared)."""
+    import argparse
+    import torch
+    from consistent_depth_amd.engine import FineTuneStep
+    from consistent_depth_amd.monodepth.depth_model_registry import get_depth_model
+    model = get_depth_model("midas2")(seed=0)
+    model.train()
+    net = model.model
+    pool = net._pack_pool
+    layer = net.scratch.layer1_rn                         # a pooled 3x3 256 -> 256
+    x = torch.rand(1, 256, 32, 32, device="cuda")
+    with torch.no_grad():
+        net(torch.rand(1, 3, 64, 64, device="cuda"))      # packs the pool
+        assert pool.fresh
+        y0 = layer(x)
+        layer.weight.mul_(2.0)                            # what an optimiser step does: in place, through the same storage
+    params = argparse.Namespace(lambda_reprojection=1.0, lambda_view_baseline=1e-4, lambda_parameter=0, learning_rate=1e-4, optimizer="Adam")
+    step = FineTuneStep(model, params, world=1)
+    step._weights_updated()
+    assert not pool.fresh
+    with torch.no_grad():
+        y1 = layer(x)                                     # re-packs (the pool is stale), then runs
+    assert pool.fresh
+    assert float((y1 - 2.0 * y0).abs().max()) <= 1e-5 * float(y0.abs().max())
