@@ -5,7 +5,6 @@
 //   prep_kernel            per-(pair, direction) camera constants + gradient scales (128 B each)
 //   forward only :  loss_main_kernel<GRAD=false>          (v1, pure streaming, no atomics)
 //   with gradient:  loss_source_kernel + loss_gather_kernel (v3: evaluate once, reduce slabs; no global atomics)
-//                   [or loss_owner_kernel (v2) when selected with cd_debug_set_loss_variant(2)]
 //                   -> overflow_apply_kernel
 //                   -> zero_guarded + loss_main_kernel<GRAD=true> (idle unless the overflow list overflowed)
 //   finalize_pairs / finalize_total   fixed-order fp64 reduction -> reproj[B], disp[B], total[1]
@@ -162,7 +161,7 @@ static inline size_t ws_layout(int B, int H, int W, void* base, Workspace* w) {
 }
 
 static int g_force_overflow_cap = -1;  // test hook: shrink the overflow list (cd_debug_set_overflow_capacity)
-static int g_loss_variant = 0;         // 0 = by batch and geometry (row sweep v4 when it fills the chip, else v3), 2 / 3 / 4 forced
+static int g_loss_variant = 0;         // 0 = by batch and geometry (row sweep v4 when it fills the chip, else v3), 3 / 4 forced
 
 static int run_loss(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb,
                     const float* mask_sum, const void* tile_windows, const float* intr, const float* extr,
@@ -214,9 +213,6 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         if (use_sweep)
             rc = launch_sweep(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf, cap,
                               s, prof_before, prof_after);
-        else if (g_loss_variant == 2)
-            rc = launch_owner(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf,
-                              cap, s, prof_before, prof_after);
         else
             rc = launch_slab(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.slabs,
                              w.ovf, cap, s, prof_before, prof_after);
@@ -283,7 +279,7 @@ int cd_debug_set_loss_chunk(int pairs) {
 }
 
 int cd_debug_set_loss_variant(int v) {
-    if (v != 0 && v != 2 && v != 3 && v != 4) return CD_ERR_INVALID_ARG;
+    if (v != 0 && v != 3 && v != 4) return CD_ERR_INVALID_ARG;
     cd::g_loss_variant = v;
     return CD_OK;
 }

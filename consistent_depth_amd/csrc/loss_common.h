@@ -1,5 +1,5 @@
 // Shared by the consistency-loss kernels (loss_fused.hip: v1 scatter-by-atomics, now the
-// forward-only path and the device-side fallback; loss_owner.hip: v2 owner-computes; loss_api.hip:
+// forward-only path and the device-side fallback; loss_tiles.hip: tile windows + overflow list; loss_api.hip:
 // C-ABI entry points and launch sequence).
 #pragma once
 #include "cd_common.h"
@@ -18,18 +18,13 @@ int launch_v1(const float* depth, const float* ff, const float* fb, const float*
               const int* run_flag, hipStream_t s);
 int launch_zero_guarded(float* buf, size_t n, const int* run_flag, hipStream_t s);
 
-// ---- v2 (loss_owner.hip)
+// ---- tile tables and the overflow list (loss_tiles.hip; the names keep round 1's "owner" prefix: 32x32 tiles of a gradient plane)
 int owner_tiles_x(int W);
 int owner_ntiles(int H, int W);
 size_t owner_windows_bytes(int B, int H, int W);
 int launch_tile_windows(const float* ff, const float* fb, const float* mf, const float* mb, int B, int H, int W,
                         void* wins, hipStream_t s);
-// Enqueues: overflow header reset, [before_main] owner kernel [after_main], overflow apply.
 // ovf_mem = 256-byte header + idx[cap] + val[cap].
-int launch_owner(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb,
-                 const void* cams, const void* wins, int mode, bool reproj, int B, int H, int W, float* partial,
-                 float* grad, void* ovf_mem, int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t),
-                 void (*after_main)(hipStream_t));
 const int* owner_fallback_flag(void* ovf_mem);
 int launch_overflow_apply(void* ovf_mem, int ovf_cap, float* grad, hipStream_t s);
 

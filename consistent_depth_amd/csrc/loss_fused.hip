@@ -7,7 +7,7 @@
 // weighted_mean_loss consistency_loss.py:73-89, plus the autograd backward of all of it.
 // Per-pixel closed form: SURVEY.md appendix A.1 / DESIGN.md section 3.
 //
-// Role since v2 exists (loss_owner.hip):
+// Role since the tiled gradient kernels exist (loss_slab.hip, loss_sweep.hip):
 //   (a) the FORWARD-ONLY path (validation sweep, GRAD = false): no gradient, hence no atomics --
 //       a pure coalesced streaming kernel (16 B per lane when W % 4 == 0);
 //   (b) the device-side FALLBACK of v2 (GRAD = true): needs a zeroed gradient and issues up to 5

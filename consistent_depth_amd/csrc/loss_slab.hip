@@ -1,6 +1,6 @@
 // Fused geometric-consistency loss, v3: "evaluate once, reduce slabs" -- the training path.
 //
-// Same math as loss_owner.hip (v2) and loss_fused.hip (v1); different decomposition of the scatter part
+// Same math as loss_fused.hip (v1); different decomposition of the scatter part
 // of d loss / d depth (the 4 bilinear taps of the OTHER frame's depth per source pixel):
 //
 //   pass A  loss_source_kernel   one workgroup = one 32x32 tile of SOURCE pixels of plane (b, j):

@@ -1,5 +1,5 @@
 // Tile / window machinery shared by the gradient kernels of the consistency loss
-// (loss_owner.hip: v2 owner-computes; loss_slab.hip: v3 single evaluation + slab reduce).
+// (loss_slab.hip: v3 single evaluation + slab reduce; loss_tiles.hip builds the table).
 #pragma once
 #include "loss_common.h"
 

@@ -133,7 +133,7 @@ int cd_profile_end(float* ms_out, int* batch_out, int capacity, int* n_out);
 int cd_debug_set_overflow_capacity(int cap);
 /* Test / A-B hook: gradient-kernel formulation.  0 = default dispatch (the row sweep when the batch gives every CU a pair
  * and the image is narrow enough for a >= 24-row ring, else the tile kernels), 4 = row sweep (one workgroup per pair, row
- * rings in LDS; falls back to 3 where its geometry is unsupported), 3 = evaluate once + slab reduce, 2 = owner-computes. */
+ * rings in LDS; falls back to 3 where its geometry is unsupported), 3 = evaluate once + slab reduce.  Any other value: CD_ERR_INVALID_ARG. */
 int cd_debug_set_loss_variant(int variant);
 /* Row sweep: pixels per thread (1, 2, 4; 0 = default rule).  It fixes the rows per item, hence the plan stored in the
  * tile-windows blob: set it BEFORE cd_tile_windows_bytes / cd_tile_windows and keep it for the loss calls that use the blob. */

@@ -45,10 +45,11 @@ def _run(torch, batch, lr, lb, mode=0, mask_sums=None):
     return total.item(), reproj.cpu().numpy(), disp.cpu().numpy(), g
 
 
-@pytest.fixture(params=[4, 3, 2], ids=["sweep", "slab", "owner"])
+@pytest.fixture(params=[4, 3], ids=["sweep", "slab"])
 def variant(request):
     """Every formulation of the gradient kernel: v4 row sweep (one workgroup per pair; the default for large batches),
-    v3 evaluate-once + slab reduce (the default for small batches), v2 owner-computes."""
+    v3 evaluate-once + slab reduce (the default for small batches).  (Round 1's v2 "owner-computes" kernel was removed in
+    round 4: never the dispatch choice, its exact fallback role is v1's.)"""
     from consistent_depth_amd import _native
     lib = _native.lib()
     assert lib.cd_debug_set_loss_variant(request.param) == 0
@@ -74,7 +75,7 @@ def test_golden_vectors(torch_cuda, oracle, name, variant):
 @pytest.mark.parametrize("H,W", [(384, 224), (224, 384)])
 def test_baseline_size_vs_oracle(torch_cuda, oracle, H, W, gen, variant):
     """BASELINE size (B=4, 384x224 and its transpose) on consistent-scene data (what real video looks
-    like: the owner kernel's windows see every source) and on the adversarial generator (unrelated
+    like: the tile windows cover every source) and on the adversarial generator (unrelated
     depth per frame: a few % of the scatter goes through the overflow list)."""
     from consistent_depth_amd import synthetic
     batch = (synthetic.make_scene_batch if gen == "scene" else synthetic.make_pair_batch)(4, H, W, seed=11)
@@ -135,7 +136,7 @@ def test_forward_only_and_cached_mask_sums(torch_cuda):
 @pytest.mark.parametrize("cap", [0, 7, 1000])
 @pytest.mark.parametrize("name", ["stress_b2_32x48", "basic_b3_48x40"])
 def test_overflow_list_and_device_fallback(torch_cuda, oracle, name, cap, variant):
-    """The owner-computes kernel is exact for ANY flow: sources outside the predicted windows go
+    """The gradient kernels are exact for ANY flow: taps outside the staged windows go
     through the overflow list (cap large), and when the list itself overflows (cap tiny) the
     device-side fallback recomputes the gradient.  Forced here with the debug capacity hook."""
     from consistent_depth_amd import _native

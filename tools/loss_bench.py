@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--mode", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=0, help="pairs per source+gather launch pair (0 = default)")
-    ap.add_argument("--variant", type=int, default=0, help="0 = default dispatch, 4 = row sweep, 3 = evaluate-once + slab reduce, 2 = owner-computes")
+    ap.add_argument("--variant", type=int, default=0, help="0 = default dispatch, 4 = row sweep, 3 = evaluate-once + slab reduce")
     ap.add_argument("--pxt", type=int, default=0, help="row sweep: pixels per thread (0 = default rule)")
     ap.add_argument("--noise-px", type=float, default=0.25)
     ap.add_argument("--inconsistent", action="store_true", help="adversarial generator: unrelated depth per frame")
