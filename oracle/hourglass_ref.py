@@ -17,6 +17,8 @@ In training mode BatchNorm uses batch statistics and (optionally) updates runnin
 import torch
 import torch.nn.functional as F
 
+from .conv64 import conv2d_same      # fp64 on the CPU: dgemm-based (torch's double conv2d has no vendor kernel); else F.conv2d
+
 _E = [[64], [3, 32, 64], [5, 32, 64], [7, 32, 64]]
 _SPEC = {
     "A": [[16], [3, 32, 16], [7, 32, 16], [11, 32, 16]],
@@ -50,7 +52,8 @@ def _bn(state, key, x, training, affine, update):
 
 
 def _conv_bn_relu(state, key_conv, key_bn, x, pad, training, update):
-    x = F.conv2d(x, state[key_conv + ".weight"], state[key_conv + ".bias"], padding=pad)
+    assert pad == (state[key_conv + ".weight"].shape[-1] - 1) // 2
+    x = conv2d_same(x, state[key_conv + ".weight"], state[key_conv + ".bias"])
     return F.relu(_bn(state, key_bn, x, training, False, update))
 
 
@@ -81,11 +84,11 @@ def _channels(state, pre, level, x, training, update):
 
 
 def forward(state, x, training=True, update_running_stats=False):
-    h = F.conv2d(x, state["seq.0.weight"], state["seq.0.bias"], padding=3)
+    h = conv2d_same(x, state["seq.0.weight"], state["seq.0.bias"])
     h = F.relu(_bn(state, "seq.1", h, training, True, update_running_stats))
     feat = _channels(state, "seq.3", 4, h, training, update_running_stats)
-    pred = F.conv2d(feat, state["pred_layer.weight"], state["pred_layer.bias"], padding=1)
-    conf = torch.sigmoid(F.conv2d(feat, state["uncertainty_layer.0.weight"], state["uncertainty_layer.0.bias"], padding=1))
+    pred = conv2d_same(feat, state["pred_layer.weight"], state["pred_layer.bias"])
+    conf = torch.sigmoid(conv2d_same(feat, state["uncertainty_layer.0.weight"], state["uncertainty_layer.0.bias"]))
     return pred, conf
 
 

@@ -69,3 +69,25 @@ def test_pairs_are_independent_except_for_the_batch_mean_focal(oracle):
     np.testing.assert_allclose(whole["total"][0], np.mean([s["total"][0] for s in singles]), rtol=1e-13)
     for i, s in enumerate(singles):
         np.testing.assert_allclose(whole["grad_depth"][i] * 3, s["grad_depth"][0], rtol=1e-10, atol=1e-16)
+
+
+@pytest.mark.parametrize("N,Ci,Co,k,H,W", [(2, 5, 7, 3, 9, 11), (1, 8, 4, 11, 13, 12), (2, 6, 6, 1, 5, 7), (1, 3, 16, 7, 20, 18), (1, 4, 3, 5, 6, 4)])
+def test_fp64_gemm_convolution_of_the_oracle_is_conv2d(N, Ci, Co, k, H, W):
+    """oracle/conv64.py (the dgemm formulation that makes fp64 ground truth at 384x224 affordable) IS
+    torch.nn.functional.conv2d(padding=(k-1)//2): values and all three gradients, to fp64 round-off."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.conv64 import conv2d_same
+    g = torch.Generator().manual_seed(N * 100 + k)
+    x = torch.randn(N, Ci, H, W, dtype=torch.float64, generator=g).requires_grad_(True)
+    w = torch.randn(Co, Ci, k, k, dtype=torch.float64, generator=g).requires_grad_(True)
+    b = torch.randn(Co, dtype=torch.float64, generator=g).requires_grad_(True)
+    dy = torch.randn(N, Co, H, W, dtype=torch.float64, generator=g)
+    y1 = conv2d_same(x, w, b)
+    y2 = F.conv2d(x, w, b, padding=(k - 1) // 2)
+    g1, g2 = torch.autograd.grad(y1, (x, w, b), dy), torch.autograd.grad(y2, (x, w, b), dy)
+    assert float((y1 - y2).abs().max()) < 1e-12 * max(1.0, float(y2.abs().max()))
+    for a, c in zip(g1, g2):
+        assert float((a - c).abs().max()) < 1e-12 * max(1.0, float(c.abs().max()))
+    # fp32 (and anything that is not fp64 on the CPU) stays on torch's own convolution
+    assert conv2d_same(x.float(), w.float(), b.float()).dtype == torch.float32
