@@ -57,6 +57,8 @@ SIGNATURES = {
     "cd_debug_set_wgrad_mode": (c_i, [c_i]),
     "cd_conv2d_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),
     "cd_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cd_conv2d_wgrad_desc": (c_i, [c_p]),
+    "cd_conv2d_wgrad_table": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "cd_conv2d_wgrad_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
     "cd_conv2d_wgrad_unpack_table": (c_i, [c_p, c_i, c_p]),
     "cd_rccl_available": (c_i, []),

@@ -721,6 +721,28 @@ int cd_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int Cin, const float
     return CD_OK;
 }
 
+int cd_conv2d_wgrad_desc(cd_wgrad_desc* desc) {
+    static_assert(sizeof(cd_wgrad_desc) == sizeof(cd::WgradDesc), "cd_wgrad_desc / WgradDesc");
+    if (!desc) return CD_ERR_INVALID_ARG;
+    cd::WgradDesc* d = reinterpret_cast<cd::WgradDesc*>(desc);
+    d->klass = -1; d->blocks = 0; d->block_end = 0; d->pad = 0;
+    if (!d->x || !d->dy || !d->workspace || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return CD_ERR_INVALID_ARG;
+    if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_ctot || d->dy_coff < 0 || d->dy_coff + d->Cout > d->dy_ctot) return CD_ERR_INVALID_ARG;
+    if ((d->in_scale == nullptr) != (d->in_shift == nullptr)) return CD_ERR_INVALID_ARG;
+    if (cd_conv2d_wgrad_workspace_floats(d->Cout, d->Cin, d->ks) == 0) return CD_ERR_UNSUPPORTED;
+    // the layout (blocks per channel group, 16 x 16 or 32 x 16 channel blocks) is the one cd_conv2d_wgrad chooses for the same
+    // arguments: same workspace contents, same cd_conv2d_wgrad_plan, same unpack descriptors
+    const cd::WgLayout L = cd::wgrad_layout(d->Cout, d->Cin, d->ks, d->N, d->H, d->W);
+    if (!L.split_arith) return CD_OK;      // klass stays -1: not one of the table kernels' gradients -- launch it on its own
+    cd::wgrad_split_desc_geometry(d, L.splits, L.cot);
+    return CD_OK;
+}
+
+int cd_conv2d_wgrad_table(const void* table_dev, int n, int klass, int total_blocks, void* stream) {
+    if (!table_dev || n <= 0 || n > 64 || klass < 0 || klass > 4 || total_blocks <= 0) return CD_ERR_INVALID_ARG;
+    return cd::launch_wgrad_split_table(table_dev, n, klass, total_blocks, (hipStream_t)stream);
+}
+
 int cd_conv2d_wgrad_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* dy, int dy_ctot, int dy_coff, int cout_g,
                             int groups, float* dw, int accumulate, float* workspace, size_t workspace_group_stride, int N, int H, int W,
                             int ks, void* stream) {

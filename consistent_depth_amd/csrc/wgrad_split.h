@@ -20,6 +20,17 @@ int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const fl
                        hipStream_t s, int groups = 1, size_t ws_group_stride = 0, int cot = 1);   // groups > 1: Cin / Cout per group, slices g * Cin / g * Cout;
                                                                                                   // cot: 16-channel output groups per block (the layout's choice)
 
+// ---- many weight gradients in one launch (cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table; = cd_wgrad_desc of the public header)
+struct WgradDesc {
+    const float* x; const float* in_scale; const float* in_shift; const float* dy; float* workspace;
+    int x_ctot, x_coff, Cin, in_relu, dy_ctot, dy_coff, Cout, N, H, W, ks;
+    int klass, splits, cigs, zpg, cogs, tiles_x, tiles_y, blocks, block_end, pad;
+};
+static_assert(sizeof(WgradDesc) == 128, "cd_wgrad_desc layout");
+int wgrad_split_class(int ks, int cot);
+void wgrad_split_desc_geometry(WgradDesc* d, int splits, int cot);    // fills klass .. blocks from the layout's choice of (splits, cot)
+int launch_wgrad_split_table(const void* table_dev, int n, int klass, int total_blocks, hipStream_t s);
+
 // ---- 1x1 weight gradient (wgrad1x1_split.hip): a wave owns a 64 x 128 (co x ci) patch of dW
 constexpr int WGRAD1X1_COB = 64, WGRAD1X1_CIB = 128;
 // usable with >= 96 output channels, when H * W is a multiple of 16 (whole 16-pixel steps inside an image), the tensors have < 2^30 elements per image set and

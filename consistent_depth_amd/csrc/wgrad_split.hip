@@ -98,12 +98,24 @@ __device__ __forceinline__ void ws_wave(const unsigned* __restrict__ s_x, const 
     }
 }
 
+// One weight gradient as the kernels see it (a stand-alone launch passes its grid: splits = gridDim.x, cigs = gridDim.y).
+struct WsArgs {
+    const float* x; const float* in_scale; const float* in_shift; const float* dy; float* dw_packed;
+    int x_ctot, x_coff, Cin, in_relu, dy_ctot, dy_coff, Cout, N, H, W, tiles_x, tiles_y, cogs, zpg, g_xc, g_dyc;
+    size_t g_ws;
+    int splits, cigs;
+};
+
+// The work of block (bx, by, bz) of the stand-alone grid (splits, cigs, zpg * groups) of one weight gradient.
 template <int KS, int COT>
-__global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split_kernel(
-    const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
-    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
-    const float* __restrict__ dy, int dy_ctot, int dy_coff, int Cout,
-    float* __restrict__ dw_packed, int N, int H, int W, int tiles_x, int tiles_y, int cogs, int zpg, int g_xc, int g_dyc, size_t g_ws) {
+__device__ __forceinline__ void ws_block(const WsArgs& a, const int bx, const int by, const int bz) {
+    const float* __restrict__ x = a.x; const float* __restrict__ in_scale = a.in_scale; const float* __restrict__ in_shift = a.in_shift;
+    const float* __restrict__ dy = a.dy; float* __restrict__ dw_packed = a.dw_packed;
+    int x_coff = a.x_coff, dy_coff = a.dy_coff;
+    const int x_ctot = a.x_ctot, Cin = a.Cin, in_relu = a.in_relu, dy_ctot = a.dy_ctot, Cout = a.Cout, N = a.N, H = a.H, W = a.W;
+    const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, cogs = a.cogs, zpg = a.zpg, g_xc = a.g_xc, g_dyc = a.g_dyc;
+    const size_t g_ws = a.g_ws;
+    const int n_splits = a.splits, n_cigs = a.cigs;
     using Cfg = WsCfg<KS, COT>;
     constexpr int TY = Cfg::TY, P = Cfg::P, TAPS = Cfg::TAPS, TPW = Cfg::TPW, ROWS = Cfg::ROWS, PSX = Cfg::PSX, PSD = Cfg::PSD;
     constexpr int SPX = Cfg::SPX, SPD = Cfg::SPD, NT = Cfg::NW * 64;
@@ -114,8 +126,8 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
     // blockIdx.z = group * zpg + cog: a grouped convolution is `groups` independent gradients on channel slices, each with its
     // own packed workspace (g_ws floats apart); dense launches have one group.  cog counts blocks of 16 * COT output channels
     // (zpg per group), `cogs` the 16-channel tiles of the packed layout.
-    const int grp = blockIdx.z / zpg;
-    const int cig = blockIdx.y, cog = blockIdx.z - grp * zpg;
+    const int grp = bz / zpg;
+    const int cig = by, cog = bz - grp * zpg;
     x_coff += grp * g_xc;
     dy_coff += grp * g_dyc;
     dw_packed += (size_t)grp * g_ws;
@@ -217,13 +229,13 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
     };
 
     constexpr bool AHEAD = KS != 11 || CD_WGRAD_AHEAD11;   // (k = 11: 64 accumulator registers + the 23-register windows; see the header)
-    if (AHEAD && !(CD_WS_DBG & 2) && (int)blockIdx.x < items) fetch(blockIdx.x);
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    if (AHEAD && !(CD_WS_DBG & 2) && bx < items) fetch(bx);
+    for (int item = bx; item < items; item += n_splits) {
         if (!AHEAD && !(CD_WS_DBG & 2)) fetch(item);   // all loads of the tile in flight at once, landing while the slower waves finish the previous tile
         __syncthreads();   // the previous tile is consumed (first trip: s_aff is written)
         if (!(CD_WS_DBG & 2)) commit();
         __syncthreads();
-        if (AHEAD && !(CD_WS_DBG & 2) && item + (int)gridDim.x < items) fetch(item + gridDim.x);   // in flight during the MFMAs below
+        if (AHEAD && !(CD_WS_DBG & 2) && item + n_splits < items) fetch(item + n_splits);   // in flight during the MFMAs below
         if (CD_WS_DBG & 1) continue;
         if (wid == 0) ws_wave<KS, 0, COT>(s_x, s_dy, acc, lane);
         else if (wid == 1) ws_wave<KS, 1, COT>(s_x, s_dy, acc, lane);
@@ -241,8 +253,8 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
     // cog * COT + sub of the packed layout (absent when Cout is not a multiple of 16 * COT)
     const int sub = wid / Cfg::WPS, cog16 = cog * COT + sub;
     if (cog16 >= cogs) return;
-    const size_t slice = (size_t)cogs * gridDim.y * TAPS * 256;
-    const size_t base = (size_t)blockIdx.x * slice + ((size_t)cog16 * gridDim.y + cig) * TAPS * 256;
+    const size_t slice = (size_t)cogs * n_cigs * TAPS * 256;
+    const size_t base = (size_t)bx * slice + ((size_t)cog16 * n_cigs + cig) * TAPS * 256;
     const int ci_l = lane & 15, co4 = (lane >> 4) * 4;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -253,6 +265,35 @@ __global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split
             dst[0] = v.x; dst[16] = v.y; dst[32] = v.z; dst[48] = v.w;
         }
     }
+}
+
+template <int KS, int COT>
+__global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split_kernel(const WsArgs a) {
+    ws_block<KS, COT>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// MANY weight gradients of one (KS, COT) class in ONE launch: a flat grid, block b belongs to the descriptor d with
+// table[d - 1].block_end <= b < table[d].block_end and is block (b - start) of that gradient's stand-alone grid, x fastest.  Every
+// block does exactly what it does in its own launch (same items, same order, same slice of the same workspace): the packed partial
+// sums -- hence the weight gradients -- are bit-identical to per-convolution launches.  What the table buys: the small images of the
+// deep hourglass levels give a stand-alone launch a few dozen short blocks and an idle chip; here they ride along with the large
+// ones (the caller orders the table heaviest first), and there is one launch tail per class instead of one per convolution.
+template <int KS, int COT>
+__global__ __launch_bounds__((WsCfg<KS, COT>::NW * 64), 2) void conv_wgrad_split_table_kernel(const WgradDesc* __restrict__ table, int n) {
+    const int b = (int)blockIdx.x, lane = (int)(threadIdx.x & 63);
+    // the descriptor: every lane looks at one entry (n <= 64 per launch), the first one whose range ends beyond b is ours
+    const int end = table[lane < n ? lane : n - 1].block_end;
+    const unsigned long long m = __ballot(lane < n && b < end);
+    const int d = __builtin_amdgcn_readfirstlane(m ? __builtin_ctzll(m) : n - 1);
+    const WgradDesc& e = table[d];
+    const int local = b - (d > 0 ? table[d - 1].block_end : 0);
+    WsArgs a;
+    a.x = e.x; a.in_scale = e.in_scale; a.in_shift = e.in_shift; a.dy = e.dy; a.dw_packed = e.workspace;
+    a.x_ctot = e.x_ctot; a.x_coff = e.x_coff; a.Cin = e.Cin; a.in_relu = e.in_relu; a.dy_ctot = e.dy_ctot; a.dy_coff = e.dy_coff;
+    a.Cout = e.Cout; a.N = e.N; a.H = e.H; a.W = e.W; a.tiles_x = e.tiles_x; a.tiles_y = e.tiles_y; a.cogs = e.cogs; a.zpg = e.zpg;
+    a.g_xc = 0; a.g_dyc = 0; a.g_ws = 0; a.splits = e.splits; a.cigs = e.cigs;
+    const int bx = local % e.splits, rest = local / e.splits;
+    ws_block<KS, COT>(a, bx, rest % e.cigs, rest / e.cigs);
 }
 
 template <int KS, int COT>
@@ -267,10 +308,52 @@ static int launch_ws(const float* x, int x_ctot, int x_coff, int Cin, const floa
         (void)hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<KS, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_split_kernel<KS, COT>), dim3(splits, cigs, zpg * groups), dim3(Cfg::NW * 64), Cfg::LDS, s, x, x_ctot, x_coff, Cin,
-                       in_scale, in_shift, in_relu, dy, dy_ctot, dy_coff, Cout, packed, N, H, W, tiles_x, tiles_y, cogs, zpg, groups > 1 ? Cin : 0,
-                       groups > 1 ? Cout : 0, ws_group_stride);
+    WsArgs a;
+    a.x = x; a.in_scale = in_scale; a.in_shift = in_shift; a.dy = dy; a.dw_packed = packed;
+    a.x_ctot = x_ctot; a.x_coff = x_coff; a.Cin = Cin; a.in_relu = in_relu; a.dy_ctot = dy_ctot; a.dy_coff = dy_coff; a.Cout = Cout;
+    a.N = N; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.cogs = cogs; a.zpg = zpg;
+    a.g_xc = groups > 1 ? Cin : 0; a.g_dyc = groups > 1 ? Cout : 0; a.g_ws = ws_group_stride; a.splits = splits; a.cigs = cigs;
+    hipLaunchKernelGGL((conv_wgrad_split_kernel<KS, COT>), dim3(splits, cigs, zpg * groups), dim3(Cfg::NW * 64), Cfg::LDS, s, a);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+template <int KS, int COT>
+static int launch_ws_table(const WgradDesc* table_dev, int n, int total_blocks, hipStream_t s) {
+    using Cfg = WsCfg<KS, COT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_split_table_kernel<KS, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_split_table_kernel<KS, COT>), dim3(total_blocks), dim3(Cfg::NW * 64), Cfg::LDS, s, table_dev, n);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+// class index of (KS, COT) for the table launches: 0 (3,1)  1 (3,2)  2 (5,1)  3 (7,1)  4 (11,1)
+int wgrad_split_class(int ks, int cot) {
+    if (ks == 3) return cot == 2 ? 1 : 0;
+    return ks == 5 ? 2 : (ks == 7 ? 3 : (ks == 11 ? 4 : -1));
+}
+
+void wgrad_split_desc_geometry(WgradDesc* d, int splits, int cot) {
+    const int ty = wgrad_split_tile_rows(d->ks);
+    d->tiles_x = (d->W + 31) / 32; d->tiles_y = (d->H + ty - 1) / ty;
+    d->cogs = (d->Cout + 15) / 16; d->cigs = (d->Cin + 15) / 16; d->zpg = (d->cogs + cot - 1) / cot;
+    d->splits = splits;
+    d->klass = wgrad_split_class(d->ks, cot);
+    d->blocks = d->splits * d->cigs * d->zpg;
+}
+
+int launch_wgrad_split_table(const void* table_dev, int n, int klass, int total_blocks, hipStream_t s) {
+    const WgradDesc* t = (const WgradDesc*)table_dev;
+    switch (klass) {
+        case 0: return launch_ws_table<3, 1>(t, n, total_blocks, s);
+        case 1: return launch_ws_table<3, 2>(t, n, total_blocks, s);
+        case 2: return launch_ws_table<5, 1>(t, n, total_blocks, s);
+        case 3: return launch_ws_table<7, 1>(t, n, total_blocks, s);
+        case 4: return launch_ws_table<11, 1>(t, n, total_blocks, s);
+    }
+    return CD_ERR_UNSUPPORTED;
 }
 
 int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const float* in_scale, const float* in_shift, int in_relu,

@@ -91,6 +91,8 @@ class ConvUnit:
             sc = sh = None
         self.out = Act(dst_buf, dst_coff, self.cout, relu=bn_mod is not None, scale=sc, shift=sh, needs_grad=False)
         self.wgrad_ws = self.sums = None  # views into the plan's arenas (HourglassEngine._carve_arenas)
+        self.wgrad_batched = False        # True: this unit's weight gradient is part of the plan's WgradTable (one launch per kernel
+                                          # class at the end of the backward pass) -- backward() does not launch it
         self.bn_fused = False             # True: the owning inception runs the BN passes of its three branch outputs jointly
         self.pk, self.pkT = eng.packed(conv_mod)
         # launch shapes, timed once per distinct convolution shape (ops/conv.py::tuned_config)
@@ -126,9 +128,10 @@ class ConvUnit:
         else:
             L.channel_sum(gbuf, g_coff, self.cout, _grad_of(self.conv.bias), accumulate=True)
         # the partial sums stay packed in the arena; plan["unpack"] writes every weight gradient at the end of the backward
-        self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
-            s.buf, gbuf, self.cin, self.cout, self.ks, None, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,
-            in_shift=s.shift, in_relu=s.relu, prezeroed=True))
+        if not self.wgrad_batched:
+            self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
+                s.buf, gbuf, self.cin, self.cout, self.ks, None, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,
+                in_shift=s.shift, in_relu=s.relu, prezeroed=True))
         if s.gbuf is not None:
             C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
@@ -252,6 +255,9 @@ class HourglassEngine:
         # BatchNorm as (scale, shift) applied by the consumers while loading (default), or round 2's in-place normalisation pass
         # (CD_AMD_BN_APPLY=0: kept for A/B measurements on one box)
         self.bn_apply = os.environ.get("CD_AMD_BN_APPLY", "1") != "0"
+        # the k x k weight gradients of a step as one launch per kernel class at the end of the backward pass (CD_AMD_WGRAD_BATCH=0:
+        # one launch per convolution inside the backward walk, round 3's schedule -- same bits, for A/B measurements)
+        self.wgrad_batch = os.environ.get("CD_AMD_WGRAD_BATCH", "1") != "0"
         # nn.BatchNorm2d counts its train-mode forwards (training steps AND the reference's train-mode validation batches);
         # momentum is fixed so nothing reads the counters, but they are part of the checkpoint the reference writes
         self._batch_counters = [m.num_batches_tracked for m in net.modules()
@@ -475,6 +481,15 @@ class HourglassEngine:
                 s0 = sum(2 * u.cout for u in units[:i0])
                 step.bn_sums = plan["sums_arena"][s0:s0 + 2 * step.bn_C]
         unpack = plan["unpack"] = C.UnpackTable(self.device)
+        plan["wgrad_table"] = C.WgradTable(self.device)
+        # (unit -> the buffer / channel offset its backward receives the output gradient in)
+        gbuf_of = {}
+        for step in self._all_steps(plan["steps"]):
+            if step.kind == "conv":
+                gbuf_of[step.unit] = (step.gbuf, step.g_coff)
+            elif step.kind == "inception":
+                for u, gb, gc in step.units:
+                    gbuf_of[u] = (gb, gc)
         N, _, H, W = plan["x"].shape
         for u, n in zip(units, sizes):
             u.wgrad_ws = plan["wgrad_arena"][o:o + n]
@@ -483,6 +498,14 @@ class HourglassEngine:
             so += 2 * u.cout
             h, w = (u.P.shape[2:] if isinstance(u, PointwiseGroup) else u.dst_buf.shape[2:])
             layout = C.wgrad_plan(u.cout, u.cin, u.ks, N, h, w)
+            if self.wgrad_batch and isinstance(u, ConvUnit) and u.ks >= 3 and u in gbuf_of:
+                # Deferred AND batched: the operands -- the producer's raw output with its (scale, shift), and the gradient w.r.t. this
+                # unit's raw output, final once the unit's backward has run -- are buffers of the plan that nothing overwrites before
+                # the end of the backward pass, so the gradient can be computed there, together with all the others of its class.
+                gb, gc = gbuf_of[u]
+                s = u.src
+                u.wgrad_batched = plan["wgrad_table"].add(s.buf, gb, u.cin, u.cout, u.ks, u.wgrad_ws, x_coff=s.coff, dy_coff=gc,
+                                                          in_scale=s.scale, in_shift=s.shift, in_relu=s.relu)
             if isinstance(u, PointwiseGroup):   # the fused gradient's rows belong to the members' weights
                 for m in u.members:
                     unpack.add(u.wgrad_ws, (lambda m=m: _grad_of(m.conv.weight)), u.cin, 1, layout, row0=m.coff, cout_total=u.cout)
@@ -574,7 +597,12 @@ class HourglassEngine:
         if self._wgrad_pending:   # join: the parameter gradients are complete when this returns (stream order)
             torch.cuda.current_stream(self.device).wait_stream(self._wgrad_stream)
             self._wgrad_pending = False
-        plan["unpack"].run()      # every weight gradient (157 tensors) in one launch
+        self._finish_wgrads(plan)
+
+    @staticmethod
+    def _finish_wgrads(plan):
+        plan["wgrad_table"].run()     # the k x k weight gradients of the whole network: one launch per kernel class
+        plan["unpack"].run()          # every weight gradient (157 tensors) written by one launch
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (N,3,H,W) -> pred_d (N,1,H,W) (log depth), attached to autograd when grad is enabled."""
@@ -627,7 +655,7 @@ class BlockRunner:
         for a in self.plan["acts"]:
             a.grad_written = False
         self.eng._run_backward(self.plan["steps"])
-        self.plan["unpack"].run()
+        self.eng._finish_wgrads(self.plan)
         return self.x.gbuf.clone()
 
 

@@ -173,6 +173,75 @@ def wgrad_plan(Cout, Cin, ks, N, H, W):
     return cob.value, cib.value, splits.value
 
 
+class WgradTable:
+    """MANY weight gradients in a handful of launches (cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table): one launch per kernel class
+    (filter size x channel-block shape) for every gradient of a network.  add() registers a gradient in deferred form (the
+    arguments of conv2d_wgrad(dw=None)) and returns False when it is not one the table kernels compute (1x1, the RGB stem, the fp32
+    arithmetic mode): the caller launches that one itself.  All operand tensors are static buffers of a plan, so the device tables
+    are built once (build()); run() enqueues the launches.  Results are bit-identical to one conv2d_wgrad per gradient."""
+
+    _DT = [("x", "<u8"), ("in_scale", "<u8"), ("in_shift", "<u8"), ("dy", "<u8"), ("workspace", "<u8"),
+           ("x_ctot", "<i4"), ("x_coff", "<i4"), ("Cin", "<i4"), ("in_relu", "<i4"), ("dy_ctot", "<i4"), ("dy_coff", "<i4"), ("Cout", "<i4"),
+           ("N", "<i4"), ("H", "<i4"), ("W", "<i4"), ("ks", "<i4"),
+           ("klass", "<i4"), ("splits", "<i4"), ("cigs", "<i4"), ("zpg", "<i4"), ("cogs", "<i4"), ("tiles_x", "<i4"), ("tiles_y", "<i4"),
+           ("blocks", "<i4"), ("block_end", "<i4"), ("pad", "<i4")]
+    MAX_PER_LAUNCH = 64
+
+    def __init__(self, device):
+        import numpy as np
+        self.device, self._descs, self._keep, self._launches = device, [], [], None
+        assert np.dtype(self._DT).itemsize == 128
+
+    def add(self, x, dy, Cin, Cout, ks, workspace, x_coff=0, dy_coff=0, in_scale=None, in_shift=None, in_relu=False) -> bool:
+        import ctypes
+        import numpy as np
+        N, x_ctot, H, W = x.shape
+        d = np.zeros(1, np.dtype(self._DT))
+        opt = lambda t, name: _native.dev_ptr(t, name) if t is not None else 0  # noqa: E731
+        d[0] = (_native.dev_ptr(x, "x"), opt(in_scale, "in_scale"), opt(in_shift, "in_shift"), _native.dev_ptr(dy, "dy"),
+                _native.dev_ptr(workspace, "workspace"), x_ctot, x_coff, Cin, int(in_relu), dy.shape[1], dy_coff, Cout, N, H, W, ks) + (0,) * 10
+        rc = _native.lib().cd_conv2d_wgrad_desc(d.ctypes.data_as(ctypes.c_void_p))
+        _native.check(rc, "cd_conv2d_wgrad_desc")
+        if int(d[0]["klass"]) < 0:
+            return False
+        self._descs.append(d)
+        self._keep += [x, dy, workspace, in_scale, in_shift]      # the table holds raw pointers
+        self._launches = None
+        return True
+
+    def __len__(self):
+        return len(self._descs)
+
+    def build(self):
+        import numpy as np
+        self._launches = []
+        by_class = {}
+        for d in self._descs:
+            by_class.setdefault(int(d[0]["klass"]), []).append(d)
+        for klass, ds in sorted(by_class.items()):
+            # heaviest first: workgroups are dispatched in table order, the long ones must not start last.  Work of one workgroup ~
+            # (image tiles it walks) x taps; ties broken by the registration order (deterministic tables)
+            def weight(d):
+                items = int(d[0]["N"]) * int(d[0]["tiles_x"]) * int(d[0]["tiles_y"])
+                return -((items + int(d[0]["splits"]) - 1) // int(d[0]["splits"])) * int(d[0]["ks"]) ** 2
+            ds = sorted(ds, key=weight)
+            for s0 in range(0, len(ds), self.MAX_PER_LAUNCH):
+                part = np.concatenate(ds[s0:s0 + self.MAX_PER_LAUNCH])
+                part["block_end"] = np.cumsum(part["blocks"])
+                tab = torch.from_numpy(part.view(np.uint8).copy()).to(self.device)
+                self._launches.append((klass, tab, len(part), int(part["block_end"][-1])))
+        return self
+
+    def run(self):
+        if not self._descs:
+            return
+        if self._launches is None:
+            self.build()
+        lib, stream = _native.lib(), _native.stream_ptr(self.device)
+        for klass, tab, n, total in self._launches:
+            _native.check(lib.cd_conv2d_wgrad_table(tab.data_ptr(), n, klass, total, stream), "cd_conv2d_wgrad_table")
+
+
 class UnpackTable:
     """Deferred weight gradients of a whole network written by ONE launch (cd_conv2d_wgrad_unpack_table).
 

@@ -45,7 +45,8 @@ typedef enum cd_depth_mode {
 } cd_depth_mode;
 
 /* ABI version, bumped on any change of an exported signature, of the meaning of an argument, or of the export list
- * (6: cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped added, cd_bn_relu_bwd's last argument became a flags bitfield).
+ * (6: cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped / cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table added, cd_bn_relu_bwd's last
+ * argument became a flags bitfield, cd_debug_set_loss_variant(2) is refused).
  * The loader (consistent_depth_amd/_native.py) refuses a library whose cd_abi_version() differs from this constant. */
 #define CD_ABI_VERSION 6
 int cd_abi_version(void);
@@ -325,6 +326,25 @@ typedef struct cd_unpack_desc {
 } cd_unpack_desc;
 int cd_conv2d_wgrad_plan(int Cout, int Cin, int ks, int N, int H, int W, int* cob, int* cib, int* splits);
 int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream);
+/* MANY weight gradients in ONE launch (the hourglass' 82 k x k gradients of a step: the backward only needs them before the
+ * optimiser, their operands -- the forward activations and the gradient buffers of every inception -- stay valid until the end of
+ * the backward pass, and the deep levels' gradients on their own launch a few dozen short workgroups on an idle chip).
+ *   cd_conv2d_wgrad_desc   fills the derived fields of ONE host descriptor whose first 16 fields (x .. ks: the arguments of
+ *                          cd_conv2d_wgrad in deferred form, `workspace` receiving the packed partial sums exactly as
+ *                          cd_conv2d_wgrad(accumulate = 4) would leave them) the caller has set.  klass = the kernel class
+ *                          (0 .. 4) or -1 when this gradient is not one the table kernels compute (1x1, the RGB stem, arithmetic
+ *                          mode 0): launch it with cd_conv2d_wgrad.  blocks = its workgroups.
+ *   cd_conv2d_wgrad_table  launches the n <= 64 descriptors of ONE class from a DEVICE-resident table; the caller has set
+ *                          block_end of entry i to blocks[0] + .. + blocks[i] and passes the total.  Order the table heaviest
+ *                          first (workgroups are dispatched in table order).  Results are bit-identical to one cd_conv2d_wgrad
+ *                          per descriptor; finish with cd_conv2d_wgrad_unpack_table as usual. */
+typedef struct cd_wgrad_desc {
+    const float* x; const float* in_scale; const float* in_shift; const float* dy; float* workspace;
+    int x_ctot, x_coff, Cin, in_relu, dy_ctot, dy_coff, Cout, N, H, W, ks;
+    int klass, splits, cigs, zpg, cogs, tiles_x, tiles_y, blocks, block_end, pad;
+} cd_wgrad_desc;
+int cd_conv2d_wgrad_desc(cd_wgrad_desc* desc);
+int cd_conv2d_wgrad_table(const void* table_dev, int n, int klass, int total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Data-parallel gradient exchange (reference: nn.DataParallel, monodepth/midas_v2_model.py:41-43 and the batch scaling of

@@ -271,3 +271,43 @@ def test_weight_gradient_with_the_producers_affine(N, Cin, Cout, H, W, ks, mode)
     ref = torch.nn.grad.conv2d_weight(xa.cpu(), (Cout, Cin, ks, ks), dy.double().cpu(), padding=ks // 2)
     err = ((outs[0].double().cpu() - ref).abs().sum() / ref.abs().sum()).item()
     assert err < 2e-6, err
+
+
+def test_weight_gradients_of_many_convolutions_in_one_launch_per_class(arith):
+    """cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table (ops/conv.py::WgradTable): a mixed bag of the hourglass' k x k gradients -- large
+    and tiny images, every kernel class, channel slices of shared buffers, with and without the producer's affine -- computed by one
+    launch per class.  The packed partial sums must be BIT-identical to one cd_conv2d_wgrad per convolution (same workgroups, same
+    tiles, same order), hence so are the unpacked gradients; gradients the table kernels do not cover (1x1, the RGB stem, everything
+    under the fp32 arithmetic) are refused by add() and stay with the caller."""
+    import torch
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shapes = [(8, 32, 64, 24, 14, 3), (8, 32, 64, 24, 14, 5), (8, 32, 64, 24, 14, 7), (8, 64, 64, 48, 28, 11), (8, 64, 32, 96, 56, 3),
+              (4, 64, 16, 96, 64, 11), (4, 64, 16, 96, 64, 7), (4, 32, 32, 48, 40, 5), (2, 64, 1, 40, 48, 3), (2, 48, 40, 20, 36, 7),
+              (4, 128, 64, 24, 40, 1), (2, 3, 128, 24, 40, 7)]
+    table = conv.WgradTable("cuda")
+    jobs = []
+    for i, (N, Cin, Cout, H, W, ks) in enumerate(shapes):
+        X = torch.randn(N, Cin + 8, H, W, device="cuda", generator=g)          # the operands are channel slices of wider buffers
+        DY = torch.randn(N, Cout + 5, H, W, device="cuda", generator=g)
+        sc = torch.rand(Cin, device="cuda", generator=g) + 0.5 if i % 2 == 0 else None
+        sh = torch.randn(Cin, device="cuda", generator=g) * 0.3 if i % 2 == 0 else None
+        ws_a, ws_b = conv.wgrad_workspace(Cout, Cin, ks, "cuda"), conv.wgrad_workspace(Cout, Cin, ks, "cuda")
+        ws_a.fill_(float("nan")); ws_b.fill_(float("nan"))
+        kw = dict(x_coff=8, dy_coff=5, in_scale=sc, in_shift=sh, in_relu=i % 2 == 0)
+        took = table.add(X, DY, Cin, Cout, ks, ws_b, **kw)
+        assert took == (arith != "fp32" and ks >= 3 and Cin >= 8), (shapes[i], took)
+        jobs.append((X, DY, Cin, Cout, ks, ws_a, ws_b, kw, took, (N, H, W)))
+    if arith == "fp32":
+        assert len(table) == 0
+        return
+    table.run()
+    table.run()           # idempotent: every workgroup rewrites its whole slice
+    for X, DY, Cin, Cout, ks, ws_a, ws_b, kw, took, (N, H, W) in jobs:
+        if not took:
+            continue
+        conv.conv2d_wgrad(X, DY, Cin, Cout, ks, None, ws_a, **kw)             # deferred form: packed partial sums in ws_a
+        cob, cib, splits = conv.wgrad_plan(Cout, Cin, ks, N, H, W)
+        used = ((Cout + cob - 1) // cob) * ((Cin + cib - 1) // cib) * ks * ks * cob * cib * splits
+        assert torch.equal(ws_a[:used].view(torch.int32), ws_b[:used].view(torch.int32)), (Cin, Cout, ks, H, W)
+        assert torch.isnan(ws_b[used:]).all()                                   # nothing written beyond the plan's slices

@@ -204,7 +204,7 @@ def test_stale_plan_falls_back_to_the_exact_path(torch_cuda, oracle):
     nbytes = lib.cd_tile_windows_bytes(3, 48, 40)
     blob = CL.tile_windows(d["flows"], d["masks"])          # plans for the default geometry (2 pixels per thread)
     try:
-        for variant, pxt in ((4, 4), (4, 1), (3, 4), (2, 4)):
+        for variant, pxt in ((4, 4), (4, 1), (3, 4)):
             assert lib.cd_debug_set_loss_variant(variant) == 0 and lib.cd_debug_set_loss_sweep(pxt) == 0
             assert lib.cd_tile_windows_bytes(3, 48, 40) == nbytes
             depth = d["depth"].clone().requires_grad_(True)
@@ -212,6 +212,7 @@ def test_stale_plan_falls_back_to_the_exact_path(torch_cuda, oracle):
             total.backward()
             np.testing.assert_allclose(total.item(), ref64["total"][0], rtol=LOSS_RTOL)
             assert oracle.rel_l1(depth.grad.cpu().numpy(), ref64["grad_depth"]) < grad_tol(oracle.rel_l1(ref32["grad_depth"], ref64["grad_depth"]))
+        assert lib.cd_debug_set_loss_variant(2) != 0       # the removed owner-computes variant is refused, not silently remapped
     finally:
         lib.cd_debug_set_loss_sweep(0)
         lib.cd_debug_set_loss_variant(0)
