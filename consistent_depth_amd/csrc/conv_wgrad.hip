@@ -725,7 +725,7 @@ int cd_conv2d_wgrad_desc(cd_wgrad_desc* desc) {
     static_assert(sizeof(cd_wgrad_desc) == sizeof(cd::WgradDesc), "cd_wgrad_desc / WgradDesc");
     if (!desc) return CD_ERR_INVALID_ARG;
     cd::WgradDesc* d = reinterpret_cast<cd::WgradDesc*>(desc);
-    d->klass = -1; d->blocks = 0; d->block_end = 0; d->pad = 0;
+    d->klass = -1; d->blocks = 0; d->block_end = 0; d->pad[0] = d->pad[1] = 0;
     if (!d->x || !d->dy || !d->workspace || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return CD_ERR_INVALID_ARG;
     if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_ctot || d->dy_coff < 0 || d->dy_coff + d->Cout > d->dy_ctot) return CD_ERR_INVALID_ARG;
     if ((d->in_scale == nullptr) != (d->in_shift == nullptr)) return CD_ERR_INVALID_ARG;

@@ -24,7 +24,7 @@ int launch_wgrad_split(const float* x, int x_ctot, int x_coff, int Cin, const fl
 struct WgradDesc {
     const float* x; const float* in_scale; const float* in_shift; const float* dy; float* workspace;
     int x_ctot, x_coff, Cin, in_relu, dy_ctot, dy_coff, Cout, N, H, W, ks;
-    int klass, splits, cigs, zpg, cogs, tiles_x, tiles_y, blocks, block_end, pad;
+    int klass, splits, cigs, zpg, cogs, tiles_x, tiles_y, blocks, block_end, pad[2];
 };
 static_assert(sizeof(WgradDesc) == 128, "cd_wgrad_desc layout");
 int wgrad_split_class(int ks, int cot);

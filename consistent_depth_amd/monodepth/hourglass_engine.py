@@ -255,9 +255,12 @@ class HourglassEngine:
         # BatchNorm as (scale, shift) applied by the consumers while loading (default), or round 2's in-place normalisation pass
         # (CD_AMD_BN_APPLY=0: kept for A/B measurements on one box)
         self.bn_apply = os.environ.get("CD_AMD_BN_APPLY", "1") != "0"
-        # the k x k weight gradients of a step as one launch per kernel class at the end of the backward pass (CD_AMD_WGRAD_BATCH=0:
-        # one launch per convolution inside the backward walk, round 3's schedule -- same bits, for A/B measurements)
-        self.wgrad_batch = os.environ.get("CD_AMD_WGRAD_BATCH", "1") != "0"
+        # CD_AMD_WGRAD_BATCH=1: the k x k weight gradients of a step as one launch per kernel class at the end of the backward pass
+        # (ops/conv.py::WgradTable; bit-identical results).  Measured in round 4 and left OFF: 67 launches become 5, but the kernel
+        # time of a step barely moves (5.21 -> 5.07 ms: the deep levels' gradients are bound by the latency of their few workgroups'
+        # own tile loops, not by idle CUs that other gradients could fill) and the step loses the overlap of the side streams'
+        # gradients with the main chain (170.1 vs 171.5 pairs/s, two runs each; profiles/wgrad_batch_r04.txt).
+        self.wgrad_batch = os.environ.get("CD_AMD_WGRAD_BATCH", "0") == "1"
         # nn.BatchNorm2d counts its train-mode forwards (training steps AND the reference's train-mode validation batches);
         # momentum is fixed so nothing reads the counters, but they are part of the checkpoint the reference writes
         self._batch_counters = [m.num_batches_tracked for m in net.modules()

@@ -184,7 +184,7 @@ class WgradTable:
            ("x_ctot", "<i4"), ("x_coff", "<i4"), ("Cin", "<i4"), ("in_relu", "<i4"), ("dy_ctot", "<i4"), ("dy_coff", "<i4"), ("Cout", "<i4"),
            ("N", "<i4"), ("H", "<i4"), ("W", "<i4"), ("ks", "<i4"),
            ("klass", "<i4"), ("splits", "<i4"), ("cigs", "<i4"), ("zpg", "<i4"), ("cogs", "<i4"), ("tiles_x", "<i4"), ("tiles_y", "<i4"),
-           ("blocks", "<i4"), ("block_end", "<i4"), ("pad", "<i4")]
+           ("blocks", "<i4"), ("block_end", "<i4"), ("pad0", "<i4"), ("pad1", "<i4")]
     MAX_PER_LAUNCH = 64
 
     def __init__(self, device):
@@ -199,7 +199,7 @@ class WgradTable:
         d = np.zeros(1, np.dtype(self._DT))
         opt = lambda t, name: _native.dev_ptr(t, name) if t is not None else 0  # noqa: E731
         d[0] = (_native.dev_ptr(x, "x"), opt(in_scale, "in_scale"), opt(in_shift, "in_shift"), _native.dev_ptr(dy, "dy"),
-                _native.dev_ptr(workspace, "workspace"), x_ctot, x_coff, Cin, int(in_relu), dy.shape[1], dy_coff, Cout, N, H, W, ks) + (0,) * 10
+                _native.dev_ptr(workspace, "workspace"), x_ctot, x_coff, Cin, int(in_relu), dy.shape[1], dy_coff, Cout, N, H, W, ks) + (0,) * 11
         rc = _native.lib().cd_conv2d_wgrad_desc(d.ctypes.data_as(ctypes.c_void_p))
         _native.check(rc, "cd_conv2d_wgrad_desc")
         if int(d[0]["klass"]) < 0:

@@ -341,7 +341,7 @@ int cd_conv2d_wgrad_unpack_table(const void* table_dev, int n, void* stream);
 typedef struct cd_wgrad_desc {
     const float* x; const float* in_scale; const float* in_shift; const float* dy; float* workspace;
     int x_ctot, x_coff, Cin, in_relu, dy_ctot, dy_coff, Cout, N, H, W, ks;
-    int klass, splits, cigs, zpg, cogs, tiles_x, tiles_y, blocks, block_end, pad;
+    int klass, splits, cigs, zpg, cogs, tiles_x, tiles_y, blocks, block_end, pad[2];
 } cd_wgrad_desc;
 int cd_conv2d_wgrad_desc(cd_wgrad_desc* desc);
 int cd_conv2d_wgrad_table(const void* table_dev, int n, int klass, int total_blocks, void* stream);
