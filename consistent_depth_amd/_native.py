@@ -48,6 +48,7 @@ SIGNATURES = {
     "cd_conv2d_fwd_cfg": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_conv2d_packed_co_tiles": (c_i, [c_i, c_i]),
     "cd_conv2d_fwd_grouped": (c_i, [c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_conv2d_fwd_multi": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "cd_conv2d_wgrad_grouped": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "cd_set_conv_arith": (c_i, [c_i]),
     "cd_get_conv_arith": (c_i, []),

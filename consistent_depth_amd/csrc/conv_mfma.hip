@@ -633,6 +633,29 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                              accumulate, N, H, W, ks, 0, 0, stream);
 }
 
+int cd_conv2d_fwd_multi(const cd_conv_desc* d, int n, int tile_rows, int co_tiles, void* stream) {
+    if (!d || n < 1 || n > 4) return CD_ERR_INVALID_ARG;
+    if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16) || !(co_tiles == 0 || co_tiles == 1 || co_tiles == 2)) return CD_ERR_INVALID_ARG;
+    if (cd::g_conv_arith < 1) return CD_ERR_UNSUPPORTED;      // the fp32-instruction kernels have no multi-convolution dispatch
+    cd::SplitConv c[4];
+    for (int i = 0; i < n; ++i) {
+        const cd_conv_desc& e = d[i];
+        if (!e.x || !e.packed_w || !e.y || e.N <= 0 || e.H <= 0 || e.W <= 0 || e.Cin <= 0 || e.Cout <= 0) return CD_ERR_INVALID_ARG;
+        if (e.x_coff < 0 || e.x_coff + e.Cin > e.x_ctot || e.y_coff < 0 || e.y_coff + e.Cout > e.y_ctot) return CD_ERR_INVALID_ARG;
+        if ((e.in_scale == nullptr) != (e.in_shift == nullptr)) return CD_ERR_INVALID_ARG;
+        if (e.N != d[0].N || e.H != d[0].H || e.W != d[0].W || e.Cout != d[0].Cout) return CD_ERR_INVALID_ARG;   // one launch shape
+        if (!cd::split_supported(e.ks) || e.Cin < 8 || e.Cout <= 16) return CD_ERR_UNSUPPORTED;
+        c[i].x = e.x; c[i].wsplit = e.packed_w + cd::fp32_packed_floats(e.Cout, e.Cin, e.ks); c[i].bias = e.bias; c[i].in_scale = e.in_scale;
+        c[i].in_shift = e.in_shift; c[i].y = e.y; c[i].stats = e.stats; c[i].x_ctot = e.x_ctot; c[i].x_coff = e.x_coff; c[i].Cin = e.Cin;
+        c[i].in_relu = e.in_relu; c[i].y_ctot = e.y_ctot; c[i].y_coff = e.y_coff; c[i].accumulate = e.accumulate; c[i].ks = e.ks;
+    }
+    int sty = cd::g_force_conv_ty ? cd::g_force_conv_ty : tile_rows, scot = cd::g_force_conv_cot ? cd::g_force_conv_cot : co_tiles;
+    const bool small = (long long)d[0].N * d[0].H * d[0].W <= 8LL * 96 * 56;      // (the unhinted rule of cd_conv2d_fwd_cfg)
+    if (scot == 0) scot = small ? 1 : 2;
+    if (sty == 0) sty = (small || cd::split_column_tiles(d[0].Cout) >= 2) ? 16 : 8;
+    return cd::launch_conv_split_multi(c, n, d[0].N, d[0].H, d[0].W, d[0].Cout, sty, scot, (hipStream_t)stream);
+}
+
 int cd_conv2d_fwd_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* packed_w, size_t packed_group_stride,
                           const float* bias, float* y, int y_ctot, int y_coff, int cout_g, int groups, int accumulate, int N, int H, int W,
                           int ks, void* stream) {

@@ -61,4 +61,11 @@ int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const flo
                       const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
                       int H, int W, int ks, int ty, int cot, hipStream_t s, const ConvGroups& grp = ConvGroups());
 
+// Several convolutions of one launch shape in ONE dispatch (cd_conv2d_fwd_multi): the members of `c` share N, H, W and Cout.
+struct SplitConv {
+    const float* x; const float* wsplit; const float* bias; const float* in_scale; const float* in_shift; float* y; double* stats;
+    int x_ctot, x_coff, Cin, in_relu, y_ctot, y_coff, accumulate, ks;
+};
+int launch_conv_split_multi(const SplitConv* c, int n, int N, int H, int W, int Cout, int ty, int cot, hipStream_t s);
+
 }  // namespace cd

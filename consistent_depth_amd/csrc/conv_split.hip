@@ -139,21 +139,31 @@ int launch_pack_split_table(const void* table_dev, int n, hipStream_t s) {
 // stores it.  The order of accumulation depends on nothing but (Cin, KS, DY): every launch shape gives the same bits.
 constexpr size_t SPLIT_REDUCE_LDS = 4 * 3 * 4096;   // one round of the cross-wave reduction: 4 owners x 3 foreign partials x 4 KB
 
+// One convolution as the kernels see it (the arguments of a stand-alone launch).
+struct SplitArgs {
+    const float* x; const u32x4* wsp; const float* bias; const float* in_scale; const float* in_shift; float* y; double* stats;
+    int x_ctot, x_coff, Cin, pack_tiles, in_relu, y_ctot, y_coff, Cout, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk_tiles, slices;
+    ConvGroups grp;
+};
+
+// The work of block (bx, by) of the stand-alone grid (chunk_tiles * 8 * slices, groups).
 template <int KS, int NT, int TYP, int DY, int CGS>
-__global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
-    const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
-    const u32x4* __restrict__ wsp, int pack_tiles, const float* __restrict__ bias,
-    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
-    float* __restrict__ y, int y_ctot, int y_coff, int Cout,
-    double* __restrict__ stats, int accumulate, int H, int W, int tiles_x, int tiles_img, int tiles_total, int chunk_tiles,
-    int slices, const ConvGroups grp) {
+__device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const int bx, const int by) {
+    const float* __restrict__ x = a.x; const u32x4* __restrict__ wsp = a.wsp; const float* __restrict__ bias = a.bias;
+    const float* __restrict__ in_scale = a.in_scale; const float* __restrict__ in_shift = a.in_shift; float* __restrict__ y = a.y;
+    double* __restrict__ stats = a.stats;
+    int x_coff = a.x_coff, y_coff = a.y_coff;
+    const int x_ctot = a.x_ctot, Cin = a.Cin, pack_tiles = a.pack_tiles, in_relu = a.in_relu, y_ctot = a.y_ctot, Cout = a.Cout;
+    const int accumulate = a.accumulate, H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_img = a.tiles_img, tiles_total = a.tiles_total;
+    const int chunk_tiles = a.chunk_tiles, slices = a.slices;
+    const ConvGroups grp = a.grp;
     using Cfg = SplitCfg<KS, TYP, DY>;
     // grouped convolution (ResNeXt's 32 x 8d 3x3): blockIdx.y = the group, a dense convolution on its channel slices with its
     // own packed filter; dense launches have one group and zero strides
-    x_coff += (int)blockIdx.y * grp.x_stride;
-    y_coff += (int)blockIdx.y * grp.y_stride;
-    wsp += (size_t)blockIdx.y * grp.w_stride;
-    if (bias != nullptr) bias += (int)blockIdx.y * grp.y_stride;
+    x_coff += by * grp.x_stride;
+    y_coff += by * grp.y_stride;
+    wsp += (size_t)by * grp.w_stride;
+    if (bias != nullptr) bias += by * grp.y_stride;
     constexpr int TY = Cfg::TY, ROWS = Cfg::ROWS, RSP = Cfg::RSP, COFF = Cfg::COFF, PADL = Cfg::PADL, PLANE = Cfg::PLANE;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, KSTEPS = Cfg::KSTEPS;
     constexpr int MB = TY / DY;                       // M-tiles (tile rows, DY output rows each) per block
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     u32x4* s_in = reinterpret_cast<u32x4*>(smem_raw);   // [3][ROWS][RSP] 16-byte slots (8 bf16 channels of one pixel)
 
     // XCD-aware block -> (image tile, channel slice) mapping (see conv_mfma.hip)
-    const int xcd = blockIdx.x & 7, kx_ = blockIdx.x >> 3;
+    const int xcd = bx & 7, kx_ = bx >> 3;
     const int tg = kx_ / slices, slice = kx_ - tg * slices;
     const int t_lin = xcd * chunk_tiles + tg;
     if (tg >= chunk_tiles || t_lin >= tiles_total) return;   // block-uniform
@@ -461,6 +471,32 @@ __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(
     }
 }
 
+template <int KS, int NT, int TYP, int DY, int CGS>
+__global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(const SplitArgs a) {
+    conv_fwd_split_block<KS, NT, TYP, DY, CGS>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// SEVERAL convolutions of one launch shape in ONE dispatch: blockIdx.y = the convolution (the three k x k branches of an inception:
+// same image, same output channels, different filter sizes and input slices), blockIdx.x its stand-alone grid.  Kernels from
+// different streams or graph branches do not share the chip on this stack (profiles/branch_overlap_r04.txt); workgroups of one
+// dispatch do -- and at 96x56 and below a single branch launches fewer workgroups than the chip has CUs, each a latency chain of
+// channel-chunk rounds.  Every workgroup does exactly what it does in its own launch: same bits.  The caller orders the branches
+// largest filter first (workgroups are dispatched y-major: the long ones must not start last).
+constexpr int kSplitMultiMax = 4;
+struct SplitMulti { SplitArgs b[kSplitMultiMax]; int ks[kSplitMultiMax]; };
+
+template <int NT, int TYP, int DY, int CGS>
+__global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_multi_kernel(const SplitMulti m) {
+    const int br = (int)blockIdx.y;
+    const SplitArgs& a = m.b[br];
+    switch (m.ks[br]) {     // block-uniform
+        case 3: conv_fwd_split_block<3, NT, TYP, DY, CGS>(a, (int)blockIdx.x, 0); break;
+        case 5: conv_fwd_split_block<5, NT, TYP, DY, CGS>(a, (int)blockIdx.x, 0); break;
+        case 7: conv_fwd_split_block<7, NT, TYP, DY, CGS>(a, (int)blockIdx.x, 0); break;
+        default: conv_fwd_split_block<11, NT, TYP, DY, CGS>(a, (int)blockIdx.x, 0); break;
+    }
+}
+
 template <int KS, int NT, int TYP, int DY, int CGS = 1>
 static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                           const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
@@ -476,10 +512,56 @@ static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const
     if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
     const int pack_tiles = split_ntiles(Cout), slices = (pack_tiles + NT - 1) / NT;
     const int tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * N, chunk_tiles = (tiles_total + 7) / 8;
-    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY, CGS>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices, (unsigned)grp.n), dim3(kBlock), lds, s, x, x_ctot,
-                       x_coff, Cin, reinterpret_cast<const u32x4*>(wsplit), pack_tiles, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff,
-                       Cout, stats, accumulate, H, W, tiles_x, tiles_img, tiles_total, chunk_tiles, slices, grp);
+    SplitArgs a;
+    a.x = x; a.wsp = reinterpret_cast<const u32x4*>(wsplit); a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.y = y; a.stats = stats;
+    a.x_ctot = x_ctot; a.x_coff = x_coff; a.Cin = Cin; a.pack_tiles = pack_tiles; a.in_relu = in_relu; a.y_ctot = y_ctot; a.y_coff = y_coff;
+    a.Cout = Cout; a.accumulate = accumulate; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_img = tiles_img; a.tiles_total = tiles_total;
+    a.chunk_tiles = chunk_tiles; a.slices = slices; a.grp = grp;
+    hipLaunchKernelGGL((conv_fwd_split_kernel<KS, NT, TYP, DY, CGS>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices, (unsigned)grp.n), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+template <int NT, int TYP, int DY, int CGS>
+static int launch_split_multi_t(const SplitConv* c, int n, int N, int H, int W, int Cout, hipStream_t s) {
+    const int tiles_x = (W + SP_TX - 1) / SP_TX, tiles_y = (H + TYP - 1) / TYP;
+    const int pack_tiles = split_ntiles(Cout), slices = (pack_tiles + NT - 1) / NT;
+    const int tiles_img = tiles_x * tiles_y, tiles_total = tiles_img * N, chunk_tiles = (tiles_total + 7) / 8;
+    SplitMulti m;
+    size_t lds = SPLIT_REDUCE_LDS;
+    for (int i = 0; i < n; ++i) {
+        SplitArgs& a = m.b[i];
+        a.x = c[i].x; a.wsp = reinterpret_cast<const u32x4*>(c[i].wsplit); a.bias = c[i].bias; a.in_scale = c[i].in_scale; a.in_shift = c[i].in_shift;
+        a.y = c[i].y; a.stats = c[i].stats;
+        a.x_ctot = c[i].x_ctot; a.x_coff = c[i].x_coff; a.Cin = c[i].Cin; a.pack_tiles = pack_tiles; a.in_relu = c[i].in_relu; a.y_ctot = c[i].y_ctot;
+        a.y_coff = c[i].y_coff; a.Cout = Cout; a.accumulate = c[i].accumulate; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_img = tiles_img;
+        a.tiles_total = tiles_total; a.chunk_tiles = chunk_tiles; a.slices = slices; a.grp = ConvGroups();
+        m.ks[i] = c[i].ks;
+        const int ks = c[i].ks;
+        const size_t need = (size_t)CGS * 3 * (TYP + ks - 1) * (SP_TX + 2 * ((((ks - 1) / 2) + 3) & ~3)) * 16;   // = CGS * SplitCfg<ks, TYP, DY>::LDS
+        if (need > lds) lds = need;
+    }
+    for (int i = n; i < kSplitMultiMax; ++i) { m.b[i] = m.b[0]; m.ks[i] = m.ks[0]; }
+    if (lds > 160 * 1024) return CD_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_split_multi_kernel<NT, TYP, DY, CGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_fwd_split_multi_kernel<NT, TYP, DY, CGS>), dim3((unsigned)chunk_tiles * 8u * (unsigned)slices, (unsigned)n), dim3(kBlock), lds, s, m);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+// n <= 4 convolutions with the SAME N, H, W, Cout (> 16) and filter sizes in {3, 5, 7, 11}; (ty, cot) as launch_conv_split.
+int launch_conv_split_multi(const SplitConv* c, int n, int N, int H, int W, int Cout, int ty, int cot, hipStream_t s) {
+    if (n < 1 || n > kSplitMultiMax || split_dy(Cout) != 1) return CD_ERR_UNSUPPORTED;
+    for (int i = 0; i < n; ++i)
+        if (!split_supported(c[i].ks)) return CD_ERR_UNSUPPORTED;
+    const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
+    const bool two = ty >= 16;
+    const int mb = (nt == 2 || ty <= 4 || two) ? 4 : 8;
+    if (nt == 2) return two ? launch_split_multi_t<2, 4, 1, 2>(c, n, N, H, W, Cout, s) : launch_split_multi_t<2, 4, 1, 1>(c, n, N, H, W, Cout, s);
+    if (mb == 8) return launch_split_multi_t<1, 8, 1, 1>(c, n, N, H, W, Cout, s);
+    return two ? launch_split_multi_t<1, 4, 1, 2>(c, n, N, H, W, Cout, s) : launch_split_multi_t<1, 4, 1, 1>(c, n, N, H, W, Cout, s);
 }
 
 int split_column_tiles(int OC) { return split_ntiles(OC); }

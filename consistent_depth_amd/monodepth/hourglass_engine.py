@@ -94,6 +94,7 @@ class ConvUnit:
         self.wgrad_batched = False        # True: this unit's weight gradient is part of the plan's WgradTable (one launch per kernel
                                           # class at the end of the backward pass) -- backward() does not launch it
         self.bn_fused = False             # True: the owning inception runs the BN passes of its three branch outputs jointly
+        self.dgrad_merged = False         # True: the owning inception computes this unit's input gradient in ONE dispatch with its siblings
         self.pk, self.pkT = eng.packed(conv_mod)
         # launch shapes, timed once per distinct convolution shape (ops/conv.py::tuned_config)
         N, _, H, W = dst_buf.shape
@@ -101,6 +102,18 @@ class ConvUnit:
                                     relu_in=src.relu, stats=bn_mod is not None, x_ctot=src.buf.shape[1], y_ctot=dst_buf.shape[1])
         self.cfg_d = C.tuned_config(self.ks, self.cout, self.cin, N, H, W, dst_buf.device, accumulate=True,
                                     x_ctot=dst_buf.shape[1], y_ctot=src.buf.shape[1])
+
+    def fwd_member(self, training):
+        """This unit's forward convolution as a member of a merged dispatch (ops/conv.py::conv2d_multi)."""
+        s = self.src
+        return dict(x=s.buf, packed_w=self.pk, Cin=self.cin, Cout=self.cout, ks=self.ks, bias=self.conv.bias, x_coff=s.coff, out=self.dst_buf,
+                    y_coff=self.dst_coff, in_scale=s.scale, in_shift=s.shift, in_relu=s.relu,
+                    stats=self.stats.view(-1) if (self.bn is not None and training) else None)
+
+    def dgrad_member(self, gbuf, g_coff, accumulate):
+        s = self.src
+        return dict(x=gbuf, packed_w=self.pkT, Cin=self.cout, Cout=self.cin, ks=self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
+                    accumulate=accumulate)
 
     def forward(self, training):
         s = self.src
@@ -132,7 +145,7 @@ class ConvUnit:
             self.eng.on_wgrad_stream(lambda: C.conv2d_wgrad(
                 s.buf, gbuf, self.cin, self.cout, self.ks, None, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,
                 in_shift=s.shift, in_relu=s.relu, prezeroed=True))
-        if s.gbuf is not None:
+        if s.gbuf is not None and not self.dgrad_merged:
             C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
 
@@ -402,8 +415,18 @@ class HourglassEngine:
             moff += mids[i]
         out = Act(P, M, Co, relu=True, scale=sl(sc, M, Co), shift=sl(sh, M, Co), needs_grad=False)
         out.gbuf = Pg
+        # ONE dispatch for the three k x k branches (largest filter first), forward and input gradient, where it is timed faster than
+        # their own launches (ops/conv.py::tuned_multi; same bits either way): a single branch at 96x56 and below launches fewer
+        # workgroups than the chip has CUs, and kernels of different streams do not share it (profiles/branch_overlap_r04.txt)
+        order = sorted(range(len(units)), key=lambda i: -units[i][0].ks)
+        us = [units[i] for i in order]
+        multi_f = C.tuned_multi([u.fwd_member(True) for u, _, _ in us], [u.cfg_f for u, _, _ in us])
+        multi_d = C.tuned_multi([u.dgrad_member(g, o, False) for u, g, o in us], [u.cfg_d for u, _, _ in us])
+        if multi_d is not None:
+            for u, _, _ in units:
+                u.dgrad_merged = True
         steps.append(_Node("inception", group=group, units=units, out=out, src=x, P=P, Pg=Pg, stats=stats, mi=mi, bn_scale=sc, bn_shift=sh,
-                           bn_coff=M + a0, bn_C=sum(outs[1:]), bn_running=run_out, bn_sums=None))
+                           bn_coff=M + a0, bn_C=sum(outs[1:]), bn_running=run_out, bn_sums=None, merged=us, multi_f=multi_f, multi_d=multi_d))
         plan["convs"] += [group] + [u for u, _, _ in units]
         return out
 
@@ -537,7 +560,11 @@ class HourglassEngine:
                 step.unit.forward(training)
             elif step.kind == "inception":
                 step.group.forward(training)
-                self._fork_join([(lambda u=u: u.forward(training)) for u, _, _ in step.units])
+                if step.multi_f is not None:
+                    if not C.conv2d_multi([u.fwd_member(training) for u, _, _ in step.merged], step.multi_f):
+                        raise RuntimeError("merged branch dispatch refused after it was timed")
+                else:
+                    self._fork_join([(lambda u=u: u.forward(training)) for u, _, _ in step.units])
                 self.bn_forward(step.P, step.bn_coff, step.bn_C, step.stats, step.mi, step.bn_running, training, step.bn_scale, step.bn_shift)   # [o1|o2|o3]
             elif step.kind == "pool":
                 s = step.src
@@ -561,6 +588,9 @@ class HourglassEngine:
                 L.bn_relu_bwd(step.Pg, step.bn_coff, step.P, step.bn_coff, step.bn_C, step.mi, step.bn_sums, sums_prezeroed=True,
                               scale=step.bn_scale, shift=step.bn_shift)
                 self._fork_join([(lambda u=u, g=gbuf, o=g_coff: u.backward(g, o)) for u, gbuf, g_coff in step.units])
+                if step.multi_d is not None:     # the three input gradients (each the only writer of its mid activation's gradient)
+                    if not C.conv2d_multi([u.dgrad_member(g, o, u.src.grad_mode()) for u, g, o in step.merged], step.multi_d):
+                        raise RuntimeError("merged branch dispatch refused after it was timed")
                 step.group.backward()
             elif step.kind == "pool":
                 s = step.src

@@ -84,7 +84,7 @@ def _save_tune_cache():
     tmp = f"{path}.{os.getpid()}.tmp"
     try:
         with open(tmp, "w") as f:
-            json.dump({json.dumps([int(x) if not isinstance(x, bool) else bool(x) for x in k]): v for k, v in _TUNED.items()}, f)
+            json.dump({json.dumps([x if isinstance(x, str) else (bool(x) if isinstance(x, bool) else int(x)) for x in k]): v for k, v in _TUNED.items()}, f)
         os.replace(tmp, path)
     except OSError:
         pass
@@ -134,6 +134,89 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
                 e1.synchronize()
                 t = min(t, e0.elapsed_time(e1))
             if t < best_t:
+                best, best_t = (ty, cot), t
+    _TUNED[key] = best
+    _save_tune_cache()
+    return best
+
+
+_CONV_DESC_DT = [("x", "<u8"), ("packed_w", "<u8"), ("bias", "<u8"), ("in_scale", "<u8"), ("in_shift", "<u8"), ("y", "<u8"), ("stats", "<u8"),
+                 ("x_ctot", "<i4"), ("x_coff", "<i4"), ("Cin", "<i4"), ("in_relu", "<i4"), ("y_ctot", "<i4"), ("y_coff", "<i4"), ("Cout", "<i4"),
+                 ("accumulate", "<i4"), ("N", "<i4"), ("H", "<i4"), ("W", "<i4"), ("ks", "<i4")]
+
+
+def conv2d_multi(members, cfg=None) -> bool:
+    """SEVERAL convolutions of one launch shape in ONE dispatch (cd_conv2d_fwd_multi): `members` = up to 4 dicts with the arguments of
+    conv2d (x, packed_w, Cin, Cout, ks, bias, x_coff, out, y_coff, in_scale, in_shift, in_relu, stats, accumulate), same N, H, W and
+    Cout, largest filter first.  Returns False -- nothing launched -- when the library has no such dispatch for them (Cout <= 16,
+    the fp32 arithmetic mode): the caller then launches the members one by one.  Same bits either way."""
+    import ctypes
+    import numpy as np
+    tab = np.zeros(len(members), np.dtype(_CONV_DESC_DT))
+    opt = lambda t, name: _native.dev_ptr(t, name) if t is not None else 0  # noqa: E731
+    dev = None
+    for i, m in enumerate(members):
+        x, out = m["x"], m["out"]
+        N, x_ctot, H, W = x.shape
+        st = m.get("stats")
+        if st is not None:
+            assert st.dtype == torch.float64 and st.is_cuda and st.is_contiguous() and st.numel() == _native.BN_STAT_SLOTS * 2 * out.shape[1]
+        tab[i] = (_native.dev_ptr(x, "x"), _native.dev_ptr(m["packed_w"], "packed_w"), opt(m.get("bias"), "bias"), opt(m.get("in_scale"), "in_scale"),
+                  opt(m.get("in_shift"), "in_shift"), _native.dev_ptr(out, "out"), st.data_ptr() if st is not None else 0,
+                  x_ctot, m.get("x_coff", 0), m["Cin"], int(bool(m.get("in_relu", False))), out.shape[1], m.get("y_coff", 0), m["Cout"],
+                  int(bool(m.get("accumulate", False))), N, H, W, m["ks"])
+        dev = x.device
+    ty, cot = cfg if cfg is not None else (0, 0)
+    rc = _native.lib().cd_conv2d_fwd_multi(tab.ctypes.data_as(ctypes.c_void_p), len(members), ty, cot, _native.stream_ptr(dev))
+    if rc == -4:      # CD_ERR_UNSUPPORTED
+        return False
+    _native.check(rc, "cd_conv2d_fwd_multi")
+    return True
+
+
+def tuned_multi(members, single_cfgs, iters=3):
+    """Is ONE dispatch of `members` (conv2d_multi) faster than their own launches with their timed shapes `single_cfgs`, and with
+    which shared launch shape?  Timed once per distinct (shapes, fusion flags) on the members' own buffers with HIP events -- the
+    results do not depend on the choice -- and cached for the life of the process.  Returns the (tile_rows, co_tiles) of the
+    fastest merged launch, or None: launch them one by one."""
+    if not autotune_enabled() or os.environ.get("CD_AMD_CONV_MULTI", "1") == "0":
+        return None
+    _load_tune_cache()
+    arith = _native.lib().cd_get_conv_arith()
+    x0 = members[0]["x"]
+    N, _, H, W = x0.shape
+    key = ("multi", N, H, W, arith) + tuple(v for m in members for v in (m["ks"], m["Cin"], m["Cout"], m["x"].shape[1], m["out"].shape[1],
+                                                                         int(m.get("in_scale") is not None), int(bool(m.get("in_relu", False))),
+                                                                         int(m.get("stats") is not None), int(bool(m.get("accumulate", False)))))
+    if key in _TUNED:
+        return _TUNED[key]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn):
+        fn()
+        t = float("inf")
+        for _ in range(2):
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            t = min(t, e0.elapsed_time(e1))
+        return t
+
+    def singles():
+        for m, cfg in zip(members, single_cfgs):
+            conv2d(m["x"], m["packed_w"], m["Cin"], m["Cout"], m["ks"], bias=m.get("bias"), x_coff=m.get("x_coff", 0), out=m["out"],
+                   y_coff=m.get("y_coff", 0), in_scale=m.get("in_scale"), in_shift=m.get("in_shift"), in_relu=m.get("in_relu", False),
+                   stats=m.get("stats"), accumulate=m.get("accumulate", False), cfg=cfg)
+    best, best_t = None, timed(singles)
+    for ty in (4, 8, 16):
+        for cot in (1, 2):
+            if not conv2d_multi(members, (ty, cot)):
+                _TUNED[key] = None
+                return None
+            t = timed(lambda: conv2d_multi(members, (ty, cot)))
+            if t < 0.97 * best_t and (best is None or t < best_t):      # (a merged launch must clearly win)
                 best, best_t = (ty, cot), t
     _TUNED[key] = best
     _save_tune_cache()

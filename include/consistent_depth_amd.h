@@ -45,7 +45,8 @@ typedef enum cd_depth_mode {
 } cd_depth_mode;
 
 /* ABI version, bumped on any change of an exported signature, of the meaning of an argument, or of the export list
- * (6: cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped / cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table added, cd_bn_relu_bwd's last
+ * (6: cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped / cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table /
+ * cd_conv2d_fwd_multi added, cd_bn_relu_bwd's last
  * argument became a flags bitfield, cd_debug_set_loss_variant(2) is refused).
  * The loader (consistent_depth_amd/_native.py) refuses a library whose cd_abi_version() differs from this constant. */
 #define CD_ABI_VERSION 6
@@ -260,6 +261,18 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
 int cd_conv2d_fwd_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* packed_w, size_t packed_group_stride,
                           const float* bias, float* y, int y_ctot, int y_coff, int cout_g, int groups, int accumulate, int N, int H, int W,
                           int ks, void* stream);
+/* SEVERAL convolutions in ONE dispatch: the n <= 4 members share N, H, W and Cout (> 16), have filter sizes in {3, 5, 7, 11} and
+ * >= 8 input channels each -- the three k x k branches of an inception (monodepth/mannequin_challenge), forward
+ * (inputs: the mid activations with their BatchNorm (scale, shift), outputs: the branch slices of the concat buffer) or input
+ * gradient (transposed packs, roles swapped).  Fields as the arguments of cd_conv2d_fwd_cfg; tile_rows / co_tiles: the launch shape
+ * hints, shared by the members.  Every workgroup does what it does in the member's own cd_conv2d_fwd_cfg launch with the same hints:
+ * identical bits.  Order the members largest filter first.  CD_ERR_UNSUPPORTED (nothing launched): arithmetic mode 0, Cout <= 16, a
+ * member the split kernels do not take -- launch the members one by one. */
+typedef struct cd_conv_desc {
+    const float* x; const float* packed_w; const float* bias; const float* in_scale; const float* in_shift; float* y; double* stats;
+    int x_ctot, x_coff, Cin, in_relu, y_ctot, y_coff, Cout, accumulate, N, H, W, ks;
+} cd_conv_desc;
+int cd_conv2d_fwd_multi(const cd_conv_desc* descs, int n, int tile_rows, int co_tiles, void* stream);
 /* dw [groups*cout_g][cin_g][ks][ks] (+)= the weight gradient of the grouped convolution; workspace: groups * workspace_group_stride
  * floats, workspace_group_stride >= cd_conv2d_wgrad_workspace_floats(cout_g, cin_g, ks). */
 int cd_conv2d_wgrad_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* dy, int dy_ctot, int dy_coff, int cout_g,

@@ -311,3 +311,59 @@ def test_weight_gradients_of_many_convolutions_in_one_launch_per_class(arith):
         used = ((Cout + cob - 1) // cob) * ((Cin + cib - 1) // cib) * ks * ks * cob * cib * splits
         assert torch.equal(ws_a[:used].view(torch.int32), ws_b[:used].view(torch.int32)), (Cin, Cout, ks, H, W)
         assert torch.isnan(ws_b[used:]).all()                                   # nothing written beyond the plan's slices
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,kss", [(8, 24, 14, 32, 64, (7, 5, 3)), (8, 48, 28, 64, 64, (11, 7, 3)), (4, 96, 56, 32, 32, (7, 5, 3)),
+                                                 (2, 40, 72, 64, 32, (11, 7, 3)), (2, 33, 47, 24, 40, (5, 3))])
+@pytest.mark.parametrize("cfg", [(4, 1), (8, 1), (16, 1), (4, 2), (16, 2)])
+def test_branches_of_an_inception_in_one_dispatch(arith, N, H, W, cin, cout, kss, cfg):
+    """cd_conv2d_fwd_multi: the k x k branches of an inception (different filter sizes, different input slices of ONE buffer, adjacent
+    output slices, producer's BatchNorm applied on load, batch statistics in the epilogue) in one dispatch vs one launch each -- outputs
+    and statistics bit for bit, for every shared launch shape; and the input-gradient form (transposed packs, accumulate)."""
+    import torch
+    from consistent_depth_amd import _native
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator(device="cuda").manual_seed(11)
+    nb = len(kss)
+    P = torch.randn(N, nb * cin + nb * cout, H, W, device="cuda", generator=g)
+    sc, sh = torch.rand(nb * cin, device="cuda", generator=g) + 0.5, torch.randn(nb * cin, device="cuda", generator=g) * 0.2
+    ws = [torch.randn(cout, cin, k, k, device="cuda", generator=g) * 0.05 for k in kss]
+    bs = [torch.randn(cout, device="cuda", generator=g) for _ in kss]
+
+    def members(out, stats):
+        return [dict(x=P, packed_w=conv.pack_weights(w), Cin=cin, Cout=cout, ks=k, bias=b, x_coff=i * cin, out=out, y_coff=nb * cin + i * cout,
+                     in_scale=sc[i * cin:(i + 1) * cin], in_shift=sh[i * cin:(i + 1) * cin], in_relu=True, stats=stats)
+                for i, (k, w, b) in enumerate(zip(kss, ws, bs))]
+    outs, stats = [], []
+    for merged in (False, True):
+        out = torch.zeros_like(P)
+        st = torch.zeros(_native.BN_STAT_SLOTS, P.shape[1], 2, dtype=torch.float64, device="cuda")
+        ms = members(out, st.view(-1))
+        if merged:
+            took = conv.conv2d_multi(ms, cfg)
+            assert took == (arith != "fp32")
+            if not took:
+                return
+        else:
+            for m in ms:
+                conv.conv2d(m["x"], m["packed_w"], cin, cout, m["ks"], bias=m["bias"], x_coff=m["x_coff"], out=out, y_coff=m["y_coff"],
+                            in_scale=m["in_scale"], in_shift=m["in_shift"], in_relu=True, stats=m["stats"], cfg=cfg)
+        outs.append(out)
+        stats.append(st)
+    assert torch.equal(outs[0], outs[1])
+    # (the statistics are fp64 atomics into 16 slots: sums of the same per-workgroup partials in a run-dependent order)
+    assert torch.allclose(stats[0].sum(0), stats[1].sum(0), rtol=1e-12, atol=1e-9)
+    # input gradient: dY = the branch outputs' slices -> the mid slices, accumulated on top of what is there
+    base = torch.randn(N, P.shape[1], H, W, device="cuda", generator=g)
+    res = []
+    for merged in (False, True):
+        dst = base.clone()
+        ms = [dict(x=outs[0], packed_w=conv.pack_weights(w, transposed=True), Cin=cout, Cout=cin, ks=k, x_coff=nb * cin + i * cout, out=dst, y_coff=i * cin,
+                   accumulate=True) for i, (k, w) in enumerate(zip(kss, ws))]
+        if merged:
+            assert conv.conv2d_multi(ms, cfg)
+        else:
+            for m in ms:
+                conv.conv2d(m["x"], m["packed_w"], cout, cin, m["ks"], x_coff=m["x_coff"], out=dst, y_coff=m["y_coff"], accumulate=True, cfg=cfg)
+        res.append(dst)
+    assert torch.equal(res[0], res[1])
