@@ -155,7 +155,8 @@ def stage_snapshot(dst):
         print(f"product epoch {e} mean", prod[f"val_e{e}_mean"].tolist())
 
 
-def stage_golden(src):
+def _cpu_run(src, dtype):
+    """oracle/cpu_loop.py continued from the snapshot in `src` for T epochs in `dtype`; returns (artefacts, snapshot checksums, extras)."""
     import make_synthetic_dataset as msd
     from consistent_depth_amd.loaders.video_dataset import VideoDataset, load_color
     from oracle import cpu_loop
@@ -177,21 +178,32 @@ def stage_golden(src):
     ds_idx = {tuple(int(v) for v in pr): i for i, pr in enumerate(ds.flow_indices)}
     plans = {e: [[ds_idx[tuple(pr)] for pr in batch] for batch in p] for e, p in plans.items()}
     out = os.path.join(work, "cpu")
-    lp = cpu_loop.CpuLoop(ds, snap["state"], out, dtype=torch.float64)
+    lp = cpu_loop.CpuLoop(ds, snap["state"], out, dtype=dtype)
     lp.ft.set_adam_state(snap["m1"], snap["m2"], snap["k"])
     lp.total_iters = K * len(ds)
     lp.fine_tune(T, lambda e: plans[K + e], start_epoch=K)
     lp.save_depth(out, list(range(CLIP["n_frames"])), lambda f: load_color(ds.color_fmt.format(f)))
     res = collect(out, len(ds))
-    res.update({"clip": np.array([CLIP["n_frames"], CLIP["H"], CLIP["W"], CLIP["seed"]]), "K": np.array(K), "T": np.array(T),
-                "k_steps": np.array(snap["k"]), "plans": z["plans"], "px_stride": np.array(PX_STRIDE), "ckpt_stride": np.array(CKPT_STRIDE),
-                "pair_order": np.array([list(p) for p in ds.flow_indices], np.int64),
-                "step_losses": np.array([l for _, _, l in lp.step_losses], np.float64)})
-    for name, v in cs.items():
-        res["checksum_" + name] = v
+    extras = {"clip": np.array([CLIP["n_frames"], CLIP["H"], CLIP["W"], CLIP["seed"]]), "K": np.array(K), "T": np.array(T),
+              "k_steps": np.array(snap["k"]), "plans": z["plans"], "px_stride": np.array(PX_STRIDE), "ckpt_stride": np.array(CKPT_STRIDE),
+              "pair_order": np.array([list(p) for p in ds.flow_indices], np.int64),
+              "step_losses": np.array([l for _, _, l in lp.step_losses], np.float64)}
     for k in list(res):
         if res[k].dtype == np.float64 and res[k].size > 4096:
             res[k] = res[k].astype(np.float32)       # maps and the checkpoint sample: the artefacts themselves are fp32 files
+    return res, cs, extras
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).sum() / max(np.abs(b).sum(), 1e-300))
+
+
+def stage_golden(src):
+    res, cs, extras = _cpu_run(src, torch.float64)
+    res.update(extras)
+    for name, v in cs.items():
+        res["checksum_" + name] = v
     np.savez_compressed(GOLDEN, **res)
     print("wrote", GOLDEN, os.path.getsize(GOLDEN) / 1e6, "MB")
     for e in range(K + 1, K + T + 1):
@@ -200,9 +212,23 @@ def stage_golden(src):
     if os.path.exists(small):
         p = np.load(small)
         for e in range(K + 1, K + T + 1):
-            m = np.abs(p[f"val_e{e}_mean"] - res[f"val_e{e}_mean"]).sum() / np.abs(res[f"val_e{e}_mean"]).sum()
-            print(f"product (snapshot run) vs fp64, epoch {e} mean rel-L1: {m:.3e}")
+            print(f"product (snapshot run) vs fp64, epoch {e} mean rel-L1: {_rel(p[f'val_e{e}_mean'], res[f'val_e{e}_mean']):.3e}")
+
+
+def stage_ref32(src):
+    """The YARDSTICK: the same continuation in the reference's own arithmetic (fp32 on the CPU, ~2 minutes) -- how far the reference
+    is from its fp64 self on every artefact.  Stored next to the fp64 golden as `ref32dist_<artefact>` (distances only: the fp32
+    artefacts themselves are one realisation of round-off and nothing is compared with them)."""
+    res, cs, _ = _cpu_run(src, torch.float32)
+    z = dict(np.load(GOLDEN))
+    for name, v in cs.items():
+        assert np.array_equal(v, z["checksum_" + name]), name
+    for k, v in res.items():
+        if v.dtype.kind == "f" and k in z:
+            z["ref32dist_" + k] = np.array(_rel(v, z[k]))
+            print(f"reference fp32 vs fp64  {k:24s} {float(z['ref32dist_' + k]):.3e}")
+    np.savez_compressed(GOLDEN, **z)
 
 
 if __name__ == "__main__":
-    {"snapshot": stage_snapshot, "golden": stage_golden}[sys.argv[1]](sys.argv[2])
+    {"snapshot": stage_snapshot, "golden": stage_golden, "ref32": stage_ref32}[sys.argv[1]](sys.argv[2])
