@@ -133,7 +133,9 @@ def parse():
                     help="frames of the synthetic clip, resident on every GPU (BASELINE configs[2]: 244 -> 715 pairs, the default at every "
                          "--gpus; configs[3] is --frames 1000 -> 2979 pairs, 7.2 GB per GPU and ~2 min of synthetic-data generation per rank)")
     ap.add_argument("--max-pairs", type=int, default=0, help="keep only the first N pairs of the clip (quick runs)")
-    ap.add_argument("--loss-batch", type=int, default=256, help="pairs per launch of the roofline micro-benchmark")
+    ap.add_argument("--loss-batch", type=int, default=256,
+                    help="pairs per launch of the roofline micro-benchmark (256 = one pair per CU, 0.88 GB: the launch every round has "
+                         "quoted; a second, 4x larger launch is reported next to it as roofline.sustained)")
     ap.add_argument("--loss-iters", type=int, default=20)
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CD_AMD_STEP_GRAPH", "1")),
                     help="1: replay the step from a HIP graph after the eager warm-up steps (GraphedFineTuneStep); 0: eager")
@@ -468,6 +470,17 @@ def main():
                                "traffic_over_algorithmic": round(traffic / alg, 4) if traffic else None,
                                "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5), "algorithmic_bytes_per_launch": alg,
                                "lib": lib.cd_build_info().decode()}
+            if sweep:
+                # The row sweep gives every CU ONE pair at a time; at 256 pairs = 256 CUs the launch lasts as long as its slowest pair
+                # (plans differ in length) -- with several pairs per CU the workgroups balance.  The same kernel at 4x the pairs:
+                try:
+                    ms4 = loss_microbench(lib, 4 * args.loss_batch, H, W, max(4, args.loss_iters // 2), device)
+                    avg4 = float(np.mean(ms4))
+                    ach4 = LOSS_BYTES_PER_PAIR_PX * px * 4 * args.loss_batch / (avg4 * 1e-3) / 1e9
+                    out["roofline"]["sustained"] = {"launch_pairs": 4 * args.loss_batch, "avg_ms": round(avg4, 5), "achieved": round(ach4, 1),
+                                                    "frac": round(ach4 / HBM_PEAK_GBS, 4)}
+                except (RuntimeError, AssertionError) as e:
+                    log(f"4x loss micro-benchmark failed: {type(e).__name__}: {e}")
         if world == 1 and not args.no_cpu_baseline and args.model == "mc":
             # the reference step restated on the host (oracle/cpu_step.py), in a bounded subprocess so a slow
             # host can never stall the benchmark: 1 warm-up + --cpu-steps timed steps of the same BS4 workload

@@ -182,12 +182,20 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         if ((rc = launch_mask_sums(mf, mb, B, HW, w.mask_sum, s)) != CD_OK) return rc;
         mask_sum = w.mask_sum;
     }
-    hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(kBlock), 0, s, intr, extr, mask_sum, lambda_r, lambda_b, B, H, W, w.cams);
-    CD_CHECK_LAUNCH();
     const bool r_on = lambda_r > 0.f, d_on = lambda_b > 0.f;
     const bool vec4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(depth) | reinterpret_cast<uintptr_t>(ff) |
                                         reinterpret_cast<uintptr_t>(fb) | reinterpret_cast<uintptr_t>(mf) |
                                         reinterpret_cast<uintptr_t>(mb)) % 16 == 0);
+    // the row sweep moves the pixels of a thread with one vector access per plane and row: planes must start on 16-byte boundaries
+    const bool sweep_aligned = grad && ((reinterpret_cast<uintptr_t>(depth) | reinterpret_cast<uintptr_t>(ff) | reinterpret_cast<uintptr_t>(fb) |
+                                          reinterpret_cast<uintptr_t>(mf) | reinterpret_cast<uintptr_t>(mb) | reinterpret_cast<uintptr_t>(grad)) % 16 == 0) &&
+                               ((size_t)HW * 4) % 16 == 0;
+    const bool use_sweep = grad && d_on && sweep_aligned && sweep_supported(H, W) &&
+                           (g_loss_variant == 4 || (g_loss_variant == 0 && sweep_preferred(B, H, W)));
+    if (!use_sweep) {      // (the row sweep computes the per-pair constants in its own units kernel: one launch less)
+        hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(kBlock), 0, s, intr, extr, mask_sum, lambda_r, lambda_b, B, H, W, w.cams);
+        CD_CHECK_LAUNCH();
+    }
     int nparts, alt_nparts = 0;
     const int* alt_flag = nullptr;
     if (!grad) {
@@ -204,15 +212,9 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         }
         g_prof.pending_batch = B;
         const int cap = (g_force_overflow_cap >= 0 && g_force_overflow_cap < w.ovf_cap) ? g_force_overflow_cap : w.ovf_cap;
-        // the row sweep moves the pixels of a thread with one vector access per plane and row: planes must start on 16-byte boundaries
-        const bool sweep_aligned = ((reinterpret_cast<uintptr_t>(depth) | reinterpret_cast<uintptr_t>(ff) | reinterpret_cast<uintptr_t>(fb) |
-                                     reinterpret_cast<uintptr_t>(mf) | reinterpret_cast<uintptr_t>(mb) | reinterpret_cast<uintptr_t>(grad)) % 16 == 0) &&
-                                   ((size_t)HW * 4) % 16 == 0;
-        const bool use_sweep = d_on && sweep_aligned && sweep_supported(H, W) &&
-                               (g_loss_variant == 4 || (g_loss_variant == 0 && sweep_preferred(B, H, W)));
         if (use_sweep)
             rc = launch_sweep(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf, cap,
-                              s, prof_before, prof_after);
+                              s, prof_before, prof_after, intr, extr, mask_sum, lambda_r, lambda_b);
         else
             rc = launch_slab(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.slabs,
                              w.ovf, cap, s, prof_before, prof_after);

@@ -37,7 +37,9 @@ bool sweep_preferred(int B, int H, int W);
 void set_sweep_pxt(int pxt);
 int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, const void* cams,
                  const void* blob, int mode, bool reproj, int B, int H, int W, float* partial, float* grad, void* ovf_mem,
-                 int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t));
+                 int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t),
+                 const float* prep_intr = nullptr, const float* prep_extr = nullptr, const float* prep_mask_sum = nullptr,
+                 float lambda_r = 0.f, float lambda_b = 0.f);   // prep_intr: compute the per-pair constants (`cams`) here instead of a prep_kernel launch in front
 
 // ---- v3 (loss_slab.hip): source pass + gather pass; slabs = slab_floats(B,H,W) floats of scratch
 size_t slab_floats(int B, int H, int W);

@@ -121,14 +121,34 @@ int launch_sweep_plan(const float* ff, const float* fb, const float* mf, const f
 }
 
 // ---------------------------------------------------------------- accumulator units (per launch: they depend on the depths)
+// PairPrep (non-null intr): the per-(pair, direction) constants are computed HERE, by the pair's own workgroup, instead of by a
+// one-workgroup prep_kernel launch in front (loss_api.hip) -- the same code on the same inputs (fbar by the same block_sum over the
+// same 256 threads: identical bits), one launch less on the path of every gradient launch.
+struct PairPrep { const float* intr; const float* extr; const float* mask_sum; float lambda_r, lambda_b; };
+
 template <int MODE>
 __global__ __launch_bounds__(kUnitGrid * kUnitGrid) void sweep_units_kernel(const float* __restrict__ depth, const float* __restrict__ ff,
                                                                             const float* __restrict__ fb, const float* __restrict__ mf,
-                                                                            const float* __restrict__ mb, PairCam* __restrict__ cams, int H, int W) {
+                                                                            const float* __restrict__ mb, PairCam* __restrict__ cams, int H, int W,
+                                                                            const PairPrep pp, int B) {
     constexpr int NS = kUnitGrid * kUnitGrid;
+    static_assert(NS == kBlock, "fbar is reduced exactly like prep_kernel does");
     __shared__ float sd[2][NS], ss[2][NS];
     __shared__ int sn[2][NS];
     const int b = blockIdx.x, t = threadIdx.x, HW = H * W;
+    if (pp.intr != nullptr) {
+        __shared__ float lds[kBlock / kWave];
+        __shared__ float fbar_s[2];
+        for (int k = 0; k < 2; ++k) {      // = prep_kernel (loss_api.hip)
+            float acc = 0.f;
+            for (int bb = threadIdx.x; bb < B; bb += kBlock) acc += pp.intr[(bb * 2 + k) * 4 + 0] + pp.intr[(bb * 2 + k) * 4 + 1];
+            acc = block_sum(acc, lds);
+            if (threadIdx.x == 0) fbar_s[k] = acc / (2.f * (float)B);
+            __syncthreads();
+        }
+        if (t == 0) prep_pair(pp.intr + b * 8, pp.extr + b * 24, pp.mask_sum + b * 2, fbar_s, pp.lambda_r, pp.lambda_b, B, H, W, cams + b * 2);
+        __syncthreads();      // the pair's constants are visible to the workgroup
+    }
     for (int j = 0; j < 2; ++j) {
         const UnitSample u = unit_sample_at<MODE>(cams + b * 2, depth + (size_t)b * 2 * HW, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW,
                                                   mf + (size_t)b * HW, mb + (size_t)b * HW, H, W, j, t);
@@ -145,11 +165,11 @@ __global__ __launch_bounds__(kUnitGrid * kUnitGrid) void sweep_units_kernel(cons
 }
 
 static int launch_sweep_units(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, PairCam* cams, int mode,
-                              int B, int H, int W, hipStream_t s) {
+                              int B, int H, int W, const PairPrep& pp, hipStream_t s) {
     const dim3 grid(B), block(kUnitGrid * kUnitGrid);
-    if (mode == CD_DEPTH_EXP) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_EXP>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W);
-    else if (mode == CD_DEPTH_RECIPROCAL) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_RECIPROCAL>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W);
-    else hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_IDENTITY>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W);
+    if (mode == CD_DEPTH_EXP) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_EXP>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W, pp, B);
+    else if (mode == CD_DEPTH_RECIPROCAL) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_RECIPROCAL>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W, pp, B);
+    else hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_IDENTITY>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W, pp, B);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -171,6 +191,7 @@ __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlan
 // COMPILE-TIME constants: ring strides, rows per pass, image size fold into immediates (the kernel is short of scalar registers:
 // ~30 wave-uniform camera constants, 10 pointers and the plan records live next to them) -- same code, same results.
 constexpr int kStaticH = 384, kStaticW = 224, kStaticPXT = 2;
+static_assert(kStagePasses == 2, "the service wave's quad count assumes SMAX = 2 passes of RP = 4 rows at the static geometry");
 
 template <int MODE, bool REPROJ, int PXT, int SG>
 __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
@@ -240,6 +261,27 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     // while the pass before it is evaluated, through two register sets that alternate explicitly (no copies): pass 0 reads set
     // A (loaded during the previous item), pass 1 set B (loaded during pass 0).  The record of the next item is read one item
     // ahead: loading it at the top of its own item exposed the scalar-load latency (0.344 -> 0.374 ms at 256 pairs).
+    // The frame's SERVICE wave (loss_sweep_core.h: the eighth wave of each frame has no source pixels at W = 224 and takes over the
+    // rows that enter and leave the ring; compile-time geometry only -- the run-time-geometry build keeps every thread on its columns).
+    constexpr bool SVC = SG == 1 && PXT == kStaticPXT;
+    if (SVC && (int)threadIdx.x - f * kFrameThreads >= g.RP * g.CG) {      // wave-uniform
+        constexpr int NQ = SVC ? (2 * 4 * (kStaticW / 4) + kSvcLanes - 1) / kSvcLanes : 1;     // kStagePasses * RP rows of W / 4 quads
+        const int sl = (int)threadIdx.x - f * kFrameThreads - g.RP * g.CG;
+        SvcRegs<NQ> q;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) q.v[i][0] = q.v[i][1] = q.v[i][2] = q.v[i][3] = 0.f;
+        Rec me = items[0].f[f];
+        __syncthreads();
+        for (int it = 0; it < n_items; ++it) {
+            r.bad = !svc_stage<MODE, NQ>(v, sl, me.s_lo, me.s_hi, q) || r.bad;
+            const bool more = it + 1 < n_items;
+            const Rec nx = items[more ? it + 1 : it].f[f];
+            svc_load<NQ>(v, sl, nx.s_lo, more ? nx.s_hi : nx.s_lo, q);
+            svc_flush<NQ>(v, sl, me.fl_lo, me.fl_hi);
+            __syncthreads();
+            me = nx;
+        }
+    } else {
     Inputs<PXT> inA, inB;
     const bool two = kGroupPasses > 1 && uni((int)(g.G > g.RP)) != 0;
     Rec me = items[0].f[f];
@@ -247,19 +289,20 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     load_inputs<PXT>(v, l, me.p, 0, inA);
     __syncthreads();
     for (int it = 0; it < n_items; ++it) {
-        r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
+        if (!SVC) r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
         const bool more = it + 1 < n_items;
         const int nt = more ? it + 1 : it;
         const Rec nx = items[nt].f[f];
         const int nwk = items[nt].f[k].w, nnvk = items[nt].f[k].nv;
-        load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
+        if (!SVC) load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
         if (two) load_inputs<PXT>(v, l, me.p, 1, inB);
-        flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);
+        if (!SVC) flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);
         process_rows<MODE, REPROJ, PXT>(v, env, r, l, inA, me.p, 0, wk, nvk);
         load_inputs<PXT>(v, l, more ? nx.p : -1, 0, inA);
         if (two) process_rows<MODE, REPROJ, PXT>(v, env, r, l, inB, me.p, 1, wk, nvk);
         __syncthreads();
         me = nx; wk = nwk; nvk = nnvk;
+    }
     }
     if (env.any(r.bad) && (threadIdx.x & (kWave - 1)) == 0) env.degenerate();
     // loss partial sums: one (reprojection, disparity) pair per (pair, direction)
@@ -343,7 +386,8 @@ static const bool g_sweep_env_read = [] {
 
 int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, const void* cams,
                  const void* blob, int mode, bool reproj, int B, int H, int W, float* partial, float* grad, void* ovf_mem,
-                 int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t)) {
+                 int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t), const float* prep_intr,
+                 const float* prep_extr, const float* prep_mask_sum, float lambda_r, float lambda_b) {
     const Geo g = sweep_geo(H, W);
     if (!sweep_supported(H, W)) return CD_ERR_UNSUPPORTED;
     Overflow* ovf = (Overflow*)ovf_mem;
@@ -354,7 +398,8 @@ int launch_sweep(const float* depth, const float* ff, const float* fb, const flo
     SweepArgs prm{depth, ff, fb, mf, mb, (const PairCam*)cams, (const char*)blob, partial, grad, ovf, oidx, oval,
                   SweepShape{g, pair_record_bytes(H, W), plan_offset(H, W)}};
     const size_t lds = ring_lds_bytes(g);
-    if (launch_sweep_units(depth, ff, fb, mf, mb, (PairCam*)const_cast<void*>(cams), mode, B, H, W, s) != CD_OK) return CD_ERR_LAUNCH;
+    const PairPrep pp{prep_intr, prep_extr, prep_mask_sum, lambda_r, lambda_b};     // prep_intr == nullptr: `cams` is already filled (prep_kernel)
+    if (launch_sweep_units(depth, ff, fb, mf, mb, (PairCam*)const_cast<void*>(cams), mode, B, H, W, pp, s) != CD_OK) return CD_ERR_LAUNCH;
     if (before_main) before_main(s);
     int rc;
     if (mode == CD_DEPTH_EXP) rc = launch_sweep_mode<CD_DEPTH_EXP>(reproj, prm, B, lds, s);

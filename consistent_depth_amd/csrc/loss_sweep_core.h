@@ -476,6 +476,87 @@ CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi) {
     }
 }
 
+// ---------------------------------------------------------------- service wave (round 4)
+// At W = 224 with 2 pixels per thread a pass of the 512 threads of a frame covers 4 rows x 112 column groups = 448 threads: the
+// eighth wave of each frame has no source pixels, and -- waves of a workgroup go to the SIMDs round robin -- both idle waves sit on
+// the SAME SIMD: three SIMDs carry four working waves, one carries two, and the kernel is bound by vector-ALU issue on the full
+// ones.  The rows entering and leaving a ring (load_stage / stage_rows / flush_rows above: the depth head's exp, the fixed-point ->
+// float conversion, the gradient store; ~12 % of a working thread's instructions) need no per-thread state of the sources at all,
+// so the idle wave of each frame takes them over as the frame's SERVICE wave: quads of 4 adjacent columns, quad lane + 64 i of the
+// rows [lo, hi) (at most SMAX rows: NQ = ceil(SMAX * W / 256) quads per lane), 16-byte global accesses, 8-byte LDS accesses (a ring
+// row is RW = W + 2 floats: 8-byte aligned).  Same per-element arithmetic, same ring contents, same gradient bits.
+constexpr int kSvcLanes = 64;
+template <int NQ> struct SvcRegs { float v[NQ][4]; };
+CD_HD bool svc_geometry_ok(const Geo& g) {     // a whole idle wave per frame, rows that split into aligned quads
+    return g.ok && g.W % 4 == 0 && g.RW % 2 == 0 && (g.RP * g.CG) % kSvcLanes == 0 && kFrameThreads - g.RP * g.CG >= kSvcLanes;
+}
+CD_HD int svc_quads(const Geo& g) { return (g.SMAX * (g.W / 4) + kSvcLanes - 1) / kSvcLanes; }
+
+// raw depth of the rows [s_lo, s_hi) that enter the ring (cf. load_stage)
+template <int NQ> CD_HD void svc_load(const View& v, int lane, int s_lo, int s_hi, SvcRegs<NQ>& q) {
+    const int QW = v.W >> 2;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qi = lane + kSvcLanes * i, rr = qi / QW, c4 = qi - rr * QW, row = s_lo + rr;
+        const bool ok = row < s_hi && row < v.H;
+        const VecF<4> a = ldgv<4>(v.vj, ok ? ((unsigned)row * (unsigned)v.W + 4u * (unsigned)c4) << 2 : 0u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.v[i][e] = ok ? a.v[e] : 0.f;
+    }
+}
+
+// the rows enter the ring (cf. stage_rows; returns false if a staged depth is not a positive finite number)
+template <int MODE, int NQ> CD_HD bool svc_stage(const View& v, int lane, int s_lo, int s_hi, const SvcRegs<NQ>& q) {
+    const int QW = v.W >> 2;
+    bool good = true;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qi = lane + kSvcLanes * i, rr = qi / QW, c4 = qi - rr * QW, row = s_lo + rr;
+        if (row < s_hi) {
+            const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW) + 4u * (unsigned)c4;
+            const bool img = row < v.H;
+            VecF<2> d0, d1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = img ? to_depth<MODE>(q.v[i][e]) : 1.f;
+                good = good && (d > 0.f && d < INFINITY);
+                if (e < 2) d0.v[e] = d; else d1.v[e - 2] = d;
+            }
+            *reinterpret_cast<VecF<2>*>(&v.Dj[base]) = d0;
+            *reinterpret_cast<VecF<2>*>(&v.Dj[base + 2]) = d1;
+        }
+    }
+    const int row = s_lo + lane;                   // the pad column(s): one row per lane
+    if (row < s_hi)
+        for (int c = v.W; c < v.RW; ++c) v.Dj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 1.f;
+    return good;
+}
+
+// rows [lo, hi) leave the ring (cf. flush_rows)
+template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) {
+    const int QW = v.W >> 2;
+    const float unit = v.cj.unit_s;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qi = lane + kSvcLanes * i, rr = qi / QW, c4 = qi - rr * QW, row = lo + rr;
+        if (row < hi) {
+            const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW) + 4u * (unsigned)c4;
+            VecU<2>* a0 = reinterpret_cast<VecU<2>*>(&v.Aj[base]);
+            VecU<2>* a1 = reinterpret_cast<VecU<2>*>(&v.Aj[base + 2]);
+            const VecU<2> n0 = *a0, n1 = *a1;
+            VecU<2> z; z.v[0] = z.v[1] = 0u;
+            *a0 = z; *a1 = z;
+            VecF<4> g;
+            g.v[0] = (float)(int)n0.v[0] * unit; g.v[1] = (float)(int)n0.v[1] * unit;
+            g.v[2] = (float)(int)n1.v[0] * unit; g.v[3] = (float)(int)n1.v[1] * unit;
+            stgv<4>(v.gradj, ((unsigned)row * (unsigned)v.W + 4u * (unsigned)c4) << 2, g);
+        }
+    }
+    const int row = lo + lane;
+    if (row < hi)
+        for (int c = v.W; c < v.RW; ++c) v.Aj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 0u;
+}
+
 // Evaluate pass q of the source rows [p, p + G) of the wave's frame j: loss partials, direct gradient -> ring j, the 4 tap
 // contributions -> ring k.  Closed form: SURVEY.md appendix A.1 (= oracle/cd_oracle_body.inc).
 // Env supplies what differs between the GPU and the host emulation:
@@ -568,7 +649,8 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
                 gdi = cj.drs * m * (ex * dpx + ey * dpy) * ie;
             }
             // z of the sampled point = -(sum of the weighted taps); 1 / z through ONE reciprocal of the positive sum
-            const float izs = -cd_rcp(d00[i] * tp[i].w00 + d01[i] * tp[i].w01 + d10[i] * tp[i].w10 + d11[i] * tp[i].w11);
+            const float zsum = d00[i] * tp[i].w00 + d01[i] * tp[i].w01 + d10[i] * tp[i].w10 + d11[i] * tp[i].w11;   // = -z of the sampled point
+            const float izs = -cd_rcp(zsum);
             const float dd = iZ - izs;
             sum_d += rowok ? m * fabsf(dd) : 0.f;
             const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
@@ -579,8 +661,13 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
             c00[i] = -gz * tp[i].w00 * depth_jac<MODE>(d00[i]); c01[i] = -gz * tp[i].w01 * depth_jac<MODE>(d01[i]);
             c10[i] = -gz * tp[i].w10 * depth_jac<MODE>(d10[i]); c11[i] = -gz * tp[i].w11 * depth_jac<MODE>(d11[i]);
             gd[i] = gdi;
-            // inside the fixed-point range?  (a sum, not a max: NaN must fail the test)
-            const bool fits = fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]) + fabsf(gdi) <= v.limit;
+            // inside the fixed-point range?  (a sum, not a max: NaN must fail the test.)  The four tap contributions are -gz w_ij jac(d_ij)
+            // with w_ij >= 0: for the exp head (jac(d) = d > 0) their |.| sum IS |gz| * zsum, for the identity head |gz| -- one
+            // multiply instead of four |.| and three adds per pixel; the reciprocal head keeps the explicit sum.  (The test only routes
+            // a source to the fast or to the exact slow path: a last-bit difference in it cannot change a result.)
+            const float csum = MODE == kDepthExp ? fabsf(gz) * zsum : (MODE == kDepthIdentity ? fabsf(gz)
+                               : fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]));
+            const bool fits = csum + fabsf(gdi) <= v.limit;
             need_slow = need_slow || (rowok && !fits);
         }
         const bool slow = __builtin_expect(slow_rd || env.any(need_slow), 0);

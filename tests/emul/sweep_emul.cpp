@@ -18,6 +18,8 @@ using namespace cd::sweep;
 namespace {
 
 int g_order = 0;   // 0: an item's sources run before its rows enter / leave, 1: after (see run_pair)
+int g_service = 0; // 1: rows enter / leave through the frame's service wave (svc_* of loss_sweep_core.h) instead of every thread's own columns
+constexpr int kEmulNQ = 16;
 
 struct HostEnv {
     std::vector<unsigned>* idx;
@@ -115,6 +117,15 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
             regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], lo, hi, sv) || regs[t].bad;
         }
     }
+    // the service-wave form of the rows entering / leaving the rings (loss_sweep_core.h; the GPU uses it for its compile-time geometry)
+    const bool service = g_service && svc_geometry_ok(g) && svc_quads(g) <= kEmulNQ;
+    if (g_service && !service) { fprintf(stderr, "emul: geometry has no service wave\n"); return -7; }
+    const int svc0 = g.RP * g.CG;
+    std::vector<SvcRegs<kEmulNQ>> svc[2];
+    for (int f = 0; f < 2; ++f) {
+        svc[f].resize(kSvcLanes);
+        for (auto& q : svc[f]) memset(&q, 0, sizeof(q));
+    }
     int wlast[2] = {0, 0};
     for (int it = 0; it < n_items; ++it) {
         for (int f = 0; f < 2; ++f) {
@@ -129,12 +140,18 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
         // LAST (1): a plan that let them depend on this item's entering / leaving rows would give different results.
         const bool more = it + 1 < n_items;
         std::vector<Regs<PXT>> nxt;
+        std::vector<SvcRegs<kEmulNQ>> svc_nxt[2];
         if (more) {      // the kernel loads the next item's entering rows while this item runs
             nxt = regs;
             for (int t = 0; t < kThreads; ++t) {
                 const Rec& nx = items[it + 1].f[fr[t]];
-                load_stage<PXT>(vw[fr[t]], lanes[t], nx.s_lo, nx.s_hi, nxt[t].sv);
+                if (!service) load_stage<PXT>(vw[fr[t]], lanes[t], nx.s_lo, nx.s_hi, nxt[t].sv);
             }
+            if (service)
+                for (int f = 0; f < 2; ++f) {
+                    svc_nxt[f] = svc[f];
+                    for (int sl = 0; sl < kSvcLanes; ++sl) svc_load<kEmulNQ>(vw[f], sl, items[it + 1].f[f].s_lo, items[it + 1].f[f].s_hi, svc_nxt[f][sl]);
+                }
         }
         const int passes = g.G > g.RP ? 2 : 1;
         for (int pass = 0; pass < 2; ++pass) {
@@ -149,6 +166,14 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
                         process_rows<MODE, REPROJ, PXT>(vw[f], env, regs[t], lanes[t], in, me.p, q, ot.w, ot.nv);
                     }
             } else {
+                if (service) {     // the frame's service wave does what the threads below do for their own columns
+                    for (int f = 0; f < 2; ++f)
+                        for (int sl = 0; sl < kSvcLanes; ++sl) {
+                            const Rec& me = items[it].f[f];
+                            regs[f * kFrameThreads + svc0 + sl].bad = !svc_stage<MODE, kEmulNQ>(vw[f], sl, me.s_lo, me.s_hi, svc[f][sl]) || regs[f * kFrameThreads + svc0 + sl].bad;
+                            svc_flush<kEmulNQ>(vw[f], sl, me.fl_lo, me.fl_hi);
+                        }
+                } else
                 for (int t = 0; t < kThreads; ++t) {
                     const Rec& me = items[it].f[fr[t]];
                     regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], me.s_lo, me.s_hi, regs[t].sv) || regs[t].bad;
@@ -156,10 +181,12 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
                 }
             }
         }
-        if (more)
+        if (more) {
             for (int t = 0; t < kThreads; ++t)
                 for (int i = 0; i < PXT; ++i)
                     for (int s = 0; s < kStagePasses; ++s) regs[t].sv[s][i] = nxt[t].sv[s][i];
+            if (service) { svc[0] = svc_nxt[0]; svc[1] = svc_nxt[1]; }
+        }
     }
     for (int f = 0; f < 2; ++f)
         if (wlast[f] < H) { fprintf(stderr, "emul: rows left in ring %d\n", f); return -5; }
@@ -198,6 +225,7 @@ int sweep_emul_fan_in(const int* geo, const float* ff, const float* fb, const fl
 }
 
 void sweep_emul_set_order(int order) { g_order = order ? 1 : 0; }
+void sweep_emul_set_service(int on) { g_service = on ? 1 : 0; }
 
 // geometry as the kernel would choose it: out[0..11] = the Geo fields; ring_rows > 0 overrides R (to force tiny rings)
 int sweep_emul_geo(int H, int W, int pxt, int ring_rows, int* out) {

@@ -138,6 +138,12 @@ def test_emulated_sweep_full_size_vs_oracle(oracle, gen, kw, H, W):
     assert grad < max(4 * oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]), 2e-6)
     e2 = E.loss(batch, 1.0, 0.1, pxt=2, order=1)      # rows entering / leaving an item are independent of its sources
     np.testing.assert_array_equal(e["grad_depth"], e2["grad_depth"])
+    if W == 224:      # the geometry with an idle wave per frame: rows enter / leave through the service wave (round 4) -- same bits
+        for order in (0, 1):
+            e3 = E.loss(batch, 1.0, 0.1, pxt=2, order=order, service=True)
+            np.testing.assert_array_equal(e["grad_depth"], e3["grad_depth"])
+            np.testing.assert_array_equal(e["total"], e3["total"])
+            assert e3["degenerate"] == e["degenerate"] and e3["overflow_entries"] == e["overflow_entries"]
     if gen == "scene" and W == 224:
         assert e["overflow_entries"] == 0 and e["slow_lanes"] < 0.01 * 2 * 2 * H * W
 
