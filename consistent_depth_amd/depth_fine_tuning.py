@@ -35,7 +35,7 @@ import numpy as np
 import torch
 
 from . import optimizer, parallel
-from .engine import FineTuneStep, GraphedFineTuneStep
+from .engine import FineTuneStep, GraphedEvaluate, GraphedFineTuneStep
 from .loaders.pair_store import PairStore
 from .loaders.video_dataset import VideoFrameDataset
 from .loss.loss_params import LossParams
@@ -223,10 +223,15 @@ class DepthFineTuner:
         plan_dev = parallel.plan_to_device(plan, store.device)
         frames_of = store.pair_indices()    # host copy of the pair list: no device sync to learn which frames a batch holds
         first = parallel.first_sightings(frames_of, p.batch_size)   # frame -> the batch of the sweep that exports it (one owner)
+        # the forward + loss of a full batch replays from a HIP graph (engine.GraphedEvaluate); its outputs are static buffers,
+        # consumed below before the next batch is launched
+        base = getattr(step, "step", step)
+        evaluator = getattr(base, "_evaluator", None)
+        if evaluator is None:
+            evaluator = base._evaluator = GraphedEvaluate(base)
         with image_io.AsyncRawWriter(device=store.device) as writer:     # the files of this sweep are on disk when the block ends
             for (chunk, ids), ids_dev in zip(chunks, plan_dev):
-                images, metadata = store.batch(ids_dev)
-                raw, _, parts = step.evaluate(images, metadata)
+                raw, parts, metadata = evaluator(store, ids_dev)
                 idx = metadata["geometry_consistency"]["indices"]
                 rows.append(torch.cat([idx.float()] + [parts[n].reshape(-1, 1).float() for n in names], 1))
                 inv = self._depth_from_raw(raw).reciprocal()

@@ -245,3 +245,57 @@ class GraphedFineTuneStep:
 
     def close(self):
         self.step.close()
+
+
+class GraphedEvaluate:
+    """The validation forward of one batch -- CNN forward (train-mode BatchNorm under no_grad, like the reference's sweep,
+    depth_fine_tuning.py:241,327-328) + forward-only loss -- replayed from a HIP graph.
+
+    A validation sweep is 179 batches of ~350 launches each (715 pairs, BS4): issued from Python it is bound by the host (~7 ms of
+    enqueue per batch for ~6 ms of GPU work), and it is a quarter of an epoch's compute.  After `eager_calls` calls per batch size (they
+    build the engine plan and time the launch shapes) the forward + loss of that batch size is captured once; every later batch is
+    ONE gather launch straight into the graph's static input buffers (PairStore.gather_into) + ONE replay.  The returned raw output and
+    per-pair losses are the graph's static output buffers: consume them (copy, reduce, hand to the writer) before the next call.
+    The sweep's short last batch has its own size, is seen once per sweep and stays eager.  Same kernels, same order, same values."""
+
+    def __init__(self, step: FineTuneStep, eager_calls: int = 1):
+        self.step, self.eager_calls = step, eager_calls
+        self._graphs, self._seen = {}, {}
+        self.enabled = os.environ.get("CD_AMD_EVAL_GRAPH", os.environ.get("CD_AMD_STEP_GRAPH", "1")) != "0"
+        self.capture_error = None
+
+    def __call__(self, store, pair_ids: torch.Tensor):
+        """-> (raw network output (B,2,H,W), {name: (B,)} per-pair losses, metadata of the batch)."""
+        key = (id(store), int(pair_ids.numel()), int(store.tile_windows.shape[1]))
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            images, metadata = store.batch(pair_ids)
+            if not self.enabled or n < self.eager_calls:
+                raw, _, parts = self.step.evaluate(images, metadata)
+                return raw, parts, metadata
+            try:
+                g = self._capture(images, metadata)
+            except Exception as e:   # noqa: BLE001 -- the (equally native) eager path
+                self.enabled, self.capture_error = False, f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize()
+                raw, _, parts = self.step.evaluate(images, metadata)
+                return raw, parts, metadata
+            self._graphs[key] = g
+        else:
+            store.gather_into(pair_ids, g["images"], g["meta"])
+        g["graph"].replay()
+        return g["raw"], g["parts"], g["meta"]
+
+    def _capture(self, images, metadata):
+        st_images, st_meta = images.detach().clone().contiguous(), _clone_tree(metadata)
+        dev = images.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                raw, _, parts = self.step.evaluate(st_images, st_meta)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return {"graph": graph, "images": st_images, "meta": st_meta, "raw": raw, "parts": parts}
