@@ -644,7 +644,7 @@ int cd_conv2d_fwd_multi(const cd_conv_desc* d, int n, int tile_rows, int co_tile
         if (e.x_coff < 0 || e.x_coff + e.Cin > e.x_ctot || e.y_coff < 0 || e.y_coff + e.Cout > e.y_ctot) return CD_ERR_INVALID_ARG;
         if ((e.in_scale == nullptr) != (e.in_shift == nullptr)) return CD_ERR_INVALID_ARG;
         if (e.N != d[0].N || e.H != d[0].H || e.W != d[0].W || e.Cout != d[0].Cout) return CD_ERR_INVALID_ARG;   // one launch shape
-        if (!cd::split_supported(e.ks) || e.Cin < 8 || e.Cout <= 16) return CD_ERR_UNSUPPORTED;
+        if (!cd::split_supported(e.ks) || e.Cin < 8) return CD_ERR_UNSUPPORTED;
         c[i].x = e.x; c[i].wsplit = e.packed_w + cd::fp32_packed_floats(e.Cout, e.Cin, e.ks); c[i].bias = e.bias; c[i].in_scale = e.in_scale;
         c[i].in_shift = e.in_shift; c[i].y = e.y; c[i].stats = e.stats; c[i].x_ctot = e.x_ctot; c[i].x_coff = e.x_coff; c[i].Cin = e.Cin;
         c[i].in_relu = e.in_relu; c[i].y_ctot = e.y_ctot; c[i].y_coff = e.y_coff; c[i].accumulate = e.accumulate; c[i].ks = e.ks;

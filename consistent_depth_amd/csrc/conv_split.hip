@@ -551,14 +551,18 @@ static int launch_split_multi_t(const SplitConv* c, int n, int N, int H, int W, 
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
-// n <= 4 convolutions with the SAME N, H, W, Cout (> 16) and filter sizes in {3, 5, 7, 11}; (ty, cot) as launch_conv_split.
+// n <= 4 convolutions with the SAME N, H, W, Cout and filter sizes in {3, 5, 7, 11}; (ty, cot) as launch_conv_split.
 int launch_conv_split_multi(const SplitConv* c, int n, int N, int H, int W, int Cout, int ty, int cot, hipStream_t s) {
-    if (n < 1 || n > kSplitMultiMax || split_dy(Cout) != 1) return CD_ERR_UNSUPPORTED;
+    if (n < 1 || n > kSplitMultiMax) return CD_ERR_UNSUPPORTED;
     for (int i = 0; i < n; ++i)
         if (!split_supported(c[i].ks)) return CD_ERR_UNSUPPORTED;
     const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
     const bool two = ty >= 16;
     const int mb = (nt == 2 || ty <= 4 || two) ? 4 : 8;
+    if (split_dy(Cout) == 2) {     // <= 16 output channels: 16 channels x 2 output rows per column tile (the shapes of launch_conv_split)
+        if (mb == 8) return launch_split_multi_t<1, 16, 2, 1>(c, n, N, H, W, Cout, s);
+        return two ? launch_split_multi_t<1, 8, 2, 2>(c, n, N, H, W, Cout, s) : launch_split_multi_t<1, 8, 2, 1>(c, n, N, H, W, Cout, s);
+    }
     if (nt == 2) return two ? launch_split_multi_t<2, 4, 1, 2>(c, n, N, H, W, Cout, s) : launch_split_multi_t<2, 4, 1, 1>(c, n, N, H, W, Cout, s);
     if (mb == 8) return launch_split_multi_t<1, 8, 1, 1>(c, n, N, H, W, Cout, s);
     return two ? launch_split_multi_t<1, 4, 1, 2>(c, n, N, H, W, Cout, s) : launch_split_multi_t<1, 4, 1, 1>(c, n, N, H, W, Cout, s);

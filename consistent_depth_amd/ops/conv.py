@@ -148,8 +148,8 @@ _CONV_DESC_DT = [("x", "<u8"), ("packed_w", "<u8"), ("bias", "<u8"), ("in_scale"
 def conv2d_multi(members, cfg=None) -> bool:
     """SEVERAL convolutions of one launch shape in ONE dispatch (cd_conv2d_fwd_multi): `members` = up to 4 dicts with the arguments of
     conv2d (x, packed_w, Cin, Cout, ks, bias, x_coff, out, y_coff, in_scale, in_shift, in_relu, stats, accumulate), same N, H, W and
-    Cout, largest filter first.  Returns False -- nothing launched -- when the library has no such dispatch for them (Cout <= 16,
-    the fp32 arithmetic mode): the caller then launches the members one by one.  Same bits either way."""
+    Cout, largest filter first.  Returns False -- nothing launched -- when the library has no such dispatch for them (the fp32
+    arithmetic mode): the caller then launches the members one by one.  Same bits either way."""
     import ctypes
     import numpy as np
     tab = np.zeros(len(members), np.dtype(_CONV_DESC_DT))

@@ -261,13 +261,13 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
 int cd_conv2d_fwd_grouped(const float* x, int x_ctot, int x_coff, int cin_g, const float* packed_w, size_t packed_group_stride,
                           const float* bias, float* y, int y_ctot, int y_coff, int cout_g, int groups, int accumulate, int N, int H, int W,
                           int ks, void* stream);
-/* SEVERAL convolutions in ONE dispatch: the n <= 4 members share N, H, W and Cout (> 16), have filter sizes in {3, 5, 7, 11} and
+/* SEVERAL convolutions in ONE dispatch: the n <= 4 members share N, H, W and Cout, have filter sizes in {3, 5, 7, 11} and
  * >= 8 input channels each -- the three k x k branches of an inception (monodepth/mannequin_challenge), forward
  * (inputs: the mid activations with their BatchNorm (scale, shift), outputs: the branch slices of the concat buffer) or input
  * gradient (transposed packs, roles swapped).  Fields as the arguments of cd_conv2d_fwd_cfg; tile_rows / co_tiles: the launch shape
  * hints, shared by the members.  Every workgroup does what it does in the member's own cd_conv2d_fwd_cfg launch with the same hints:
- * identical bits.  Order the members largest filter first.  CD_ERR_UNSUPPORTED (nothing launched): arithmetic mode 0, Cout <= 16, a
- * member the split kernels do not take -- launch the members one by one. */
+ * identical bits.  Order the members largest filter first.  CD_ERR_UNSUPPORTED (nothing launched): arithmetic mode 0, or a member the
+ * split kernels do not take -- launch the members one by one. */
 typedef struct cd_conv_desc {
     const float* x; const float* packed_w; const float* bias; const float* in_scale; const float* in_shift; float* y; double* stats;
     int x_ctot, x_coff, Cin, in_relu, y_ctot, y_coff, Cout, accumulate, N, H, W, ks;

@@ -314,7 +314,7 @@ def test_weight_gradients_of_many_convolutions_in_one_launch_per_class(arith):
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,kss", [(8, 24, 14, 32, 64, (7, 5, 3)), (8, 48, 28, 64, 64, (11, 7, 3)), (4, 96, 56, 32, 32, (7, 5, 3)),
-                                                 (2, 40, 72, 64, 32, (11, 7, 3)), (2, 33, 47, 24, 40, (5, 3))])
+                                                 (2, 40, 72, 64, 32, (11, 7, 3)), (2, 33, 47, 24, 40, (5, 3)), (2, 40, 72, 64, 16, (11, 7, 3)), (4, 48, 64, 32, 16, (11, 7, 3))])
 @pytest.mark.parametrize("cfg", [(4, 1), (8, 1), (16, 1), (4, 2), (16, 2)])
 def test_branches_of_an_inception_in_one_dispatch(arith, N, H, W, cin, cout, kss, cfg):
     """cd_conv2d_fwd_multi: the k x k branches of an inception (different filter sizes, different input slices of ONE buffer, adjacent
