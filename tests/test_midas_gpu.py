@@ -198,3 +198,52 @@ def test_pooled_layer_outside_the_network_forward_sees_updated_weights():
         y1 = layer(x)                                     # re-packs (the pool is stale), then runs
     assert pool.fresh
     assert float((y1 - 2.0 * y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+
+
+_BLOCKS = {
+    "layer1.bottleneck0 (stride 1, 64 -> 256, down-sample 1x1) @96x96": (lambda n: n.pretrained.layer1[4][0], (2, 64, 96, 96)),
+    "layer2.bottleneck0 (stride 2, 256 -> 512) @96x96": (lambda n: n.pretrained.layer2[0], (2, 256, 96, 96)),
+    "layer3.bottleneck5 (1024 -> 1024) @24x24": (lambda n: n.pretrained.layer3[5], (4, 1024, 24, 24)),
+    "layer4.bottleneck0 (stride 2, 1024 -> 2048) @24x24": (lambda n: n.pretrained.layer4[0], (4, 1024, 24, 24)),
+    "refinenet3 (two inputs, 256 ch) @24x24": (lambda n: n.scratch.refinenet3, (2, 256, 24, 24)),
+    "layer3_rn (3x3 1024 -> 256) @24x24": (lambda n: n.scratch.layer3_rn, (2, 1024, 24, 24)),
+}
+
+
+@pytest.mark.parametrize("name", list(_BLOCKS))
+def test_midas_blocks_match_fp64(name):
+    """Between one convolution and the 100-layer network: single blocks of the backbone on the HIP back end against the SAME block
+    of the plain-PyTorch twin evaluated in fp64 on the CPU, at the extents they have in BASELINE configs[4] (96x96 ... 12x12 for a
+    384x384 input), where a train-mode BatchNorm has hundreds of samples per channel and round-off is not amplified: output, input
+    gradient and EVERY parameter gradient to <= 2e-4.  A branch scaled wrongly, a stride-2 path sampled at the wrong phase, a group
+    mapped to the wrong channels or a stale packed filter is an O(1) error here -- the whole-network test above cannot see such things
+    through its 1e-1 noise floor."""
+    import torch
+    from consistent_depth_amd.monodepth.midas_net import MidasNet
+    torch.manual_seed(1)
+    net = MidasNet(backend="hip")
+    twin = MidasNet(backend="torch")
+    twin.load_state_dict(net.state_dict())
+    pick, shape = _BLOCKS[name]
+    net = net.cuda().train()
+    block, ref = pick(net), pick(twin).double().train()
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(shape, generator=g, dtype=torch.float64) for _ in range(2 if name.startswith("refinenet") else 1)]
+    res = {}
+    for tag, mod, conv in (("hip", block, lambda t: t.float().cuda()), ("fp64", ref, lambda t: t.clone())):
+        ins = [conv(t).requires_grad_(True) for t in xs]
+        if tag == "hip":
+            net._pack_pool.invalidate()          # a pooled layer called outside the network's forward re-packs the pool
+        y = mod(*ins)
+        w = torch.cos(torch.arange(y.numel(), dtype=torch.float64).reshape(y.shape) * 0.37).to(y)
+        (0.5 * w * y * y).sum().backward()
+        res[tag] = (y.detach().double().cpu(), [t.grad.detach().double().cpu() for t in ins],
+                    {k: p.grad.detach().double().cpu() for k, p in mod.named_parameters() if p.grad is not None})
+    rel = lambda a, b: float((a - b).abs().sum() / max(float(b.abs().sum()), 1e-300))  # noqa: E731
+    dy = rel(res["hip"][0], res["fp64"][0])
+    dx = max(rel(a, b) for a, b in zip(res["hip"][1], res["fp64"][1]))
+    assert set(res["hip"][2]) == set(res["fp64"][2]) and res["hip"][2]
+    dw = {k: rel(res["hip"][2][k], v) for k, v in res["fp64"][2].items()}
+    worst = max(dw, key=dw.get)
+    report(f"midas_block[{name}]", y=dy, dx=dx, dW_worst=dw[worst], worst=worst)
+    assert dy < 2e-5 and dx < 2e-4 and dw[worst] < 2e-4, (dy, dx, worst, dw[worst])
