@@ -404,8 +404,11 @@ def main():
                                if args.model == "mc" else
                                (f"midas2 plugin: MiDaS-v2-shaped backbone (ResNeXt-101 32x8d + feature-fusion decoder restated, random init, "
                                 f"seed 0), fine-tuning steps over a synthetic {args.frames}-frame {H}x{W} clip ({len(store)} pairs), BS{B} pairs/GPU, "
-                                f"lambda_r 1.0 lambda_b 1e-4, Adam lr 1e-4 (BASELINE configs[4] shape on {world} GPU(s); convolutions: "
-                                + ("hand-written HIP kernels through ops/conv_layer.py)" if args.backend == "hip" else "PyTorch-ROCm/MIOpen)")),
+                                f"lambda_r 1.0 lambda_b 1e-4, Adam lr 1e-4 (BASELINE configs[4] shape on {world} GPU(s); "
+                                + ("k >= 3 convolutions incl. the grouped 32x8d 3x3 (1/3 of the multiply-adds): hand-written split-bf16 HIP kernels, "
+                                   "forward / input gradient / weight gradient; dense 1x1 convolutions (2/3 of the multiply-adds): fp32 GEMMs of the "
+                                   "library (rocBLAS / hipBLASLt through torch.matmul / bmm); BatchNorm, ReLU, max-pool, bilinear: ATen; stride 2 = "
+                                   "stride 1 + sub-sampling; loss + Adam: hand-written HIP)" if args.backend == "hip" else "convolutions: PyTorch-ROCm/MIOpen)")),
                    "model": args.model,
                    "conv_backend": args.backend,
                    "conv_arith": ("fp32 results from split operands: every fp32 input = 3 exact bf16 terms, 6 cross products on the BF16 matrix "
@@ -433,12 +436,13 @@ def main():
             "flops_per_pair": flops_per_pair, "per": "GPU, whole step time (BatchNorm, loss, Adam and launch gaps included: a lower bound "
                                                      "of what the convolution kernels reach while they run)",
             "peak_note": ("fp32-equivalent roof of the split-operand kernels = dense BF16 peak 2500 / 6 products" if split else
-                          ("fp32 matrix instruction (v_mfma_f32_16x16x4_f32); a mixture for midas2 -- the dense 1x1 run as fp32 library GEMMs, "
-                           "the k >= 3 convolutions on the split-operand kernels (roof 416.7) -- priced against the lower peak"
+                          ("a MIXTURE for midas2, priced against the LOWER of its two roofs (which flatters the fraction): 2/3 of the flops are "
+                           "fp32 library GEMMs (roof 157.3), 1/3 run on the split-operand kernels (roof 416.7); against the flop-weighted roof "
+                           "1 / (2/3 / 157.3 + 1/3 / 416.7) = 198.4 TFLOP/s the fraction is frac x 0.793"
                            if args.model == "midas2" and args.backend == "hip" else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)")),
             "frac_of_fp32_mfma_peak": round(ach_tf / MFMA_FP32_PEAK_TFLOPS, 4),
-            "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r03.txt (SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES per kernel family), "
-                                "profiles/conv_roofline_r03.txt (per launch)"}
+            "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r04.txt (SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES per kernel family), "
+                                "profiles/conv_roofline_r04.txt (per launch)"}
         in_step_ms = float(np.mean(ms_step)) if len(ms_step) else None
         if in_step_ms:
             ach = LOSS_BYTES_PER_PAIR_PX * px * B / (in_step_ms * 1e-3) / 1e9
