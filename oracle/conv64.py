@@ -13,6 +13,11 @@ the filter:
 Pure restatement of torch.nn.functional.conv2d(x, w, b, padding=(k-1)//2) for stride 1 / odd square kernels -- checked against
 it, values and gradients, in tests/test_oracle_properties_cpu.py.  Only used for float64 tensors (oracle/hourglass_ref.py
 dispatches); fp32 keeps torch's mkldnn convolution.  Nothing here is reachable from consistent_depth_amd/.
+
+OPT-IN (`ENABLED`, set by oracle/gen_golden_loop_384.py): measured 5.2x faster than torch's double conv2d on the 8-core build
+container (2 images of 384x224, forward + backward: 76 s -> 14.6 s), but 2x SLOWER on the many-core host of the GPU box, where
+torch's own loop nest parallelises over more cores than the unfold copies here do (tests/test_finetune_gpu.py's fp64 reference:
+~250 s -> 544 s) -- so the tests on the GPU box keep torch's convolution.
 """
 import torch
 import torch.nn.functional as F
@@ -72,9 +77,12 @@ class _Conv64(torch.autograd.Function):
         return dx, dw, db
 
 
+ENABLED = False
+
+
 def conv2d_same(x, w, b=None):
     """F.conv2d(x, w, b, padding=(k - 1) // 2), stride 1, odd square kernel; float64 on the CPU goes through dgemm."""
     k = w.shape[-1]
-    if x.dtype == torch.float64 and x.device.type == "cpu" and w.shape[-2] == k and k % 2 == 1:
+    if ENABLED and x.dtype == torch.float64 and x.device.type == "cpu" and w.shape[-2] == k and k % 2 == 1:
         return _Conv64.apply(x, w, b)
     return F.conv2d(x, w, b, padding=(k - 1) // 2)

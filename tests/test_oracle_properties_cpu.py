@@ -77,13 +77,20 @@ def test_fp64_gemm_convolution_of_the_oracle_is_conv2d(N, Ci, Co, k, H, W):
     torch.nn.functional.conv2d(padding=(k-1)//2): values and all three gradients, to fp64 round-off."""
     import torch
     import torch.nn.functional as F
+    from oracle import conv64
     from oracle.conv64 import conv2d_same
     g = torch.Generator().manual_seed(N * 100 + k)
     x = torch.randn(N, Ci, H, W, dtype=torch.float64, generator=g).requires_grad_(True)
     w = torch.randn(Co, Ci, k, k, dtype=torch.float64, generator=g).requires_grad_(True)
     b = torch.randn(Co, dtype=torch.float64, generator=g).requires_grad_(True)
     dy = torch.randn(N, Co, H, W, dtype=torch.float64, generator=g)
-    y1 = conv2d_same(x, w, b)
+    assert not conv64.ENABLED          # opt-in (the golden generator switches it on): off, conv2d_same IS F.conv2d
+    conv64.ENABLED = True
+    try:
+        y1 = conv2d_same(x, w, b)
+        assert y1.grad_fn is not None and "Conv64" in type(y1.grad_fn).__name__
+    finally:
+        conv64.ENABLED = False
     y2 = F.conv2d(x, w, b, padding=(k - 1) // 2)
     g1, g2 = torch.autograd.grad(y1, (x, w, b), dy), torch.autograd.grad(y2, (x, w, b), dy)
     assert float((y1 - y2).abs().max()) < 1e-12 * max(1.0, float(y2.abs().max()))
