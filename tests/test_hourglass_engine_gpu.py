@@ -26,11 +26,12 @@ def test_engine_matches_autograd(N, H, W):
     from consistent_depth_amd.monodepth.hourglass import HourglassModel
     from consistent_depth_amd.monodepth.hourglass_engine import HourglassEngine
     bg = conftest.background_engine_reference() if N == 8 else None
-    # The fp64 autograd reference of 8 images at 384x224 keeps ~25 GB of activations.  A host with less than 32 GB free FAILS this
-    # test (it is the only whole-network gradient check at the headline shape; a silent skip on the driver's box would read as
-    # "covered").  CD_AMD_ALLOW_MEM_SKIP=1 turns the failure into a skip on a small development host.
+    # The fp64 autograd reference of 8 images at 384x224 keeps ~25 GB of activations and peaks well above that (a GPU box was lost
+    # in round 4 when the bar was lowered to 32 GB: a host that dies takes the whole run with it).  A host with less than 48 GB free
+    # FAILS this test (it is the only whole-network gradient check at the headline shape; a silent skip on the driver's box would
+    # read as "covered").  CD_AMD_ALLOW_MEM_SKIP=1 turns the failure into a skip on a small development host.
     def no_memory():
-        msg = "less than 32 GB of free host memory: the fp64 reference at the BASELINE shape (8x384x224) cannot run"
+        msg = "less than 48 GB of free host memory: the fp64 reference at the BASELINE shape (8x384x224) cannot run"
         if os.environ.get("CD_AMD_ALLOW_MEM_SKIP") == "1":
             pytest.skip(msg)
         pytest.fail(msg + " (CD_AMD_ALLOW_MEM_SKIP=1 skips instead)")
@@ -38,7 +39,7 @@ def test_engine_matches_autograd(N, H, W):
         no_memory()
     if N * H * W > 100000 and bg is None:
         import psutil
-        if psutil.virtual_memory().available < 32e9:
+        if psutil.virtual_memory().available < 48e9:
             no_memory()
     torch.manual_seed(0)
     ref = HourglassModel().double()
