@@ -77,7 +77,9 @@ class _Conv64(torch.autograd.Function):
         return dx, dw, db
 
 
-ENABLED = False
+import os
+
+ENABLED = os.environ.get("CD_ORACLE_CONV64", "0") == "1"
 
 
 def conv2d_same(x, w, b=None):

@@ -12,8 +12,28 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU box shows 256 cores and grants 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # CPU references (fp64 hourglass, oracle loops) with as many threads as the cgroup grants: torch's default is the number of
+    # cores it SEES (256 on the GPU box, of which the container may use 16) -- oversubscribed OpenMP / MKL teams crawl
+    try:
+        import torch
+        if torch.get_num_threads() > usable_cores():       # only ever DOWN: fewer threads than torch's default would change the
+            torch.set_num_threads(usable_cores())          # summation order of the fp32 goldens produced with the default
+    except ImportError:
+        pass
 
 
 _BG = {}
@@ -29,7 +49,7 @@ def pytest_collection_finish(session):
     if len(session.items) < 20:       # run on its own: nothing to overlap with, the test computes inline
         return
     dst = os.path.join(tempfile.mkdtemp(prefix="cd_bg_"), "engine_ref_8x384x224.npz")
-    threads = max(2, (os.cpu_count() or 8) // 2)
+    threads = max(2, usable_cores() // 2)
     proc = subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "bg_reference.py"), dst, str(threads)],
                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
     _BG["engine_ref"] = (proc, dst)
