@@ -198,3 +198,40 @@ def test_a_captured_collective_does_not_fall_back(monkeypatch):
     for expected in (1.0, 2.0, 3.0):
         assert g(img, m)[0].item() == expected
     assert g.graphed is False and st.calls == 3
+
+
+def test_engine_reference_golden_matches_the_network_it_is_for():
+    """tests/golden/engine_ref_8x384x224.npz (tests/bg_reference.py --golden): one sampled fp32 array per parameter gradient of the
+    hourglass, the sampled prediction, the full BatchNorm running statistics -- keyed and sized for the network
+    tests/test_hourglass_engine_gpu.py::test_engine_matches_autograd builds, with the sampling rule the test applies to the engine's tensors."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bg_reference as R
+    from consistent_depth_amd.monodepth.hourglass import HourglassModel
+    g = R.load_golden()
+    assert g is not None and int(g["sampled"]) == R.SAMPLE
+    net = HourglassModel()
+    n_grad = 0
+    for name, p in net.named_parameters():
+        key = "grad:" + name
+        if name.startswith("uncertainty_layer"):
+            assert key not in g                                   # the unused head receives no gradient
+            continue
+        assert key in g, name
+        want = R.sample(torch.zeros(p.numel())).shape[0]
+        assert g[key].shape == (want,) and g[key].dtype == np.float32 and np.isfinite(g[key]).all(), name
+        assert want >= min(p.numel(), R.SAMPLE)
+        n_grad += 1
+    assert n_grad == len([k for k in g if k.startswith("grad:")]) > 300
+    assert g["pred"].shape == (R.sample(torch.zeros(R.N * R.H * R.W)).shape[0],) and np.abs(g["pred"]).max() > 0
+    stats = [k for k in g if k.startswith("stat:")]
+    sd = net.state_dict()
+    assert len(stats) == 2 * 155
+    for k in stats:
+        assert g[k].shape == tuple(sd[k[len("stat:"):]].shape)
+    # numpy and torch sample alike
+    a = np.arange(100000, dtype=np.float32)
+    assert np.array_equal(R.sample(a), R.sample(torch.as_tensor(a)).numpy())

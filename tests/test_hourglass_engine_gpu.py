@@ -19,13 +19,18 @@ def _rel(a, b):
 def test_engine_matches_autograd(N, H, W):
     """The last two cases run at the BASELINE resolution (384x224): the XCD-aware tile mapping, the level streams, the timed
     launch shapes and the wide-1x1 / few-input-channel weight-gradient plans only exist at this size.  The fp64 CPU reference
-    of the full BS4 batch of 8 images takes ~5 minutes of host time: in a full GPU session conftest.py computes it in a
-    background process (tests/bg_reference.py) while the other tests run; on its own the test computes it inline."""
+    of the full BS4 batch of 8 images takes ~5 minutes of host time and tens of GB: it is a committed golden
+    (tests/golden/engine_ref_8x384x224.npz, written by tests/bg_reference.py --golden from the seeds used here; every tensor
+    sampled as flat[::stride], the engine's tensors are sampled the same way below); CD_AMD_TEST_LIVE_ENGINE_REF=1 computes it
+    live instead (background process in a full session, inline on its own)."""
     import torch
     import conftest
     from consistent_depth_amd.monodepth.hourglass import HourglassModel
     from consistent_depth_amd.monodepth.hourglass_engine import HourglassEngine
+    import bg_reference
     bg = conftest.background_engine_reference() if N == 8 else None
+    sampled = isinstance(bg, dict) and "sampled" in bg
+    pick = (lambda t: bg_reference.sample(t)) if sampled else (lambda t: t)      # the golden holds flat[::stride] of every tensor
     # The fp64 autograd reference of 8 images at 384x224 keeps ~25 GB of activations and peaks well above that (a GPU box was lost
     # in round 4 when the bar was lowered to 32 GB: a host that dies takes the whole run with it).  A host with less than 48 GB free
     # FAILS this test (it is the only whole-network gradient check at the headline shape; a silent skip on the driver's box would
@@ -64,7 +69,7 @@ def test_engine_matches_autograd(N, H, W):
         p.grad = torch.zeros_like(p)
     pred = eng.forward(x.float().cuda())
     assert pred.requires_grad
-    assert _rel(pred.cpu(), pred_ref.detach()) < 2e-4
+    assert _rel(pick(pred.detach().cpu()), pred_ref.detach()) < 2e-4
     pred.backward(dpred.float().cuda())
     torch.cuda.synchronize()
     # fp32 noise floor of autograd itself on this (deep, BatchNorm-heavy) network: same net in fp32 on the CPU
@@ -88,7 +93,7 @@ def test_engine_matches_autograd(N, H, W):
             assert p.grad.abs().max().item() == 0.0
             continue
         # torch-fp32 autograd at 8x384x224, measured once (profiles/parity_engine_r02.txt): median 1.07e-2, worst 1.25e-2
-        errs.append((_rel(p.grad.cpu(), g), _rel(g32[name].grad, g) if g32 is not None else 1.07e-2, name))
+        errs.append((_rel(pick(p.grad.cpu()), g), _rel(g32[name].grad, g) if g32 is not None else 1.07e-2, name))
     errs.sort(reverse=True)
     for e, e32, name in errs[:8]:
         print(f"  {name:45s} engine {e:.2e}   torch-fp32 {e32:.2e}")
@@ -111,8 +116,8 @@ def test_engine_matches_autograd(N, H, W):
     for k, v in stat_ref.items():
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
     from gpu_util import report
-    report(f"engine_vs_fp64_autograd[{N}x{H}x{W}]", pred_rel_l1=_rel(pred.detach().cpu(), pred_ref.detach()), grad_median=med,
-           grad_worst=errs[0][0], torch_fp32_grad_median=med32, background_reference=bg is not None)
+    report(f"engine_vs_fp64_autograd[{N}x{H}x{W}]", pred_rel_l1=_rel(pick(pred.detach().cpu()), pred_ref.detach()), grad_median=med,
+           grad_worst=errs[0][0], torch_fp32_grad_median=med32, reference="golden (sampled)" if sampled else ("background" if bg is not None else "inline"))
 
 
 def test_engine_under_both_conv_arithmetics():
