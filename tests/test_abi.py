@@ -114,3 +114,63 @@ def test_packed_filter_holds_every_layout():
         assert sizes[0] == sizes[1] == sizes[2] and all(v > 0 for v in sizes[0])
     finally:
         lib.cd_set_conv_arith(before)
+
+
+def test_host_record_layouts_match_the_public_header(tmp_path):
+    """Every struct the Python host fills byte by byte (numpy record types, ctypes.Structure) against the C layout of
+    include/consistent_depth_amd.h -- compiled with gcc as plain C (the header needs no HIP): size and the offset of EVERY field.
+    (Round 4 shipped a 124-byte record for a 128-byte struct to the GPU box once; this catches that on the CPU.)"""
+    import ctypes
+    import re
+    import subprocess
+    import numpy as np
+    from consistent_depth_amd.loaders import pair_store
+    from consistent_depth_amd.ops import conv
+    hdr = open(os.path.join(REPO, "include", "consistent_depth_amd.h")).read()
+
+    def c_fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = decl.split(",")
+            names.append(re.sub(r"\[.*\]", "", first.split()[-1].lstrip("*")))
+            names += [re.sub(r"\[.*\]", "", r.strip().lstrip("*")) for r in rest]
+        return names
+
+    records = {
+        "cd_conv_desc": np.dtype(conv._CONV_DESC_DT),
+        "cd_wgrad_desc": np.dtype(conv.WgradTable._DT),
+        "cd_unpack_desc": np.dtype(conv.UnpackTable._DT),
+        "cd_pack_desc": np.dtype(conv.PackTable._DT),
+    }
+    structs = {"cd_pair_store": pair_store._StoreDesc, "cd_pair_batch": pair_store._BatchDesc}
+    src = ["#include <stdio.h>", "#include <stddef.h>", "#include <stdint.h>", '#include "consistent_depth_amd.h"', "int main(void) {"]
+    for s in list(records) + list(structs):
+        src.append(f'printf("{s} size %zu\\n", sizeof({s}));')
+        for f in c_fields(s):
+            src.append(f'printf("{s} {f} %zu\\n", offsetof({s}, {f}));')
+    src += ["return 0; }"]
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(tmp_path / "layout.c"), "-o", str(tmp_path / "layout")])
+    out = subprocess.check_output([str(tmp_path / "layout")], text=True)
+    c = {}
+    for line in out.splitlines():
+        s, f, v = line.split()
+        c.setdefault(s, []).append((f, int(v)))
+    for s, dt in records.items():
+        assert dt.itemsize == dict(c[s])["size"], (s, dt.itemsize, dict(c[s])["size"])
+        offs = [v for f, v in c[s] if f != "size"]
+        mine = [dt.fields[n][1] for n in dt.names]
+        # one numpy field per C field, in order, at the same offsets; a C array field (cd_wgrad_desc.pad[2]) is several consecutive
+        # numpy fields: every C offset must be a numpy offset, and the numpy fields in between must be 4-byte ints that tile the gap
+        assert offs == sorted(offs) and mine == sorted(mine) and set(offs) <= set(mine), (s, offs, mine)
+        assert [o for o in mine if o in set(offs)] == offs, (s, offs, mine)
+        for a, b in zip(mine, mine[1:] + [dt.itemsize]):
+            assert b - a == dt.fields[dt.names[mine.index(a)]][0].itemsize, (s, a, b)       # no holes, no overlaps
+    for s, st in structs.items():
+        assert ctypes.sizeof(st) == dict(c[s])["size"], s
+        assert [getattr(st, n).offset for n, _ in st._fields_] == [v for f, v in c[s] if f != "size"], s
