@@ -27,8 +27,10 @@ into a HIP graph (consistent_depth_amd/engine.py::GraphedFineTuneStep).
 
 Launch economy: one launch re-packs all filters per step, one writes all weight gradients at the end of the
 backward, the BatchNorm passes of adjacent channel slices of an inception share launches ([m1|m2|m3|b0] and
-[o1|o2|o3]; their running statistics are views of contiguous buffers), and each convolution's launch shape is
-timed once per distinct shape (ops/conv.py::tuned_config).
+[o1|o2|o3]; their running statistics are views of contiguous buffers), each convolution's launch shape is
+timed once per distinct shape (ops/conv.py::tuned_config), and the three k x k branch convolutions of an inception
+run as ONE dispatch, forward and input gradient (cd_conv2d_fwd_multi: the branch is a grid dimension; chosen per
+inception by timing it against the branches' own launches, ops/conv.py::tuned_multi; bit-identical either way).
 
 No autograd tape is built for the network: the backward pass is the explicit reverse walk of the plan.
 Towards PyTorch the engine is ONE autograd node: forward(x) returns pred_d attached to the graph, and
