@@ -200,6 +200,49 @@ def test_bucketed_allreduce_overlaps_backward_and_matches_the_global_batch():
     assert dict(out) == {0: True, 1: True}
 
 
+def _one_rank_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = []
+    orig = dist.all_reduce
+
+    def counting(t, *a, **kw):
+        calls.append(t.numel())
+        return orig(t, *a, **kw)
+    dist.all_reduce = counting
+    try:
+        assert parallel.collective_active()
+        buf = torch.arange(5.0)
+        parallel.allreduce_sum_(buf)                                   # the flat path
+        net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+        opt = _FlatStandIn(list(net.parameters()))
+        buckets = parallel.GradBuckets(opt, n_buckets=2)
+        loss = net(torch.randn(4, 6)).pow(2).mean()
+        opt.loss_slot.copy_(loss.detach().reshape(1))
+        before = opt.loss_slot.clone()
+        buckets.arm()
+        loss.backward()
+        buckets.finish()                                               # the bucketed path: 2 buckets + the loss slot
+        buckets.close()
+        hooks_gone = buckets._handles == []
+    finally:
+        dist.all_reduce = orig
+    out[0] = (calls[0] == 5 and len(calls) == 4 and sorted(calls[1:])[0] == 1 and torch.equal(buf, torch.arange(5.0))
+              and torch.equal(before, opt.loss_slot) and hooks_gone)
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_runs_the_collectives_of_both_exchange_paths():
+    """ONE predicate (parallel.collective_active): with a process group of a single rank the flat all-reduce AND the bucketed one
+    (gradient buckets + loss slot) issue their collectives -- that is how the RCCL launches of a captured step are exercised on a
+    one-GPU box; round 3's bucketed path skipped them for world == 1 while the flat path did not."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_rank_worker, args=(1, port, out), nprocs=1, join=True)
+    assert dict(out) == {0: True}
+
+
 def test_bench_epoch_plans_deal_disjoint_full_batches_to_the_ranks():
     """bench.py's schedule (EpochPlans over parallel.shard_indices): at every step the ranks hold disjoint pairs of ONE shared
     permutation, all batches are full (one graph signature), and every rank sees the same number of steps per epoch -- so the ranks
