@@ -178,3 +178,38 @@ def test_emulated_sweep_nan_and_range_go_through_the_overflow_list(oracle):
     batch["depth"][0, 0, 5, 5] = np.nan
     e = E.loss(batch, 1.0, 0.1, pxt=2)
     assert np.isnan(e["total"][0]) and np.isnan(e["grad_depth"][0, 0, 5, 5])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_service_wave_assignment_is_bit_identical(oracle, mode):
+    """Round 4: at a geometry with an idle wave per frame (W = 224, two pixels per thread) the rows entering / leaving a ring are
+    handled by that wave for the whole frame (svc_load / svc_stage / svc_flush) instead of by every thread for its own columns.
+    Same per-element arithmetic, so everything must come out bit for bit: all three depth heads, the slow path of wild flows, the
+    overflow list of out-of-range values, the degenerate flag of a non-positive depth (which the SERVICE wave now raises: it is
+    the one that sees the staged depths), NaN propagation."""
+    from consistent_depth_amd import synthetic
+    base = synthetic.make_scene_batch(2, 96, 224, seed=4)
+    wild = synthetic.make_pair_batch(1, 64, 224, seed=5, noise_px=30.0)
+    conv = {0: lambda d: d, 1: np.log, 2: lambda d: 1.0 / d}[mode]
+    cases = [("scene", dict(base, depth=conv(base["depth"].astype(np.float64)).astype(np.float32))),
+             ("wild", dict(wild, depth=conv(wild["depth"].astype(np.float64)).astype(np.float32)))]
+    big = dict(base, depth=base["depth"].copy())
+    big["depth"][0, 1, 30:34, 100:104] = 1e-4                       # contributions far outside the fixed-point range
+    cases.append(("range", dict(big, depth=conv(big["depth"].astype(np.float64)).astype(np.float32))))
+    bad = dict(base, depth=conv(base["depth"].astype(np.float64)).astype(np.float32))
+    bad["depth"] = bad["depth"].copy()
+    bad["depth"][1, 0, 50, 60] = {0: -1.0, 1: np.inf, 2: 0.0}[mode]  # a depth that is not a positive finite number -> degenerate flag
+    cases.append(("degenerate", bad))
+    nan = dict(base, depth=conv(base["depth"].astype(np.float64)).astype(np.float32).copy())
+    nan["depth"][0, 0, 7, 9] = np.nan
+    cases.append(("nan", nan))
+    for name, batch in cases:
+        a = E.loss(batch, 1.0, 0.1, mode=mode, pxt=2)
+        b = E.loss(batch, 1.0, 0.1, mode=mode, pxt=2, service=True)
+        for k in ("total", "reprojection", "disparity", "grad_depth"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{name} {k}")
+        assert (a["degenerate"], a["overflow_entries"], a["slow_lanes"]) == (b["degenerate"], b["overflow_entries"], b["slow_lanes"]), name
+        if name == "degenerate":
+            assert a["degenerate"]
+        if name == "range" and mode != 2:      # (the reciprocal head's units, estimated from the data, absorb this case)
+            assert a["overflow_entries"] > 0
