@@ -24,6 +24,14 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+if (os.cpu_count() or 1) > usable_cores():
+    # A container that sees more cores than it is granted (the GPU box: 256 / 16): OpenMP / MKL teams sized by the visible cores crawl
+    # under the CPU quota (round 4: a 2-pair 64x48 fp64 reference took 213 s).  Set before torch is imported, inherited by the
+    # subprocesses the multi-rank tests start.  Untouched where the two agree (the build container: the goldens' thread count).
+    for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(_v, str(usable_cores()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # CPU references (fp64 hourglass, oracle loops) with as many threads as the cgroup grants: torch's default is the number of
