@@ -235,3 +235,61 @@ def test_engine_reference_golden_matches_the_network_it_is_for():
     # numpy and torch sample alike
     a = np.arange(100000, dtype=np.float32)
     assert np.array_equal(R.sample(a), R.sample(torch.as_tensor(a)).numpy())
+
+
+def test_wgrad_table_orders_heaviest_first_and_accumulates_block_ranges(monkeypatch):
+    """ops/conv.py::WgradTable.build(): descriptors grouped by kernel class, inside a class ordered by the work of ONE workgroup
+    (image tiles it walks x taps) descending -- workgroups are dispatched in table order, the long ones must not start last --, block_end =
+    running sum of the members' workgroup counts, at most 64 descriptors per launch.  (The descriptors themselves come from the C library:
+    injected here.)"""
+    import numpy as np
+    import torch
+    from consistent_depth_amd.ops import conv
+    t = conv.WgradTable(torch.device("cpu"))
+    rng = np.random.default_rng(0)
+
+    def desc(klass, ks, N, tiles_x, tiles_y, splits, blocks):
+        d = np.zeros(1, np.dtype(conv.WgradTable._DT))
+        d[0]["klass"], d[0]["ks"], d[0]["N"], d[0]["tiles_x"], d[0]["tiles_y"], d[0]["splits"], d[0]["blocks"] = klass, ks, N, tiles_x, tiles_y, splits, blocks
+        return d
+    members = [desc(3, 7, 8, 7, 64, 64, 512), desc(3, 7, 8, 1, 3, 24, 192), desc(3, 7, 8, 4, 19, 64, 512), desc(0, 3, 8, 7, 64, 128, 512)]
+    members += [desc(2, 5, 8, 2, 5, int(rng.integers(8, 64)), int(rng.integers(64, 512))) for _ in range(70)]
+    t._descs = [members[i] for i in rng.permutation(len(members))]
+    launches = []
+    monkeypatch.setattr(torch, "from_numpy", lambda a: _Keep(a, launches))
+    t.build()
+    by_class = {}
+    for klass, tab, n, total in t._launches:
+        by_class.setdefault(klass, []).append((tab.array, n, total))
+    assert sorted(by_class) == [0, 2, 3]
+    assert [n for _, n, _ in by_class[2]] == [64, 6]                      # 70 descriptors of class 2: two launches
+    for klass, parts in by_class.items():
+        for arr, n, total in parts:
+            rec = arr.view(np.dtype(conv.WgradTable._DT))
+            assert len(rec) == n and list(rec["block_end"]) == list(np.cumsum(rec["blocks"])) and total == int(rec["block_end"][-1])
+            assert set(rec["klass"]) == {klass}
+            work = [-(-(int(r["N"]) * int(r["tiles_x"]) * int(r["tiles_y"])) // int(r["splits"])) * int(r["ks"]) ** 2 for r in rec]
+            if len(parts) == 1:
+                assert work == sorted(work, reverse=True)
+
+
+class _Keep:
+    """Stand-in for the uploaded table: keeps the host bytes (`.to()` returns itself)."""
+
+    def __init__(self, array, log):
+        self.array = array
+        log.append(self)
+
+    def to(self, *_a, **_k):
+        return self
+
+
+def test_merged_dispatch_is_off_without_autotune(monkeypatch):
+    """ops/conv.py::tuned_multi takes a decision only by timing; with the autotuner disabled (or CD_AMD_CONV_MULTI=0) it returns None
+    without touching the device: the engine then launches the branches one by one."""
+    from consistent_depth_amd.ops import conv
+    monkeypatch.setenv("CD_AMD_CONV_AUTOTUNE", "0")
+    assert conv.tuned_multi([], []) is None
+    monkeypatch.setenv("CD_AMD_CONV_AUTOTUNE", "1")
+    monkeypatch.setenv("CD_AMD_CONV_MULTI", "0")
+    assert conv.tuned_multi([], []) is None
