@@ -125,8 +125,8 @@ def test_run_level_parity_after_burn_in():
     BatchNorm statistics and Adam moments after a burn-in (Adam's first steps are sign-like, m/sqrt(v) = +-1: every weight
     whose gradient is at fp32 noise level moves by a full +-lr in a random direction -- the random-init start of the test
     above measures that, not the kernels).  From that state the GPU engine and the CPU restatement of the reference step
-    (oracle/cpu_step.py, fp64) run the same T steps at the BASELINE size (4 pairs of 384x224); the reference's own fp32 run
-    is the yardstick printed next to it."""
+    (oracle/cpu_step.py, fp64) run the same T steps at the BASELINE image size (384x224; 2 pairs by default, the BASELINE batch of 4 with
+    CD_AMD_TEST_FULL_BASELINE=1 -- see below); the reference's own fp32 run is the yardstick printed next to it."""
     import argparse
     import torch
     from consistent_depth_amd import synthetic
