@@ -24,12 +24,19 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def reference_threads() -> int:
+    """Threads for the CPU references: torch's default where the visible cores are all usable (the build container: the thread count the
+    fp32 goldens were produced with); under a CPU quota (the GPU box: 256 visible / 16 granted) the quota minus two -- a team that
+    burns the whole quota gets the entire cgroup throttled, the box's own agent included."""
+    u = usable_cores()
+    return u if (os.cpu_count() or 1) <= u else max(1, u - 2)
+
+
 if (os.cpu_count() or 1) > usable_cores():
-    # A container that sees more cores than it is granted (the GPU box: 256 / 16): OpenMP / MKL teams sized by the visible cores crawl
-    # under the CPU quota (round 4: a 2-pair 64x48 fp64 reference took 213 s).  Set before torch is imported, inherited by the
-    # subprocesses the multi-rank tests start.  Untouched where the two agree (the build container: the goldens' thread count).
+    # OpenMP / MKL teams sized by the visible cores crawl under the CPU quota (round 4: a 2-pair 64x48 fp64 reference took 213 s).
+    # Set before torch is imported, inherited by the subprocesses the multi-rank tests start.
     for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(_v, str(usable_cores()))
+        os.environ.setdefault(_v, str(reference_threads()))
 
 
 def pytest_configure(config):
@@ -38,8 +45,8 @@ def pytest_configure(config):
     # cores it SEES (256 on the GPU box, of which the container may use 16) -- oversubscribed OpenMP / MKL teams crawl
     try:
         import torch
-        if torch.get_num_threads() > usable_cores():       # only ever DOWN: fewer threads than torch's default would change the
-            torch.set_num_threads(usable_cores())          # summation order of the fp32 goldens produced with the default
+        if torch.get_num_threads() > reference_threads():  # only ever DOWN: fewer threads than torch's default would change the
+            torch.set_num_threads(reference_threads())     # summation order of the fp32 goldens produced with the default
     except ImportError:
         pass
 
