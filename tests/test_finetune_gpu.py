@@ -181,7 +181,18 @@ def test_run_level_parity_after_burn_in():
     def cpu(dtype):
         ft = cpu_step.CpuFineTuner(state, lr=4e-4, lambda_r=1.0, lambda_b=0.1, dtype=dtype)
         ft.set_adam_state(m1, m2, k0)
-        losses = [float(ft.step(images, b)[0]["total"][0]) for images, b in run]
+        import time
+        import conftest
+        losses = []
+        for i, (images, b) in enumerate(run):
+            t0 = time.monotonic()
+            losses.append(float(ft.step(images, b)[0]["total"][0]))
+            # the suite's time budget (tests/conftest.py): the first step calibrates this host; what is left = the other steps + the probe
+            need, left = (time.monotonic() - t0) * (len(run) - 1 - i + 0.3), conftest.budget_left()
+            if need > left:
+                pytest.skip(f"time budget: the fp64 CPU reference needs another ~{need:.0f} s on this host, {left:.0f} s are left "
+                            f"(the headline-shape criterion is asserted by test_loop_gpu.py::test_epochs_at_the_headline_shape_within_1e_3 "
+                            f"against the committed fp64 golden; CD_AMD_TEST_BUDGET_S=0 runs this test regardless)")
         x = torch.as_tensor(probe_images, dtype=dtype).reshape(-1, 3, PH, PW)
         with torch.no_grad():
             pred, _ = hourglass_ref.forward(ft.state, x, training=True, update_running_stats=False)

@@ -293,3 +293,31 @@ def test_merged_dispatch_is_off_without_autotune(monkeypatch):
     monkeypatch.setenv("CD_AMD_CONV_AUTOTUNE", "1")
     monkeypatch.setenv("CD_AMD_CONV_MULTI", "0")
     assert conv.tuned_multi([], []) is None
+
+
+def test_gpu_suite_runs_the_live_cpu_references_last_and_within_the_budget(monkeypatch):
+    """tests/conftest.py: the three tests whose cost is a live CPU reference on the GPU box's host go to the end of the session, cheapest
+    first, and are skipped -- with the numbers in the reason -- only when the time left cannot hold their estimate."""
+    import conftest
+
+    class Item:
+        def __init__(self, nodeid):
+            self.nodeid = nodeid
+    heavy = ["tests/" + k for k in conftest._HEAVY]
+    ids = [heavy[2], "tests/test_a_gpu.py::test_x", heavy[0], "tests/test_b_gpu.py::test_y[hip]", heavy[1], "tests/test_c_gpu.py::test_z"]
+    out = [it.nodeid for it in conftest.order_heavy_last([Item(i) for i in ids])]
+    assert out[:3] == [ids[1], ids[3], ids[5]]                                   # the others keep their order
+    assert out[3:] == sorted(heavy, key=conftest._heavy_cost)                    # cheapest first
+    # a parametrisation that is not in the table is not heavy
+    assert conftest._heavy_cost("tests/test_finetune_gpu.py::test_short_finetune_matches_cpu_reference[torch]") == 0
+    cost = conftest._heavy_cost(heavy[2])
+    assert conftest.budget_verdict(heavy[2], 1050 - cost, 1050) is None
+    why = conftest.budget_verdict(heavy[2], 1050 - cost + 1, 1050)
+    assert why and "time budget" in why and str(cost) in why
+    assert conftest.budget_verdict(heavy[2], 5000, 0) is None                    # CD_AMD_TEST_BUDGET_S=0: no guard
+    assert conftest.budget_verdict("tests/test_a_gpu.py::test_x", 5000, 1050) is None
+    assert sum(conftest._HEAVY.values()) + 330 < 1200                            # the estimates plus the rest of the suite (~290 s) fit the driver's 1200 s
+    monkeypatch.setenv("CD_AMD_TEST_BUDGET_S", "0")
+    assert conftest.budget_left() == float("inf")
+    monkeypatch.setenv("CD_AMD_TEST_BUDGET_S", "100000")
+    assert 0 < conftest.budget_left() < 100000                                    # counts from the start of the interpreter
