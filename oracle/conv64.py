@@ -14,11 +14,14 @@ Pure restatement of torch.nn.functional.conv2d(x, w, b, padding=(k-1)//2) for st
 it, values and gradients, in tests/test_oracle_properties_cpu.py.  Only used for float64 tensors (oracle/hourglass_ref.py
 dispatches); fp32 keeps torch's mkldnn convolution.  Nothing here is reachable from consistent_depth_amd/.
 
-OPT-IN (`ENABLED`, set by oracle/gen_golden_loop_384.py): measured 5.2x faster than torch's double conv2d on the 8-core build
-container (2 images of 384x224, forward + backward: 76 s -> 14.6 s), but 2x SLOWER on the many-core host of the GPU box, where
-torch's own loop nest parallelises over more cores than the unfold copies here do (tests/test_finetune_gpu.py's fp64 reference:
-~250 s -> 544 s) -- so the tests on the GPU box keep torch's convolution.
+OPT-IN (`ENABLED` / CD_ORACLE_CONV64=1, set by oracle/gen_golden_loop_384.py): measured 5.2x faster than torch's double conv2d on the
+8-core build container (2 images of 384x224, forward + backward: 76 s -> 14.6 s), but 2x SLOWER in the one run on the GPU box
+(tests/test_finetune_gpu.py's fp64 reference: ~250 s -> 544 s).  That run had OpenMP / MKL teams of 256 threads (the visible cores)
+against a cgroup quota of 16 CPUs -- found afterwards, tests/conftest.py now caps the teams -- so the slowdown may have been dgemm
+thrashing rather than the formulation; not re-measured with the capped teams, hence off by default on the GPU box.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -76,8 +79,6 @@ class _Conv64(torch.autograd.Function):
             db = dy.sum((0, 2, 3))
         return dx, dw, db
 
-
-import os
 
 ENABLED = os.environ.get("CD_ORACLE_CONV64", "0") == "1"
 
