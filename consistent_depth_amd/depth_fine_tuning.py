@@ -94,6 +94,19 @@ class DepthFineTuner:
         print(f"Using {self.world} GPUs (one process each); global batch {params.batch_size * self.world}.")
         self.store = store
         self.seed = getattr(params, "seed", 0)
+        self._resume = None
+
+    def resume_from(self, state_dict, exp_avg, exp_avg_sq, adam_steps: int, epoch: int, total_iters: int):
+        """EXTENSION (the reference cannot resume): the next fine_tune() continues a run at the START of `epoch` -- network weights
+        and BatchNorm buffers from `state_dict` (a checkpoints/%04d.pth), the Adam moments as {parameter name: tensor} dicts, the
+        number of optimiser steps taken and the `total_iters` (pairs) counter that names the validation files.  The validation
+        sweep before the first epoch is not repeated (it belongs to the end of epoch `epoch - 1`)."""
+        from .monodepth.hourglass import load_state_dict_any_prefix
+        net = self.model.netG if hasattr(self.model, "netG") else self.model.model
+        load_state_dict_any_prefix(net, state_dict)
+        names = [n for n, _ in net.named_parameters()]
+        self._resume = dict(m1=[exp_avg[n] for n in names], m2=[exp_avg_sq[n] for n in names], steps=int(adam_steps),
+                            epoch=int(epoch), total_iters=int(total_iters))
 
     # ------------------------------------------------------------------ depth export (:164-199)
     @torch.no_grad()
@@ -145,9 +158,17 @@ class DepthFineTuner:
             if self.rank == 0:
                 print(f"Done Validation for epoch {epoch} ({niters} iterations)")
 
-        validate(0, 0)
-        total_iters = 0
-        for epoch in range(p.num_epochs):
+        first_epoch, total_iters = 0, 0
+        if self._resume is not None:
+            r, self._resume = self._resume, None
+            base = getattr(step, "step", step)
+            by_id = {id(q): i for i, q in enumerate(self.model.parameters())}
+            order = [by_id[id(q)] for q in base.opt._params]      # FlatAdam's parameter order (= model.parameters() order)
+            base.opt.load_moments([r["m1"][i] for i in order], [r["m2"][i] for i in order], r["steps"])
+            first_epoch, total_iters = r["epoch"], r["total_iters"]
+        else:
+            validate(0, 0)
+        for epoch in range(first_epoch, p.num_epochs):
             t0 = time.perf_counter()
             plan = self.epoch_plan(epoch)
             plan_dev = parallel.plan_to_device(plan, store.device)   # the epoch's index lists: uploaded once

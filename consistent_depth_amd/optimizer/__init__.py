@@ -55,6 +55,20 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)  # device-side count (guarded steps)
         self.numel = sum(p.numel() for p in params)
 
+    @torch.no_grad()
+    def load_moments(self, exp_avg, exp_avg_sq, steps: int):
+        """Resume: the Adam moments (one tensor per parameter, in the order of the constructor's parameter list) and the number of
+        steps already taken.  (torch.optim.Adam keeps the same three things per parameter: `exp_avg`, `exp_avg_sq`, `step`.)"""
+        if len(exp_avg) != len(self._params) or len(exp_avg_sq) != len(self._params):
+            raise ValueError("FlatAdam.load_moments: one moment tensor per parameter")
+        for p, o, m1, m2 in zip(self._params, self._offsets, exp_avg, exp_avg_sq):
+            if m1.numel() != p.numel() or m2.numel() != p.numel():
+                raise ValueError("FlatAdam.load_moments: moment shape does not match its parameter")
+            self.exp_avg[o:o + p.numel()].copy_(m1.reshape(-1).to(self.exp_avg))
+            self.exp_avg_sq[o:o + p.numel()].copy_(m2.reshape(-1).to(self.exp_avg_sq))
+        self.step_count = int(steps)
+        self.step_dev.fill_(int(steps))
+
     def zero_grad(self, set_to_none: bool = False):
         # grads are views into the flat buffer: keep them bound, clear with one memset
         self._grad_store.zero_()

@@ -180,11 +180,12 @@ def make_scene_batch(B: int, H: int, W: int, seed: int = 0, noise_px: float = 0.
             "extrinsics": extr.astype(dtype)}
 
 
-def make_video(n_frames: int, H: int, W: int, seed: int = 0):
-    """A whole synthetic clip: colours (N,3,H,W) U[0,1), GT depth (N,H,W), cameras."""
+def make_video(n_frames: int, H: int, W: int, seed: int = 0, step: float = 0.01, max_angle: float = 0.15):
+    """A whole synthetic clip: colours (N,3,H,W) U[0,1), GT depth (N,H,W), cameras.  `step` / `max_angle` bound the camera motion
+    (small values keep every pixel of a frame inside the other frame of its pairs: a clip whose masks can cover everything)."""
     rng = np.random.default_rng(seed)
     K = clip_intrinsics(H, W)
-    extr = camera_path(n_frames, rng, step=0.01, max_angle=0.15)
+    extr = camera_path(n_frames, rng, step=step, max_angle=max_angle)
     surf = Surface(rng)
     depth = np.stack([render_depth(surf, K, extr[i], H, W) for i in range(n_frames)])
     color = rng.random((n_frames, 3, H, W), dtype=np.float32)

@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE ONLY.  Per-epoch parity at the HEADLINE shape: tests/golden/loop_16f_384x224.npz.
+"""TEST INFRASTRUCTURE ONLY.  Per-epoch parity at the HEADLINE shape over a FULL-LENGTH run (num_epochs = 20, the reference's
+default, /root/reference/depth_fine_tuning.py:52): tests/golden/loop_16f_384x224.npz and tests/golden/loop_dense8f_384x224.npz.
 
 BASELINE.json asks for "depth maps and per-epoch losses matching the reference PyTorch CPU path within 1e-3 relative L1".  The
 6-frame 64x48 loop golden (oracle/gen_golden_loop.py) pins the loop to the reference's own code; this file pins the NUMBERS at
-384x224, where fp64 ground truth costs about a minute per training step (oracle/conv64.py) and cannot be computed inside a GPU test:
+384x224, where fp64 ground truth costs about a minute per training step (oracle/conv64.py) and cannot be computed inside a GPU test.
+Two clips (SPECS):
 
-  stage 1  `snapshot <dir>`  (GPU box, through gpurun): the product's DepthFineTuner runs K burn-in epochs on the seeded 16-frame
-           384x224 clip from the seeded random init (from a random init Adam's first steps are sign-like and amplify round-off --
-           DESIGN.md section 2 -- so the 1e-3 budget is measured from a warm state); at the end of epoch K the weights, BatchNorm
-           buffers, Adam moments and step count are written to <dir>/snap384.npz (64 MB: scratch, never committed).
-  stage 2  `golden <dir>`    (build container, ~35 min of CPU): oracle/cpu_loop.py -- the reference's loop restated, pinned to
+  "a"      16 frames, 37 pairs, BS4: 10 steps per epoch; masks keep 70 % of the in-bounds pixels (the clip of every earlier golden).
+           K = 3 burn-in epochs, then T = 20 compared epochs = 200 steps + 20 validation sweeps + the export.
+  "dense"  8 frames, 15 pairs, 4 steps per epoch; small camera motion and mask_keep = 1: every pair's masks cover >= 95 % of the
+           pixels, i.e. (nearly) every pixel of every depth map is constrained by a valid flow.  K = 3, T = 10.  It answers whether the
+           depth-map drift seen on clip "a" belongs to pixels no valid flow constrains.
+
+  stage 1  `snapshot <spec> <dir>`  (GPU box, through gpurun): the product's DepthFineTuner runs K + T epochs on the seeded clip from
+           the seeded random init (from a random init Adam's first steps are sign-like and amplify round-off -- DESIGN.md section 2 --
+           so the 1e-3 budget is measured from a warm state); at the end of epoch K the weights, BatchNorm buffers, Adam moments and
+           step count are written to <dir>/snap_<spec>.npz (64 MB: scratch, never committed), the product's own artefacts of the
+           compared epochs to <dir>/product_<spec>.npz (for the curves of profiles/parity_20ep_r05.txt).
+  stage 2  `golden <spec> <dir>`    (build container, HOURS of CPU): oracle/cpu_loop.py -- the reference's loop restated, pinned to
            /root/reference's own DepthFineTuner by tests/test_reference_loop_live_cpu.py -- continues FROM THAT SNAPSHOT in fp64 for
-           T epochs over the same batches and writes every artefact of those epochs as the golden: eval/loss_e*.json (per pair and
-           mean), eval/depth_*.raw, depth/frame_*.raw (every 2nd pixel in both directions: 1/4 of each map, to keep the fixture at
-           a few MB), the final checkpoint (every 16th element of every tensor) and the snapshot's checksums.
-  test     tests/test_loop_gpu.py::test_epochs_at_the_headline_shape_within_1e_3 re-runs the product from the seeds (the step is
-           bit-reproducible: the regenerated snapshot is compared with the golden's checksums) and asserts <= 1e-3 on every
-           artefact of epochs K+1 .. K+T.
+           T epochs over the same batches and writes the artefacts of EVERY epoch as the golden: eval/loss_e*.json (per pair and
+           mean), eval/depth_*.raw (every 8th pixel in both directions), the checkpoint (every 256th element per epoch, every 16th
+           of the last one), depth/frame_*.raw (every 2nd pixel) and the snapshot's checksums.  The work directory is persistent
+           (<dir>/cpu_<spec>_<dtype>): `golden` on a directory whose run was interrupted collects the epochs that are complete.
+  stage 3  `ref32 <spec> <dir>`     the same continuation in the reference's OWN arithmetic (fp32 on the CPU): its distances to the
+           fp64 run are the yardstick stored next to each artefact (`ref32dist_*`).
+  test     tests/test_loop_gpu.py::test_full_length_run_within_1e_3[...] re-runs the product from the seeds (the step is
+           bit-reproducible: the regenerated snapshot is compared with the golden's checksums) and asserts the bounds at EVERY epoch.
 
-    gpurun -- 'python -m oracle.gen_golden_loop_384 snapshot gpurun_out/snap384'
-    python -m oracle.gen_golden_loop_384 golden gpurun_out/snap384
+    gpurun -- 'python -m oracle.gen_golden_loop_384 snapshot a gpurun_out/snap384'
+    python -m oracle.gen_golden_loop_384 golden a gpurun_out/snap384
+    python -m oracle.gen_golden_loop_384 ref32 a gpurun_out/snap384
 """
 import json
 import os
@@ -33,10 +45,17 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tools"))
 
-CLIP = dict(n_frames=16, H=384, W=224, seed=5)
-K, T, INIT_SEED = 3, 2, 0          # burn-in epochs (10 steps each: 37 pairs, BS4), compared epochs
-GOLDEN = os.path.join(REPO, "tests", "golden", "loop_16f_384x224.npz")
-PX_STRIDE, CKPT_STRIDE = 2, 16
+INIT_SEED = 0
+SPECS = {
+    "a": dict(clip=dict(n_frames=16, H=384, W=224, seed=5), K=3, T=20, golden="loop_16f_384x224.npz"),
+    "dense": dict(clip=dict(n_frames=8, H=384, W=224, seed=11, mask_keep=1.0, step=0.004, max_angle=0.012), K=3, T=10,
+                  golden="loop_dense8f_384x224.npz"),
+}
+EVAL_STRIDE, EXPORT_STRIDE, CKPT_EPOCH_STRIDE, CKPT_STRIDE = 8, 2, 256, 16
+
+
+def golden_path(spec):
+    return os.path.join(REPO, "tests", "golden", SPECS[spec]["golden"])
 
 
 def initial_state():
@@ -45,28 +64,35 @@ def initial_state():
     return HourglassModel().state_dict()
 
 
-def run_product(work_dir):
-    """The product loop on the GPU: K + T epochs; returns (fine-tuner, snapshot at the end of epoch K, {epoch: plan})."""
+def adam_snapshot(ft):
+    """Weights, BatchNorm buffers, Adam moments and step count of a product fine-tuner, on the host."""
+    torch.cuda.synchronize()
+    opt = getattr(ft._step, "step", ft._step).opt      # GraphedFineTuneStep wraps the FineTuneStep that owns FlatAdam
+    names = {id(p): n for n, p in ft.model.netG.named_parameters()}
+    return {"state": {k: v.detach().cpu().clone() for k, v in ft.model.netG.state_dict().items()},
+            "m1": {names[id(p)]: opt.exp_avg[o:o + p.numel()].detach().cpu().clone() for p, o in zip(opt._params, opt._offsets)},
+            "m2": {names[id(p)]: opt.exp_avg_sq[o:o + p.numel()].detach().cpu().clone() for p, o in zip(opt._params, opt._offsets)},
+            "k": int(opt.step_dev.item())}
+
+
+def run_product(spec, work_dir, extra_args=()):
+    """The product loop on the GPU: K + T epochs; returns (fine-tuner, snapshot at the end of epoch K, {epoch: plan}, clip path, range dir)."""
     import make_synthetic_dataset as msd
     from consistent_depth_amd.depth_fine_tuning import DepthFineTuner
     from consistent_depth_amd.params import Video3dParamsParser
+    S = SPECS[spec]
+    K, T = S["K"], S["T"]
     path = os.path.join(work_dir, "clip")
-    range_dir, pairs = msd.write_dataset(path, **CLIP)
-    params = Video3dParamsParser().parse(["--path", path, "--num_epochs", str(K + T), "--batch_size", "4", "--print_freq", "0"])
-    ft = DepthFineTuner(range_dir, list(range(CLIP["n_frames"])), params)
+    range_dir, pairs = msd.write_dataset(path, **S["clip"])
+    params = Video3dParamsParser().parse(["--path", path, "--num_epochs", str(K + T), "--batch_size", "4", "--print_freq", "0", *extra_args])
+    ft = DepthFineTuner(range_dir, list(range(S["clip"]["n_frames"])), params)
     ft.model.netG.load_state_dict(initial_state())
     snap, save = {}, ft.model.save
 
     def save_and_snapshot(file_name):      # end of every epoch (save_epoch_freq = 1), after its validation sweep
         save(file_name)
         if os.path.basename(file_name) == f"{K:04d}.pth":
-            torch.cuda.synchronize()
-            opt = getattr(ft._step, "step", ft._step).opt
-            names = {id(p): n for n, p in ft.model.netG.named_parameters()}
-            snap["state"] = {k: v.detach().cpu().clone() for k, v in ft.model.netG.state_dict().items()}
-            snap["m1"] = {names[id(p)]: opt.exp_avg[o:o + p.numel()].detach().cpu().clone() for p, o in zip(opt._params, opt._offsets)}
-            snap["m2"] = {names[id(p)]: opt.exp_avg_sq[o:o + p.numel()].detach().cpu().clone() for p, o in zip(opt._params, opt._offsets)}
-            snap["k"] = int(opt.step_dev.item())
+            snap.update(adam_snapshot(ft))
     ft.model.save = save_and_snapshot
     plans, orig = {}, ft.epoch_plan
 
@@ -89,25 +115,38 @@ def checksums(snap):
     return out
 
 
-def subsample(maps):
-    return np.ascontiguousarray(np.asarray(maps)[..., ::PX_STRIDE, ::PX_STRIDE])
+def subsample(maps, stride):
+    return np.ascontiguousarray(np.asarray(maps)[..., ::stride, ::stride])
 
 
-def collect(out_dir, n_pairs):
-    """Artefacts of epochs K+1 .. K+T of a finished run (product or CPU loop), in the golden's (sub-sampled) form."""
+def _ckpt_sample(file_name, stride):
+    sd = torch.load(file_name, map_location="cpu")
+    keys = [k for k in sd if sd[k].is_floating_point() and "uncertainty" not in k]
+    sample = np.concatenate([sd[k].double().reshape(-1)[::stride].numpy() for k in keys])
+    return sample, np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")], np.int64)
+
+
+def collect(out_dir, n_pairs, K, T, skipped_pairs=0):
+    """Artefacts of epochs K+1 .. K+T of a run (product or CPU loop), in the golden's (sub-sampled) form.  Epochs whose files are
+    not there yet (an interrupted CPU run) end the collection: `res["epochs"]` is the list of complete ones."""
     from oracle import gen_golden_loop as G
     a = G.collect({"out_dir": out_dir, "steps": []})
-    res = {}
+    res, epochs = {}, []
     for e in range(K + 1, K + T + 1):
-        tag = f"e{e:04d}_iter{e * n_pairs:06d}"
+        tag = f"e{e:04d}_iter{e * n_pairs - skipped_pairs:06d}"
+        ck = os.path.join(out_dir, "checkpoints", f"{e:04d}.pth")
+        if f"val_{tag}_mean" not in a or not os.path.exists(ck):
+            break
         for part in ("pairs", "reprojection", "disparity", "mean"):
             res[f"val_e{e}_{part}"] = a[f"val_{tag}_{part}"]
-        res[f"evaldepth_e{e}"] = subsample(a[f"evaldepth_{tag}"])
-    res["depth"] = subsample(a["depth"])
-    sd = torch.load(os.path.join(out_dir, "checkpoints", f"{K + T:04d}.pth"), map_location="cpu")
-    keys = [k for k in sd if sd[k].is_floating_point() and "uncertainty" not in k]
-    res["ckpt_sample"] = np.concatenate([sd[k].double().reshape(-1)[::CKPT_STRIDE].numpy() for k in keys])
-    res["num_batches_tracked"] = np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")], np.int64)
+        res[f"evaldepth_e{e}"] = subsample(a[f"evaldepth_{tag}"], EVAL_STRIDE)
+        res[f"ckpt_e{e}"], res["num_batches_tracked"] = _ckpt_sample(ck, CKPT_EPOCH_STRIDE)
+        epochs.append(e)
+    if epochs:
+        res["ckpt_sample"], _ = _ckpt_sample(os.path.join(out_dir, "checkpoints", f"{epochs[-1]:04d}.pth"), CKPT_STRIDE)
+    if "depth" in a and len(epochs) == T:
+        res["depth"] = subsample(a["depth"], EXPORT_STRIDE)
+    res["epochs"] = np.array(epochs, np.int64)
     return res
 
 
@@ -128,10 +167,12 @@ def _unpack(planes, table):
     return out
 
 
-def stage_snapshot(dst):
+def stage_snapshot(spec, dst):
+    S = SPECS[spec]
+    K, T = S["K"], S["T"]
     os.makedirs(dst, exist_ok=True)
     work = tempfile.mkdtemp(prefix="cd384_")
-    ft, snap, plans, _, _ = run_product(work)
+    ft, snap, plans, _, _ = run_product(spec, work)
     assert snap and snap["k"] == K * len(plans[0]), (snap.get("k"), len(plans[0]))
     flat, tables = {}, {}
     for part in ("state", "m1", "m2"):
@@ -143,25 +184,28 @@ def stage_snapshot(dst):
     store_pairs = [list(map(int, pr)) for pr in ft.store.pair_indices()]
     # the batches as PAIRS (frame, frame): independent of how a loader numbers its items
     flat["plans"] = np.array(json.dumps({str(e): [[store_pairs[i] for i in ids] for ids in p] for e, p in plans.items()}))
+    flat["mask_coverage"] = np.array(float(ft.store.masks.float().mean().item()))
     for name, v in checksums(snap).items():
         flat["checksum_" + name] = v
-    np.savez_compressed(os.path.join(dst, "snap384.npz"), **flat)
-    prod = collect(ft.out_dir, len(ft.store))
-    small = {k: v for k, v in prod.items() if not k.startswith("evaldepth") and k not in ("depth", "ckpt_sample")}
-    np.savez_compressed(os.path.join(dst, "product384_small.npz"), **small)
-    print("snapshot at step", snap["k"], "->", os.path.getsize(os.path.join(dst, "snap384.npz")) / 1e6, "MB;",
-          {k: v.tolist() for k, v in checksums(snap).items()})
-    for e in range(K + 1, K + T + 1):
-        print(f"product epoch {e} mean", prod[f"val_e{e}_mean"].tolist())
+    np.savez_compressed(os.path.join(dst, f"snap_{spec}.npz"), **flat)
+    prod = collect(ft.out_dir, len(ft.store), K, T)
+    np.savez_compressed(os.path.join(dst, f"product_{spec}.npz"), **prod)
+    print(f"[{spec}] snapshot at step", snap["k"], "->", os.path.getsize(os.path.join(dst, f"snap_{spec}.npz")) / 1e6, "MB; mask coverage",
+          float(flat["mask_coverage"]), {k: v.tolist() for k, v in checksums(snap).items()})
+    for e in prod["epochs"]:
+        print(f"[{spec}] product epoch {e} mean", prod[f"val_e{e}_mean"].tolist())
 
 
-def _cpu_run(src, dtype):
-    """oracle/cpu_loop.py continued from the snapshot in `src` for T epochs in `dtype`; returns (artefacts, snapshot checksums, extras)."""
+def _cpu_run(spec, src, dtype):
+    """oracle/cpu_loop.py continued from the snapshot in `src` for T epochs in `dtype`; returns (artefacts, snapshot checksums, extras).
+    The run lives in <src>/cpu_<spec>_<dtype>; if that directory already holds a run (finished or interrupted) it is COLLECTED, not redone."""
     import make_synthetic_dataset as msd
     from consistent_depth_amd.loaders.video_dataset import VideoDataset, load_color
     from oracle import conv64, cpu_loop
+    S = SPECS[spec]
+    K, T, CLIP = S["K"], S["T"], S["clip"]
     conv64.ENABLED = True        # the dgemm formulation of the fp64 convolution: 5x faster on the build container's 8 cores
-    z = np.load(os.path.join(src, "snap384.npz"))
+    z = np.load(os.path.join(src, f"snap_{spec}.npz"))
     tables = json.loads(str(z["tables"]))
     snap = {part: _unpack(z[part], tables[part]) for part in ("state", "m1", "m2")}
     snap["k"] = int(z["k"])
@@ -171,27 +215,37 @@ def _cpu_run(src, dtype):
     cs = checksums(snap)
     for name, v in cs.items():
         assert np.array_equal(v, z["checksum_" + name]), name
-    work = tempfile.mkdtemp(prefix="cd384_")
+    work = os.path.join(src, f"cpu_{spec}_{'f64' if dtype == torch.float64 else 'f32'}")
     path = os.path.join(work, "clip")
+    out = os.path.join(work, "cpu")
+    fresh = not os.path.exists(out)
+    os.makedirs(work, exist_ok=True)
     range_dir, pairs = msd.write_dataset(path, **CLIP)
     ds = VideoDataset(path, os.path.join(range_dir, "metadata_scaled.npz"))
     assert len(ds) == len(pairs)
-    ds_idx = {tuple(int(v) for v in pr): i for i, pr in enumerate(ds.flow_indices)}
-    plans = {e: [[ds_idx[tuple(pr)] for pr in batch] for batch in p] for e, p in plans.items()}
-    out = os.path.join(work, "cpu")
-    lp = cpu_loop.CpuLoop(ds, snap["state"], out, dtype=dtype)
-    lp.ft.set_adam_state(snap["m1"], snap["m2"], snap["k"])
-    lp.total_iters = K * len(ds)
-    lp.fine_tune(T, lambda e: plans[K + e], start_epoch=K)
-    lp.save_depth(out, list(range(CLIP["n_frames"])), lambda f: load_color(ds.color_fmt.format(f)))
-    res = collect(out, len(ds))
-    extras = {"clip": np.array([CLIP["n_frames"], CLIP["H"], CLIP["W"], CLIP["seed"]]), "K": np.array(K), "T": np.array(T),
-              "k_steps": np.array(snap["k"]), "plans": z["plans"], "px_stride": np.array(PX_STRIDE), "ckpt_stride": np.array(CKPT_STRIDE),
+    step_losses = []
+    if fresh:
+        ds_idx = {tuple(int(v) for v in pr): i for i, pr in enumerate(ds.flow_indices)}
+        plans = {e: [[ds_idx[tuple(pr)] for pr in batch] for batch in p] for e, p in plans.items()}
+        lp = cpu_loop.CpuLoop(ds, snap["state"], out, dtype=dtype)
+        lp.ft.set_adam_state(snap["m1"], snap["m2"], snap["k"])
+        lp.total_iters = K * len(ds)
+        lp.fine_tune(T, lambda e: plans[K + e], start_epoch=K)
+        lp.save_depth(out, list(range(CLIP["n_frames"])), lambda f: load_color(ds.color_fmt.format(f)))
+        step_losses = [l for _, _, l in lp.step_losses]
+        np.save(os.path.join(work, "step_losses.npy"), np.array(step_losses, np.float64))
+    elif os.path.exists(os.path.join(work, "step_losses.npy")):
+        step_losses = np.load(os.path.join(work, "step_losses.npy")).tolist()
+    res = collect(out, len(ds), K, T)
+    extras = {"clip": np.array(json.dumps(CLIP)), "K": np.array(K), "T": np.array(len(res["epochs"])),
+              "k_steps": np.array(snap["k"]), "plans": z["plans"], "eval_stride": np.array(EVAL_STRIDE), "export_stride": np.array(EXPORT_STRIDE),
+              "ckpt_stride": np.array(CKPT_STRIDE), "ckpt_epoch_stride": np.array(CKPT_EPOCH_STRIDE),
+              "mask_coverage": z["mask_coverage"],
               "pair_order": np.array([list(p) for p in ds.flow_indices], np.int64),
-              "step_losses": np.array([l for _, _, l in lp.step_losses], np.float64)}
+              "step_losses": np.array(step_losses, np.float64)}
     for k in list(res):
         if res[k].dtype == np.float64 and res[k].size > 4096:
-            res[k] = res[k].astype(np.float32)       # maps and the checkpoint sample: the artefacts themselves are fp32 files
+            res[k] = res[k].astype(np.float32)       # maps and the checkpoint samples: the artefacts themselves are fp32 files
     return res, cs, extras
 
 
@@ -200,36 +254,60 @@ def _rel(a, b):
     return float(np.abs(a - b).sum() / max(np.abs(b).sum(), 1e-300))
 
 
-def stage_golden(src):
-    res, cs, extras = _cpu_run(src, torch.float64)
+def distances(got, z, epochs):
+    """Relative-L1 distance of every artefact of `got` to the golden `z`, per epoch: the rows of profiles/parity_20ep_r05.txt and the
+    quantities tests/test_loop_gpu.py bounds."""
+    rows = {}
+    for e in epochs:
+        rows[int(e)] = {
+            "mean": _rel(got[f"val_e{e}_mean"], z[f"val_e{e}_mean"]),
+            "perpair": max(_rel(got[f"val_e{e}_{p}"], z[f"val_e{e}_{p}"]) for p in ("reprojection", "disparity")),
+            "perpair_max": float(max(np.abs(np.asarray(got[f"val_e{e}_{p}"], np.float64) - z[f"val_e{e}_{p}"]).max()
+                                     / np.abs(z[f"val_e{e}_{p}"]).mean() for p in ("reprojection", "disparity"))),
+            "evaldepth": _rel(got[f"evaldepth_e{e}"], z[f"evaldepth_e{e}"]),
+            "ckpt": _rel(got[f"ckpt_e{e}"], z[f"ckpt_e{e}"]),
+        }
+    return rows
+
+
+def stage_golden(spec, src):
+    res, cs, extras = _cpu_run(spec, src, torch.float64)
     res.update(extras)
     for name, v in cs.items():
         res["checksum_" + name] = v
-    np.savez_compressed(GOLDEN, **res)
-    print("wrote", GOLDEN, os.path.getsize(GOLDEN) / 1e6, "MB")
-    for e in range(K + 1, K + T + 1):
-        print(f"fp64 epoch {e} mean", res[f"val_e{e}_mean"].tolist())
-    small = os.path.join(src, "product384_small.npz")
-    if os.path.exists(small):
-        p = np.load(small)
-        for e in range(K + 1, K + T + 1):
-            print(f"product (snapshot run) vs fp64, epoch {e} mean rel-L1: {_rel(p[f'val_e{e}_mean'], res[f'val_e{e}_mean']):.3e}")
+    out = golden_path(spec)
+    np.savez_compressed(out, **res)
+    print("wrote", out, os.path.getsize(out) / 1e6, "MB; epochs", res["epochs"].tolist())
+    prod = os.path.join(src, f"product_{spec}.npz")
+    if os.path.exists(prod):
+        p = np.load(prod)
+        for e, row in distances(p, res, res["epochs"]).items():
+            print(f"[{spec}] product (snapshot run) vs fp64, epoch {e}: " + "  ".join(f"{k} {v:.3e}" for k, v in row.items()))
 
 
-def stage_ref32(src):
-    """The YARDSTICK: the same continuation in the reference's own arithmetic (fp32 on the CPU, ~2 minutes) -- how far the reference
-    is from its fp64 self on every artefact.  Stored next to the fp64 golden as `ref32dist_<artefact>` (distances only: the fp32
-    artefacts themselves are one realisation of round-off and nothing is compared with them)."""
-    res, cs, _ = _cpu_run(src, torch.float32)
-    z = dict(np.load(GOLDEN))
+def stage_ref32(spec, src):
+    """The YARDSTICK: the same continuation in the reference's own arithmetic (fp32 on the CPU) -- how far the reference is from its
+    fp64 self on every artefact.  Stored next to the fp64 golden as `ref32dist_<artefact>` (distances only: the fp32 artefacts
+    themselves are one realisation of round-off and nothing is compared with them)."""
+    res, cs, _ = _cpu_run(spec, src, torch.float32)
+    out = golden_path(spec)
+    z = dict(np.load(out))
     for name, v in cs.items():
         assert np.array_equal(v, z["checksum_" + name]), name
     for k, v in res.items():
-        if v.dtype.kind == "f" and k in z:
+        if v.dtype.kind == "f" and k in z and z[k].shape == v.shape:
             z["ref32dist_" + k] = np.array(_rel(v, z[k]))
-            print(f"reference fp32 vs fp64  {k:24s} {float(z['ref32dist_' + k]):.3e}")
-    np.savez_compressed(GOLDEN, **z)
+            print(f"[{spec}] reference fp32 vs fp64  {k:24s} {float(z['ref32dist_' + k]):.3e}")
+    for e in z["epochs"]:      # the per-pair maximum, like distances()
+        if f"val_e{e}_reprojection" in res:
+            z[f"ref32dist_perpair_max_e{e}"] = np.array(distances(res, z, [e])[int(e)]["perpair_max"])
+    np.savez_compressed(out, **z)
+
+
+def stage_run32(spec, src):
+    """Only the fp32 continuation itself (its work directory persists; `ref32` collects it once the fp64 golden exists)."""
+    _cpu_run(spec, src, torch.float32)
 
 
 if __name__ == "__main__":
-    {"snapshot": stage_snapshot, "golden": stage_golden, "ref32": stage_ref32}[sys.argv[1]](sys.argv[2])
+    {"snapshot": stage_snapshot, "golden": stage_golden, "ref32": stage_ref32, "run32": stage_run32}[sys.argv[1]](sys.argv[2], sys.argv[3])

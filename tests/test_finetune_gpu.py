@@ -136,7 +136,7 @@ def test_run_level_parity_after_burn_in():
     import os
     # Default: 2 pairs = 4 images of 384x224, 2 steps -- the fp64 CPU reference is computed HERE, on the GPU box's host, and dominates the
     # test (and, at 8 images, the host's memory: torch's double convolution unfolds the whole batch).  The BASELINE batch itself (4 pairs,
-    # 10 steps per epoch, 2 epochs) is covered by tests/test_loop_gpu.py::test_epochs_at_the_headline_shape_within_1e_3 against an fp64
+    # 10 steps per epoch, 20 epochs) is covered by tests/test_loop_gpu.py::test_full_length_run_within_1e_3 against an fp64
     # continuation computed offline; CD_AMD_TEST_FULL_BASELINE=1 runs this test at 4 pairs x 4 steps with the fp32 yardstick (~8 minutes).
     full = bool(os.environ.get("CD_AMD_TEST_FULL_BASELINE"))
     BURN, T, PB, PH, PW = (24, 4, 4, 384, 224) if full else (24, 2, 2, 384, 224)
@@ -191,7 +191,7 @@ def test_run_level_parity_after_burn_in():
             need, left = (time.monotonic() - t0) * (len(run) - 1 - i + 0.3), conftest.budget_left()
             if need > left:
                 pytest.skip(f"time budget: the fp64 CPU reference needs another ~{need:.0f} s on this host, {left:.0f} s are left "
-                            f"(the headline-shape criterion is asserted by test_loop_gpu.py::test_epochs_at_the_headline_shape_within_1e_3 "
+                            f"(the headline-shape criterion is asserted by test_loop_gpu.py::test_full_length_run_within_1e_3 "
                             f"against the committed fp64 golden; CD_AMD_TEST_BUDGET_S=0 runs this test regardless)")
         x = torch.as_tensor(probe_images, dtype=dtype).reshape(-1, 3, PH, PW)
         with torch.no_grad():
