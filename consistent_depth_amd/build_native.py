@@ -42,6 +42,12 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the native library cannot be built")
 
 
+# Per-file flags.  loss_sweep.hip: the SLP vectorizer pairs the two pixels of a lane into v_pk_*_f32 instructions -- which issue at
+# HALF the rate of their scalar forms on gfx950 (no gain) and need register moves to form the pairs: 80 v_mov per two items in the fast
+# source pass, 412 vector instructions instead of 386 (static census, profiles/loss_sweep_isa_r05.txt).
+EXTRA_FLAGS = {"loss_sweep.hip": ["-fno-slp-vectorize"]}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return SO
@@ -55,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         hdr_t = max(os.path.getmtime(h) for h in _deps() if h.endswith(".h"))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            cmd = [hipcc(), *flags, "-c", src, "-o", obj]
+            cmd = [hipcc(), *flags, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))

@@ -192,6 +192,14 @@ __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlan
 // ~30 wave-uniform camera constants, 10 pointers and the plan records live next to them) -- same code, same results.
 constexpr int kStaticH = 384, kStaticW = 224, kStaticPXT = 2;
 static_assert(kStagePasses == 2, "the service wave's quad count assumes SMAX = 2 passes of RP = 4 rows at the static geometry");
+constexpr int kStaticSvcQuads = (2 * 4 * (kStaticW / 4) + kSvcLanes - 1) / kSvcLanes;
+// what the compile-time instantiation assumes about its geometry beyond H / W / PXT (the service wave's row assignment and the fast
+// source pass): checked at launch against make_geo's result -- a change of kFrameThreads, kStagePasses or make_geo that breaks one of
+// them sends the BASELINE shape to the run-time-geometry instantiation instead of computing wrong gradients
+static bool static_geometry_holds(const Geo& c) {
+    return svc_geometry_ok(c) && svc_quads(c) == kStaticSvcQuads && c.RP == 4 && c.SMAX == kStagePasses * c.RP && fast_geometry_ok(c) &&
+           kStaticH % 4 == 0;
+}
 
 template <int MODE, bool REPROJ, int PXT, int SG>
 __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     float* __restrict__ grad, Overflow* ovf, unsigned* __restrict__ oidx, float* __restrict__ oval, const SweepShape sh) {
     extern __shared__ __align__(16) unsigned smem[];   // [2][ring] accumulators, [2][ring] depths, reduction scratch
     const Geo g = SG == 1 ? make_geo(kStaticH, kStaticW, kStaticPXT) : sh.g;
-    const int b = blockIdx.x, HW = g.H * g.W, ring = g.R * g.RW;
+    const int b = blockIdx.x, HW = g.H * g.W, ring = ring_rows(g) * g.RW;
     const int f = uni((int)(threadIdx.x / kFrameThreads)), k = 1 - f;   // whole waves serve one frame: everything derived from f is scalar
     View v;
     v.H = g.H; v.W = g.W; v.R = g.R; v.RW = g.RW; v.RP = g.RP; v.G = g.G; v.CG = g.CG; v.HW = (unsigned)HW;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     // rows that enter and leave the ring; compile-time geometry only -- the run-time-geometry build keeps every thread on its columns).
     constexpr bool SVC = SG == 1 && PXT == kStaticPXT;
     if (SVC && (int)threadIdx.x - f * kFrameThreads >= g.RP * g.CG) {      // wave-uniform
-        constexpr int NQ = SVC ? (2 * 4 * (kStaticW / 4) + kSvcLanes - 1) / kSvcLanes : 1;     // kStagePasses * RP rows of W / 4 quads
+        constexpr int NQ = kStaticSvcQuads;     // kStagePasses * RP rows of W / 4 quads (launch_sweep_inst checks it against the geometry)
         const int sl = (int)threadIdx.x - f * kFrameThreads - g.RP * g.CG;
         SvcRegs<NQ> q;
 #pragma unroll
@@ -286,8 +294,48 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const bool two = kGroupPasses > 1 && uni((int)(g.G > g.RP)) != 0;
     Rec me = items[0].f[f];
     int wk = items[0].f[k].w, nvk = items[0].f[k].nv;
-    load_inputs<PXT>(v, l, me.p, 0, inA);
+    // the fast source pass (loss_sweep_core.h): compile-time geometry whose source waves have a row for every lane in every item
+    constexpr bool FAST = SVC && PXT == 2 && kStaticH % 4 == 0;
+    LaneF<PXT> lf;
+    CamF cf;
+    if constexpr (FAST) {
+        lf = make_lanef<PXT>(v, l);
+        cf = make_camf(v.cj);
+        float* cff = reinterpret_cast<float*>(&cf);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(CamF) / sizeof(float)); ++i) cff[i] = uni(cff[i]);
+        load_inputs_all<PXT>(v, lf, me.p > 0 ? me.p : 0, inA);
+    } else load_inputs<PXT>(v, l, me.p, 0, inA);
     __syncthreads();
+    if (!two) {
+        // ONE pass per item (the default): the flow / mask of item t + 1 are requested at the TOP of item t and consumed one whole item
+        // later, through two register sets that alternate explicitly (the loop is unrolled by two: no copies, and nothing the compiler
+        // can fold back into "load right before the first use").  Round 4 issued them at the END of item t -- right before the barrier
+        // -- and waited for them at the top of item t + 1: every wave of the workgroup then sat out one full memory latency per item
+        // at the same time (all of them have just passed the barrier), with nothing left on the CU to cover it.
+        auto item = [&](int it, const Inputs<PXT>& cur, Inputs<PXT>& nxt) {
+            const bool more = it + 1 < n_items;
+            const int nt = more ? it + 1 : it;
+            const Rec nx = items[nt].f[f];
+            const int nwk = items[nt].f[k].w, nnvk = items[nt].f[k].nv;
+            if constexpr (FAST) load_inputs_all<PXT>(v, lf, nx.p > 0 ? nx.p : 0, nxt);      // (an item without a group, and the last one: row 0, unused)
+            else load_inputs<PXT>(v, l, more ? nx.p : -1, 0, nxt);
+            if (!SVC) {
+                r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
+                load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
+                flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);
+            }
+            if constexpr (FAST) {
+                if (me.p >= 0) process_rows_fast<MODE, REPROJ, PXT>(v, cf, env, r, l, lf, cur, me.p, wk, nvk);     // wave-uniform branch
+            } else process_rows<MODE, REPROJ, PXT>(v, env, r, l, cur, me.p, 0, wk, nvk);
+            __syncthreads();
+            me = nx; wk = nwk; nvk = nnvk;
+        };
+        for (int it = 0; it < n_items; it += 2) {
+            item(it, inA, inB);
+            if (it + 1 < n_items) item(it + 1, inB, inA);
+        }
+    } else {
     for (int it = 0; it < n_items; ++it) {
         if (!SVC) r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
         const bool more = it + 1 < n_items;
@@ -295,13 +343,14 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         const Rec nx = items[nt].f[f];
         const int nwk = items[nt].f[k].w, nnvk = items[nt].f[k].nv;
         if (!SVC) load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
-        if (two) load_inputs<PXT>(v, l, me.p, 1, inB);
+        load_inputs<PXT>(v, l, me.p, 1, inB);
         if (!SVC) flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);
         process_rows<MODE, REPROJ, PXT>(v, env, r, l, inA, me.p, 0, wk, nvk);
         load_inputs<PXT>(v, l, more ? nx.p : -1, 0, inA);
-        if (two) process_rows<MODE, REPROJ, PXT>(v, env, r, l, inB, me.p, 1, wk, nvk);
+        process_rows<MODE, REPROJ, PXT>(v, env, r, l, inB, me.p, 1, wk, nvk);
         __syncthreads();
         me = nx; wk = nwk; nvk = nnvk;
+    }
     }
     }
     if (env.any(r.bad) && (threadIdx.x & (kWave - 1)) == 0) env.degenerate();
@@ -345,7 +394,7 @@ template <int MODE, bool REPROJ, int PXT>
 static int launch_sweep_inst(const SweepArgs& a, int B, size_t lds, hipStream_t s) {
     if (PXT == kStaticPXT && a.sh.g.H == kStaticH && a.sh.g.W == kStaticW && g_sweep_static_geo) {
         const Geo c = make_geo(kStaticH, kStaticW, kStaticPXT);
-        if (memcmp(&c, &a.sh.g, sizeof(Geo)) == 0) return launch_sweep_sg<MODE, REPROJ, PXT, PXT == kStaticPXT ? 1 : 0>(a, B, lds, s);
+        if (memcmp(&c, &a.sh.g, sizeof(Geo)) == 0 && static_geometry_holds(c)) return launch_sweep_sg<MODE, REPROJ, PXT, PXT == kStaticPXT ? 1 : 0>(a, B, lds, s);
     }
     return launch_sweep_sg<MODE, REPROJ, PXT, 0>(a, B, lds, s);
 }

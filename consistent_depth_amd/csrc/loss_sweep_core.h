@@ -72,8 +72,10 @@ CD_HD Geo make_geo(int H, int W, int pxt) {
     g.RP = kFrameThreads / g.CG;
     if (g.RP > 16) g.RP = 16;
     g.RW = (W + pxt) / pxt * pxt;                // >= W + 1
-    int R = (kLdsBytes - kLdsReserve) / (2 * g.RW * 8);   // fp32 depth + 32-bit accumulator per element
+    // fp32 depth + 32-bit accumulator per element; one row more than R is kept: slot R is a COPY of slot 0 (see ring_rows below)
+    int R = (kLdsBytes - kLdsReserve) / (2 * g.RW * 8) - 1;
     if (R > 512) R = 512;
+    if (R < 1) return g;
     // a POWER OF TWO: image row r lives in slot r & (R - 1) -- one AND per ring address instead of a window-relative offset
     // with a wrap (the rings are direct mapped; windows only say which rows are resident)
     while (R & (R - 1)) R &= R - 1;
@@ -94,7 +96,11 @@ CD_HD Geo make_geo(int H, int W, int pxt) {
     return g;
 }
 
-CD_HD size_t ring_lds_bytes(const Geo& g) { return (size_t)2 * g.R * g.RW * 8 + kLdsReserve; }
+// Rows a ring occupies in LDS: the R direct-mapped slots plus slot R, which MIRRORS slot 0 -- the depth of the row in slot 0 is written
+// to both, accumulator words of slot R are added to slot 0's when the row leaves -- so that "the ring row under slot s" is slot s + 1 for
+// EVERY s < R: the four bilinear taps of a source are one address and the constant offsets {0, 1, RW, RW + 1} (process_rows_fast).
+CD_HD int ring_rows(const Geo& g) { return g.R + 1; }
+CD_HD size_t ring_lds_bytes(const Geo& g) { return (size_t)2 * ring_rows(g) * g.RW * 8 + kLdsReserve; }
 
 // ---------------------------------------------------------------- plan
 struct Item {
@@ -445,8 +451,12 @@ CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, con
                 good = good && (d.v[i] > 0.f && d.v[i] < INFINITY);
             }
             *reinterpret_cast<VecF<PXT>*>(&v.Dj[base + l.x0]) = d;
+            if (base == 0u) *reinterpret_cast<VecF<PXT>*>(&v.Dj[(unsigned)(v.R * v.RW) + l.x0]) = d;      // slot R mirrors slot 0
             if (l.x0 == 0u)
-                for (int c = v.W; c < v.RW; ++c) v.Dj[base + (unsigned)c] = 1.f;   // the pad column(s)
+                for (int c = v.W; c < v.RW; ++c) {
+                    v.Dj[base + (unsigned)c] = 1.f;   // the pad column(s)
+                    if (base == 0u) v.Dj[(unsigned)(v.R * v.RW + c)] = 1.f;
+                }
         }
     }
     return good;
@@ -463,15 +473,27 @@ CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi) {
         if (l.on && row < hi) {
             const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW);
             VecU<PXT>* ap = reinterpret_cast<VecU<PXT>*>(&v.Aj[base + l.x0]);
-            const VecU<PXT> n = *ap;
+            VecU<PXT> n = *ap;
             VecU<PXT> z;
             VecF<PXT> g;
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) { z.v[i] = 0u; g.v[i] = (float)(int)n.v[i] * unit; }
+            for (int i = 0; i < PXT; ++i) z.v[i] = 0u;
+            if (base == 0u) {      // what the fast pass added to the mirror of slot 0
+                VecU<PXT>* mp = reinterpret_cast<VecU<PXT>*>(&v.Aj[(unsigned)(v.R * v.RW) + l.x0]);
+                const VecU<PXT> n2 = *mp;
+#pragma unroll
+                for (int i = 0; i < PXT; ++i) n.v[i] += n2.v[i];
+                *mp = z;
+            }
+#pragma unroll
+            for (int i = 0; i < PXT; ++i) g.v[i] = (float)(int)n.v[i] * unit;
             *ap = z;
             stgv<PXT>(v.gradj, ((unsigned)(lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2, g);
             if (l.x0 == 0u)
-                for (int c = v.W; c < v.RW; ++c) v.Aj[base + (unsigned)c] = 0u;
+                for (int c = v.W; c < v.RW; ++c) {
+                    v.Aj[base + (unsigned)c] = 0u;
+                    if (base == 0u) v.Aj[(unsigned)(v.R * v.RW + c)] = 0u;
+                }
         }
     }
 }
@@ -524,11 +546,19 @@ template <int MODE, int NQ> CD_HD bool svc_stage(const View& v, int lane, int s_
             }
             *reinterpret_cast<VecF<2>*>(&v.Dj[base]) = d0;
             *reinterpret_cast<VecF<2>*>(&v.Dj[base + 2]) = d1;
+            if ((row & (v.R - 1)) == 0) {              // slot R mirrors slot 0
+                const unsigned mb = (unsigned)(v.R * v.RW) + 4u * (unsigned)c4;
+                *reinterpret_cast<VecF<2>*>(&v.Dj[mb]) = d0;
+                *reinterpret_cast<VecF<2>*>(&v.Dj[mb + 2]) = d1;
+            }
         }
     }
     const int row = s_lo + lane;                   // the pad column(s): one row per lane
     if (row < s_hi)
-        for (int c = v.W; c < v.RW; ++c) v.Dj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 1.f;
+        for (int c = v.W; c < v.RW; ++c) {
+            v.Dj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 1.f;
+            if ((row & (v.R - 1)) == 0) v.Dj[(unsigned)(v.R * v.RW + c)] = 1.f;
+        }
     return good;
 }
 
@@ -543,9 +573,16 @@ template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) 
             const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW) + 4u * (unsigned)c4;
             VecU<2>* a0 = reinterpret_cast<VecU<2>*>(&v.Aj[base]);
             VecU<2>* a1 = reinterpret_cast<VecU<2>*>(&v.Aj[base + 2]);
-            const VecU<2> n0 = *a0, n1 = *a1;
+            VecU<2> n0 = *a0, n1 = *a1;
             VecU<2> z; z.v[0] = z.v[1] = 0u;
             *a0 = z; *a1 = z;
+            if ((row & (v.R - 1)) == 0) {              // what the fast pass added to the mirror of slot 0
+                VecU<2>* m0 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + 4u * (unsigned)c4]);
+                VecU<2>* m1 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + 4u * (unsigned)c4 + 2]);
+                const VecU<2> k0 = *m0, k1 = *m1;
+                n0.v[0] += k0.v[0]; n0.v[1] += k0.v[1]; n1.v[0] += k1.v[0]; n1.v[1] += k1.v[1];
+                *m0 = z; *m1 = z;
+            }
             VecF<4> g;
             g.v[0] = (float)(int)n0.v[0] * unit; g.v[1] = (float)(int)n0.v[1] * unit;
             g.v[2] = (float)(int)n1.v[0] * unit; g.v[3] = (float)(int)n1.v[1] * unit;
@@ -554,7 +591,10 @@ template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) 
     }
     const int row = lo + lane;
     if (row < hi)
-        for (int c = v.W; c < v.RW; ++c) v.Aj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 0u;
+        for (int c = v.W; c < v.RW; ++c) {
+            v.Aj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 0u;
+            if ((row & (v.R - 1)) == 0) v.Aj[(unsigned)(v.R * v.RW + c)] = 0u;
+        }
 }
 
 // Evaluate pass q of the source rows [p, p + G) of the wave's frame j: loss partials, direct gradient -> ring j, the 4 tap
@@ -702,6 +742,175 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
                 scatter(tp[i].yb, tp[i].xa, c10[i]); scatter(tp[i].yb, tp[i].xb, c11[i]);
             }
         }
+    }
+    r.acc_r += (double)sum_r; r.acc_d += (double)sum_d;
+}
+
+// ---------------------------------------------------------------- the fast source pass (round 5)
+// process_rows above is the GENERAL pass: any geometry, any lane may be without a row, every decision per lane.  At 256 pairs it ran
+// at 145 vector instructions per pixel-direction, a third of them compares / selects guarding cases that cannot occur when
+//   * every lane of a source wave has a row in every pass (H a multiple of RP, G = RP: `rowok` is the wave-uniform p >= 0), and
+//   * the ring keeps a COPY of slot 0 behind slot R - 1 (slot R; View::dup): the row under ring row s is always at s + 1, i.e. the four
+//     taps of a source are ONE address + the immediates {0, 1, RW, RW + 1} (ds_read2_b32 / ds_add_u32 offsets) -- no second wrap.
+// process_rows_fast is the same closed form written for that case, in "target pixel" units -- the camera constants
+// arrive premultiplied by the target intrinsics (CamF): X' = fx_t X, Y' = fy_t Y, so
+//     ex = (cx_t - mx) - X'/Z        ey = (cy_t - my) + Y'/Z        d ex/dd = (t a2 - a0')/Z     d ey/dd = (a1' - u a2)/Z   (t = X'/Z, u = Y'/Z)
+// and without selects on the hot path: 1/|e| = rsq(max(e2, 1e-30)) (e2 is 0 or >= ulp(coordinate)^2 ~ 1e-11: the max only replaces the
+// reference's "subgradient 0 at e = 0" select), sign(dd) = med3(dd * 2^126, -1, 1) (exactly -1 / 0 / 1: dd is 0 or a normal number),
+// the tap row clamped into the resident window by one med3 (sources outside are either mask-0 "lenient" lanes -- any resident row
+// gives their exact 0 -- or raise the wave's slow vote).  Whenever a wave votes "slow" (a valid source outside the ring, a value beyond
+// the fixed-point range, NaN) NOTHING of the fast pass is kept and the general pass runs for that wave and pass: the exact paths
+// (overflow list, global taps) live in one place.  Fast and general passes differ in the last bits of the algebra (both are within
+// the fp32 class of the oracle; tests/test_sweep_cpu.py runs the goldens through both).
+struct CamF {
+    float b1x, b2x, b1y, b2y, b1z, b2z;   // row part of a' = (fx_t a0, fy_t a1, a2):  a' = A'(x) + b1 * r1 - b2
+    float cX, cY, cZ;                      // fx_t c0, fy_t c1, c2
+    float cx_t, cy_t, cy_r, ify_r, sx, sy;
+    float drs, dbs, scs;
+};
+CD_HD CamF make_camf(const Cam& c) {
+    CamF f;
+    f.b1x = c.fx_t * c.M[1]; f.b2x = c.fx_t * c.M[2];
+    f.b1y = c.fy_t * c.M[4]; f.b2y = c.fy_t * c.M[5];
+    f.b1z = c.M[7]; f.b2z = c.M[8];
+    f.cX = c.fx_t * c.c[0]; f.cY = c.fy_t * c.c[1]; f.cZ = c.c[2];
+    f.cx_t = c.cx_t; f.cy_t = c.cy_t; f.cy_r = c.cy_r; f.ify_r = c.ify_r; f.sx = c.sx; f.sy = c.sy;
+    f.drs = c.drs; f.dbs = c.dbs; f.scs = c.scs;
+    return f;
+}
+template <int PXT> struct LaneF {
+    float ax[PXT], ay[PXT], az[PXT];   // column part of a': fx_t M[0] r0(x), fy_t M[3] r0(x), M[6] r0(x)
+    float xf[PXT];                     // the columns as floats
+    unsigned own;                      // rr * RW + x0: element index of the lane's own pixels in ring row 0
+    unsigned goff;                     // (rr * W + x0) * 4: byte offset of the lane's pixels inside a row group
+    int rr;
+};
+template <int PXT> CD_HD LaneF<PXT> make_lanef(const View& v, const Lane<PXT>& l) {
+    LaneF<PXT> f;
+    for (int i = 0; i < PXT; ++i) {
+        const float x = (float)(l.x0 + i);
+        const float r0 = (x - v.cj.cx_r) * v.cj.ifx_r;
+        f.ax[i] = v.cj.fx_t * v.cj.M[0] * r0; f.ay[i] = v.cj.fy_t * v.cj.M[3] * r0; f.az[i] = v.cj.M[6] * r0;
+        f.xf[i] = x;
+    }
+    f.rr = l.rr;
+    f.own = (unsigned)(l.rr * v.RW) + l.x0;
+    f.goff = (l.rrW + l.x0) << 2;
+    return f;
+}
+// does this geometry allow the fast pass?  (every lane of a source wave has a row in every item that has a group at all)
+CD_HD bool fast_geometry_ok(const Geo& g) { return g.ok && g.PXT == 2 && g.G == g.RP && g.H % g.RP == 0 && g.RP * g.CG <= kFrameThreads; }
+
+// flow / mask of the source rows [p, p + RP): unconditional loads (p >= 0; the caller clamps) -- nothing to select afterwards, so the
+// compiler has no reason to wait for them before their first use one item later
+template <int PXT> CD_HD void load_inputs_all(const View& v, const LaneF<PXT>& lf, int p, Inputs<PXT>& in) {
+    const unsigned off = (unsigned)p * ((unsigned)v.W << 2) + lf.goff;
+    const VecF<PXT> a = ldgv<PXT>(v.flj, off), b = ldgv<PXT>(v.flj + v.HW, off), mm = ldgv<PXT>(v.mkj, off);
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) { in.fx[i] = a.v[i]; in.fy[i] = b.v[i]; in.m[i] = mm.v[i]; }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// (VOP3 reads ONE scalar register on gfx9: the upper bound arrives in a vector register, copied once per item)
+CD_HD int cd_med3i(int a, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(lo), "v"(hi)); return r; }
+#else
+CD_HD int cd_med3i(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
+#endif
+CD_HD float cd_sign(float x) { return cd_clamp(x * 8.5070592e37f /* 2^126 */, -1.f, 1.f); }
+
+// Evaluate the source rows [p, p + RP) (p >= 0: wave-uniform) of the wave's frame j.  wk / nvk: first resident row of ring k and the
+// number of rows usable by this item (Rec::w, Rec::nv of the other frame).
+template <int MODE, bool REPROJ, int PXT, class Env>
+CD_HD void process_rows_fast(const View& v, const CamF& cf, Env& env, Regs<PXT>& r, const Lane<PXT>& l, const LaneF<PXT>& lf,
+                             const Inputs<PXT>& in, int p, int wk, int nvk) {
+    static_assert(PXT == 2, "the fast pass handles the two adjacent pixels of a lane as one batch");
+    const int R = v.R, RW = v.RW, W = v.W, H = v.H;
+    const int y = p + lf.rr;
+    const float yf = (float)y;
+    const unsigned own = lf.own + (unsigned)((p & (R - 1)) * RW);      // rows of a group share p's slot run: (p + rr) & (R - 1) = (p & (R - 1)) + rr
+    const VecF<PXT> dv = *reinterpret_cast<const VecF<PXT>*>(&v.Dj[own]);
+    const float r1 = (cf.cy_r - yf) * cf.ify_r;
+    const float bx = cd_fma(cf.b1x, r1, -cf.b2x), by = cd_fma(cf.b1y, r1, -cf.b2y), bz = cd_fma(cf.b1z, r1, -cf.b2z);
+    const int hi = wk + (nvk >= 2 ? nvk - 2 : 0);                      // last row whose lower neighbour is usable too (scalar)
+    const bool window = nvk >= 2;
+    // ---- stage 0: sampling coordinates, ring address of the upper-left tap
+    float tx[PXT], ty[PXT], mx[PXT], my[PXT];
+    unsigned i0[PXT];
+    int ya[PXT], xa[PXT];
+    bool need_slow = false;
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) {
+        mx[i] = cd_fadd(lf.xf[i], in.fx[i]); my[i] = cd_fadd(yf, in.fy[i]);
+        const float ix = cd_clamp(cd_fma(mx[i], cf.sx, -0.5f), 0.f, (float)(W - 1));
+        const float iy = cd_clamp(cd_fma(my[i], cf.sy, -0.5f), 0.f, (float)(H - 1));
+        tx[i] = cd_fract(ix); ty[i] = cd_fract(iy);
+        xa[i] = (int)ix; ya[i] = (int)iy;
+        const int ra = cd_med3i(ya[i], wk, hi);
+        const bool inside = window && ra == ya[i];
+        need_slow = need_slow || (!inside && in.m[i] != 0.f);
+        i0[i] = mad24((unsigned)ra & (unsigned)(R - 1), (unsigned)RW, (unsigned)xa[i]);
+    }
+    // ---- stage 1: the 4 depth taps of frame k (the row under slot s is slot s + 1: View::dup)
+    float d00[PXT], d01[PXT], d10[PXT], d11[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) { d00[i] = v.Dk[i0[i]]; d01[i] = v.Dk[i0[i] + 1]; d10[i] = v.Dk[i0[i] + (unsigned)RW]; d11[i] = v.Dk[i0[i] + (unsigned)RW + 1]; }
+    // ---- stage 2: the algebra
+    float gd[PXT], c00[PXT], c01[PXT], c10[PXT], c11[PXT], er[PXT], ed[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) {
+        const float d = dv.v[i], m = in.m[i];
+        const float a0 = lf.ax[i] + bx, a1 = lf.ay[i] + by, a2 = lf.az[i] + bz;
+        const float X = cd_fma(d, a0, cf.cX), Y = cd_fma(d, a1, cf.cY), Z = cd_fma(d, a2, cf.cZ);
+        const float iZ = cd_rcp(Z);
+        float g1 = 0.f;      // direct term before the depth head's jacobian, in units of ring j (times 2^20)
+        er[i] = 0.f;
+        if (REPROJ) {
+            const float t = X * iZ, u = Y * iZ;
+            const float ex = (cf.cx_t - mx[i]) - t, ey = (cf.cy_t - my[i]) + u;
+            const float e2 = cd_fma(ey, ey, ex * ex);
+            const float ie = cd_rsq(fmaxf(e2, 1e-30f));
+            er[i] = e2 * ie;
+            const float q = cd_fma(ey, cd_fma(-u, a2, a1), ex * cd_fma(t, a2, -a0));
+            g1 = (m * cf.drs) * ((ie * iZ) * q);
+        }
+        const float omx = 1.f - tx[i], omy = 1.f - ty[i];
+        const float w00 = omx * omy, w01 = tx[i] * omy, w10 = omx * ty[i], w11 = tx[i] * ty[i];
+        // exp head: jac(d) = d, so the weighted taps p_ij = w_ij d_ij serve the sampled depth AND the scatter (c_ij = -gz p_ij)
+        const float p00 = w00 * d00[i], p01 = w01 * d01[i], p10 = w10 * d10[i], p11 = w11 * d11[i];
+        const float zsum = (p00 + p01) + (p10 + p11);             // = -z of the sampled point
+        const float izp = cd_rcp(zsum);                           // = -1 / z
+        const float dd = iZ + izp;
+        ed[i] = fabsf(dd);
+        const float ms = m * cd_sign(dd);
+        const float g = cd_fma(-(ms * cf.dbs), a2 * (iZ * iZ), g1);
+        gd[i] = g * depth_jac<MODE>(d);
+        const float ngz = -((ms * cf.scs) * (izp * izp));         // -(scatter scale), in units of ring k (times 2^20)
+        float csum;
+        if (MODE == kDepthExp) {
+            c00[i] = ngz * p00; c01[i] = ngz * p01; c10[i] = ngz * p10; c11[i] = ngz * p11;
+            csum = fabsf(ngz) * zsum;
+        } else {
+            c00[i] = ngz * w00 * depth_jac<MODE>(d00[i]); c01[i] = ngz * w01 * depth_jac<MODE>(d01[i]);
+            c10[i] = ngz * w10 * depth_jac<MODE>(d10[i]); c11[i] = ngz * w11 * depth_jac<MODE>(d11[i]);
+            csum = MODE == kDepthIdentity ? fabsf(ngz) : fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]);
+        }
+        need_slow = need_slow || !(csum + fabsf(gd[i]) <= v.limit);       // (NaN fails the test)
+    }
+    if (__builtin_expect(env.any(need_slow), 0)) {     // the exact paths: the general pass redoes this wave's pass from scratch
+        process_rows<MODE, REPROJ, PXT>(v, env, r, l, in, p, 0, wk, nvk);
+        return;
+    }
+    // ---- stage 3: 5 integer LDS atomics per pixel, loss partial sums
+    float sum_r = 0.f, sum_d = 0.f;
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) {
+        env.add32(&v.Aj[own + (unsigned)i], sweep_scaled_to_fixed(gd[i]));
+        if (in.m[i] != 0.f) {
+            env.add32(&v.Ak[i0[i]], sweep_scaled_to_fixed(c00[i])); env.add32(&v.Ak[i0[i] + 1], sweep_scaled_to_fixed(c01[i]));
+            env.add32(&v.Ak[i0[i] + (unsigned)RW], sweep_scaled_to_fixed(c10[i])); env.add32(&v.Ak[i0[i] + (unsigned)RW + 1], sweep_scaled_to_fixed(c11[i]));
+        }
+        sum_r = cd_fma(in.m[i], er[i], sum_r);           // multiply, not select: 0 * inf = NaN exactly like the reference
+        sum_d = cd_fma(in.m[i], ed[i], sum_d);
     }
     r.acc_r += (double)sum_r; r.acc_d += (double)sum_d;
 }

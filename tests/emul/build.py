@@ -67,7 +67,7 @@ def fan_in(g, flow_fwd, flow_bwd, mask_fwd, mask_bwd):
     return lib().sweep_emul_fan_in(g["_raw"], _p(ff), _p(fb), _p(mf), _p(mb))
 
 
-def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False, order=0, service=False):
+def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False, order=0, service=False, fast=False):
     c = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
     depth = c(batch["depth"])
     B, _, H, W = depth.shape
@@ -78,6 +78,7 @@ def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False
     stats = (ctypes.c_long * 4)()
     lib().sweep_emul_set_order(int(order))
     lib().sweep_emul_set_service(int(service))
+    lib().sweep_emul_set_fast(int(fast))
     fn = lib().sweep_emul_loss
     fn.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_float, ctypes.c_float] + [ctypes.c_int] * 7 + [ctypes.c_void_p] * 5
     rc = fn(_p(depth), _p(ff), _p(fb), _p(mf), _p(mb), _p(intr), _p(extr), lambda_r, lambda_b, mode, B, H, W, pxt, ring_rows,

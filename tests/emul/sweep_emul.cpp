@@ -18,6 +18,7 @@ using namespace cd::sweep;
 namespace {
 
 int g_order = 0;   // 0: an item's sources run before its rows enter / leave, 1: after (see run_pair)
+int g_fast = 0;    // 1: source rows go through process_rows_fast (round 5) wherever the geometry allows it, else the general pass
 int g_service = 0; // 1: rows enter / leave through the frame's service wave (svc_* of loss_sweep_core.h) instead of every thread's own columns
 constexpr int kEmulNQ = 16;
 
@@ -81,7 +82,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
              const PairCam* cams, const Item* raw_items, int n_items, unsigned gbase0, float* grad_p, float* partial,
              HostEnv& env) {
     const float limit = sweep_limit_scaled(fan_in_of(g, ff, fb, mf, mb));
-    const int H = g.H, W = g.W, HW = H * W, ring = g.R * g.RW;
+    const int H = g.H, W = g.W, HW = H * W, ring = ring_rows(g) * g.RW;
     std::vector<float> D(2 * (size_t)ring, 0.f);
     std::vector<unsigned> A(2 * (size_t)ring, 0u);
     std::vector<PlanItem> items(n_items);
@@ -101,10 +102,15 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
     }
     std::vector<Regs<PXT>> regs(kThreads);
     std::vector<Lane<PXT>> lanes(kThreads);
+    std::vector<LaneF<PXT>> lanesf(kThreads);
     std::vector<int> fr(kThreads);
+    const bool fast = g_fast && PXT == 2 && fast_geometry_ok(g);
+    if (g_fast && !fast) { fprintf(stderr, "emul: geometry has no fast pass\n"); return -8; }
+    CamF camf[2] = {make_camf(vw[0].cj), make_camf(vw[1].cj)};
     for (int t = 0; t < kThreads; ++t) {
         fr[t] = t / kFrameThreads;
         lanes[t] = make_lane<PXT>(vw[fr[t]], t - fr[t] * kFrameThreads);
+        lanesf[t] = make_lanef<PXT>(vw[fr[t]], lanes[t]);
         init_regs<PXT>(regs[t]);
     }
     // prologue: the initial window [0, R) of both rings
@@ -162,6 +168,15 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
                         const Rec& me = items[it].f[f];
                         const Rec& ot = items[it].f[1 - f];
                         Inputs<PXT> in;
+                        if constexpr (PXT == 2) {
+                            if (fast) {      // the kernel's source waves: lanes with a row (the others are the service wave), items with a group
+                                if (lanes[t].on && me.p >= 0) {
+                                    load_inputs_all<PXT>(vw[f], lanesf[t], me.p, in);
+                                    process_rows_fast<MODE, REPROJ, PXT>(vw[f], camf[f], env, regs[t], lanes[t], lanesf[t], in, me.p, ot.w, ot.nv);
+                                }
+                                continue;
+                            }
+                        }
                         load_inputs<PXT>(vw[f], lanes[t], me.p, q, in);
                         process_rows<MODE, REPROJ, PXT>(vw[f], env, regs[t], lanes[t], in, me.p, q, ot.w, ot.nv);
                     }
@@ -226,6 +241,7 @@ int sweep_emul_fan_in(const int* geo, const float* ff, const float* fb, const fl
 
 void sweep_emul_set_order(int order) { g_order = order ? 1 : 0; }
 void sweep_emul_set_service(int on) { g_service = on ? 1 : 0; }
+void sweep_emul_set_fast(int on) { g_fast = on ? 1 : 0; }
 
 // geometry as the kernel would choose it: out[0..11] = the Geo fields; ring_rows > 0 overrides R (to force tiny rings)
 int sweep_emul_geo(int H, int W, int pxt, int ring_rows, int* out) {

@@ -213,3 +213,76 @@ def test_service_wave_assignment_is_bit_identical(oracle, mode):
             assert a["degenerate"]
         if name == "range" and mode != 2:      # (the reciprocal head's units, estimated from the data, absorb this case)
             assert a["overflow_entries"] > 0
+
+
+@pytest.mark.parametrize("gen,kw", [("scene", {}), ("pair", {}), ("pair", {"noise_px": 40.0})], ids=["scene", "unrelated", "wild"])
+@pytest.mark.parametrize("H,W", [(384, 224), (224, 384), (96, 224)])
+def test_fast_source_pass_vs_oracle(oracle, gen, kw, H, W):
+    """Round 5: `process_rows_fast` (the pass the GPU runs at its compile-time geometry: premultiplied camera constants, no selects,
+    one ring address per source thanks to the mirrored slot) against the fp64 oracle at the general pass's bounds -- fast path, wild
+    flows (every wave votes slow: the general pass takes over inside the fast one), both execution orders, service wave on."""
+    from consistent_depth_amd import synthetic
+    batch = (synthetic.make_scene_batch if gen == "scene" else synthetic.make_pair_batch)(2, H, W, seed=11, **kw)
+    args = (batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], 1.0, 0.1)
+    ref = oracle.consistency_loss(*args, dtype=np.float64)
+    if ref["total"][0] == 0.0:
+        pytest.skip("unrelated flows at this small size leave no pixel in bounds: empty masks, nothing to compare")
+    r32 = oracle.consistency_loss(*args, dtype=np.float32)
+    e = E.loss(batch, 1.0, 0.1, pxt=2, fast=True)
+    loss_rel, grad = _dist(oracle, e, ref)
+    assert loss_rel < 1e-6
+    assert grad < max(4 * oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]), 2e-6)
+    np.testing.assert_allclose(e["reprojection"], ref["reprojection"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(e["disparity"], ref["disparity"], rtol=1e-6, atol=1e-7)
+    e2 = E.loss(batch, 1.0, 0.1, pxt=2, order=1, fast=True)
+    np.testing.assert_array_equal(e["grad_depth"], e2["grad_depth"])
+    if W == 224:
+        e3 = E.loss(batch, 1.0, 0.1, pxt=2, order=1, service=True, fast=True)
+        np.testing.assert_array_equal(e["grad_depth"], e3["grad_depth"])
+        np.testing.assert_array_equal(e["total"], e3["total"])
+    g = E.loss(batch, 1.0, 0.1, pxt=2)           # the general pass on the same data: same exact-path decisions
+    assert e["overflow_entries"] == g["overflow_entries"] and e["degenerate"] == g["degenerate"]
+    if gen == "scene":
+        assert e["slow_lanes"] == 0 and e["overflow_entries"] == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_fast_source_pass_heads_scales_and_exact_paths(oracle, mode):
+    """The fast pass with all three depth heads, MiDaS' lambda and a reprojection-free configuration; values beyond the fixed-point range,
+    a degenerate depth and NaN take the same exact paths as in the general pass."""
+    from consistent_depth_amd import synthetic
+    base = synthetic.make_scene_batch(2, 96, 224, seed=4)
+    depth = base["depth"].astype(np.float64)
+    conv = {0: lambda d: d, 1: np.log, 2: lambda d: 1.0 / d}[mode]
+    jac = {0: 1.0, 1: depth, 2: -depth * depth}[mode]
+    for lr, lb in ((1.0, 0.1), (1.0, 1e-4), (0.0, 1.0)):
+        ref = oracle.consistency_loss(depth, base["flows"], base["masks"], base["intrinsics"], base["extrinsics"], lr, lb)
+        r32 = oracle.consistency_loss(depth, base["flows"], base["masks"], base["intrinsics"], base["extrinsics"], lr, lb, dtype=np.float32)
+        e = E.loss(dict(base, depth=conv(depth).astype(np.float32)), lr, lb, mode=mode, pxt=2, fast=True, service=True)
+        assert abs(e["total"][0] - ref["total"][0]) / abs(ref["total"][0]) < 1e-6
+        assert oracle.rel_l1(e["grad_depth"], ref["grad_depth"] * jac) < max(4 * oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]), 2e-6)
+        assert e["slow_lanes"] == 0
+    big = dict(base, depth=base["depth"].copy())
+    big["depth"][0, 1, 30:34, 100:104] = 1e-4                       # contributions far outside the fixed-point range
+    big = dict(big, depth=conv(big["depth"].astype(np.float64)).astype(np.float32))
+    a, b = E.loss(big, 1.0, 0.1, mode=mode, pxt=2), E.loss(big, 1.0, 0.1, mode=mode, pxt=2, fast=True)
+    assert a["overflow_entries"] == b["overflow_entries"] and (mode == 2 or b["overflow_entries"] > 0)
+    assert oracle.rel_l1(b["grad_depth"], a["grad_depth"]) < 2e-6
+    bad = dict(base, depth=conv(depth).astype(np.float32).copy())
+    bad["depth"][1, 0, 50, 60] = {0: -1.0, 1: np.inf, 2: 0.0}[mode]
+    assert E.loss(bad, 1.0, 0.1, mode=mode, pxt=2, fast=True)["degenerate"]
+    nan = dict(base, depth=conv(depth).astype(np.float32).copy())
+    nan["depth"][0, 0, 7, 9] = np.nan
+    e = E.loss(nan, 1.0, 0.1, mode=mode, pxt=2, fast=True)
+    assert np.isnan(e["total"][0]) and np.isnan(e["grad_depth"][0, 0, 7, 9])
+
+
+def test_mirrored_slot_survives_forced_general_pass():
+    """Slot R of a ring mirrors slot 0 (ring_rows): rows staged / flushed by either assignment keep both copies in step, and a run that
+    mixes fast and general passes (force_slow: every wave votes slow inside the fast pass) drains every accumulator word."""
+    from consistent_depth_amd import synthetic
+    batch = synthetic.make_scene_batch(1, 96, 224, seed=9)
+    a = E.loss(batch, 1.0, 0.1, pxt=2)
+    b = E.loss(batch, 1.0, 0.1, pxt=2, fast=True, force_slow=True, service=True)      # (the emulation fails on a non-drained accumulator)
+    np.testing.assert_array_equal(a["grad_depth"], b["grad_depth"])
+    np.testing.assert_array_equal(a["total"], b["total"])
