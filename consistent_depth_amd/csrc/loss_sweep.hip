@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     // The frame's SERVICE wave (loss_sweep_core.h: the eighth wave of each frame has no source pixels at W = 224 and takes over the
     // rows that enter and leave the ring; compile-time geometry only -- the run-time-geometry build keeps every thread on its columns).
     constexpr bool SVC = SG == 1 && PXT == kStaticPXT;
+    constexpr bool SRC_STAGES = SVC;       // the sources stage their own columns, the service wave only flushes (see below)
     if (SVC && (int)threadIdx.x - f * kFrameThreads >= g.RP * g.CG) {      // wave-uniform
         constexpr int NQ = kStaticSvcQuads;     // kStagePasses * RP rows of W / 4 quads (launch_sweep_inst checks it against the geometry)
         const int sl = (int)threadIdx.x - f * kFrameThreads - g.RP * g.CG;
@@ -280,11 +281,16 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         for (int i = 0; i < NQ; ++i) q.v[i][0] = q.v[i][1] = q.v[i][2] = q.v[i][3] = 0.f;
         Rec me = items[0].f[f];
         __syncthreads();
+        // Round 5: the rows ENTERING the rings are staged by the source waves again (two pixels per lane: their share of a frame's
+        // rows costs a source lane ~12 instructions per item); the service wave keeps the rows LEAVING them.  With both on one wave the
+        // service wave was the critical path of every item once the fast source pass had halved the sources' work: measured at 256
+        // pairs, sources alone 0.181 ms, service waves alone 0.209 ms -- a single wave issues an instruction every ~4-5 cycles and
+        // each of its quads is a latency chain (load -> exp -> LDS write; LDS read -> convert -> store).
         for (int it = 0; it < n_items; ++it) {
-            r.bad = !svc_stage<MODE, NQ>(v, sl, me.s_lo, me.s_hi, q) || r.bad;
+            if (!SRC_STAGES) r.bad = !svc_stage<MODE, NQ>(v, sl, me.s_lo, me.s_hi, q) || r.bad;
             const bool more = it + 1 < n_items;
             const Rec nx = items[more ? it + 1 : it].f[f];
-            svc_load<NQ>(v, sl, nx.s_lo, more ? nx.s_hi : nx.s_lo, q);
+            if (!SRC_STAGES) svc_load<NQ>(v, sl, nx.s_lo, more ? nx.s_hi : nx.s_lo, q);
             svc_flush<NQ>(v, sl, me.fl_lo, me.fl_hi);
             __syncthreads();
             me = nx;
@@ -320,7 +326,10 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
             const int nwk = items[nt].f[k].w, nnvk = items[nt].f[k].nv;
             if constexpr (FAST) load_inputs_all<PXT>(v, lf, nx.p > 0 ? nx.p : 0, nxt);      // (an item without a group, and the last one: row 0, unused)
             else load_inputs<PXT>(v, l, more ? nx.p : -1, 0, nxt);
-            if (!SVC) {
+            if (SRC_STAGES) {      // the depth rows entering now were requested during the previous item; request the next ones
+                r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
+                load_stage_nosel<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
+            } else if (!SVC) {
                 r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
                 load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
                 flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);

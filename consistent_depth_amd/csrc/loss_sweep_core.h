@@ -433,6 +433,20 @@ template <int PXT> CD_HD void load_stage(const View& v, const Lane<PXT>& l, int 
     }
 }
 
+// ... the same without anything to select after the loads (clamped addresses; stage_rows only reads the values of rows it stages): the
+// compiler has no reason to wait for them before the stage of the NEXT item
+template <int PXT> CD_HD void load_stage_nosel(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, float (*sv)[PXT]) {
+#pragma unroll
+    for (int s = 0; s < kStagePasses; ++s) {
+        const int row = s_lo + s * v.RP + l.rr;
+        const bool ok = row < s_hi && row < v.H;
+        const unsigned off = ok ? ((unsigned)(s_lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2 : 0u;
+        const VecF<PXT> a = ldgv<PXT>(v.vj, off);
+#pragma unroll
+        for (int i = 0; i < PXT; ++i) sv[s][i] = a.v[i];
+    }
+}
+
 // rows [s_lo, s_hi) enter the ring (their values are in sv; row r -> slot r & (R - 1)).  Returns false if a staged depth
 // is not a positive finite number (such an input takes the exact v1 path: see process_rows, "lenient").
 template <int MODE, int PXT>
@@ -562,31 +576,50 @@ template <int MODE, int NQ> CD_HD bool svc_stage(const View& v, int lane, int s_
     return good;
 }
 
-// rows [lo, hi) leave the ring (cf. flush_rows)
+// rows [lo, hi) leave the ring (cf. flush_rows).  Round 5: ONE wave per frame does this for everybody, so it is bound by how fast a
+// single wave issues instructions and by the latency chain LDS read -> convert -> store: all reads of the call are issued before the
+// first use, and the mirror of slot 0 (one row in R) is folded in by a separate, wave-uniform rare branch.
 template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) {
     const int QW = v.W >> 2;
+    const int nq = (hi - lo) * QW;
     const float unit = v.cj.unit_s;
+    VecU<2> n0[NQ], n1[NQ];
+    unsigned base[NQ];
+    bool any_mirror = false;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int qi = lane + kSvcLanes * i, rr = qi / QW, c4 = qi - rr * QW, row = lo + rr;
-        if (row < hi) {
-            const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW) + 4u * (unsigned)c4;
-            VecU<2>* a0 = reinterpret_cast<VecU<2>*>(&v.Aj[base]);
-            VecU<2>* a1 = reinterpret_cast<VecU<2>*>(&v.Aj[base + 2]);
-            VecU<2> n0 = *a0, n1 = *a1;
-            VecU<2> z; z.v[0] = z.v[1] = 0u;
-            *a0 = z; *a1 = z;
-            if ((row & (v.R - 1)) == 0) {              // what the fast pass added to the mirror of slot 0
-                VecU<2>* m0 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + 4u * (unsigned)c4]);
-                VecU<2>* m1 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + 4u * (unsigned)c4 + 2]);
+        const unsigned slot = (unsigned)(row & (v.R - 1));
+        base[i] = slot * (unsigned)v.RW + 4u * (unsigned)c4;
+        n0[i].v[0] = n0[i].v[1] = n1[i].v[0] = n1[i].v[1] = 0u;
+        if (qi < nq) {
+            n0[i] = *reinterpret_cast<const VecU<2>*>(&v.Aj[base[i]]); n1[i] = *reinterpret_cast<const VecU<2>*>(&v.Aj[base[i] + 2]);
+            any_mirror = any_mirror || slot == 0u;
+        }
+    }
+    VecU<2> z; z.v[0] = z.v[1] = 0u;
+    if (any_mirror) {      // (per lane; a row of slot 0 leaves once in R rows) what the fast pass added to the mirror of slot 0
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int qi = lane + kSvcLanes * i;
+            if (qi < nq && base[i] < (unsigned)v.RW) {
+                VecU<2>* m0 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + base[i]]);
+                VecU<2>* m1 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + base[i] + 2]);
                 const VecU<2> k0 = *m0, k1 = *m1;
-                n0.v[0] += k0.v[0]; n0.v[1] += k0.v[1]; n1.v[0] += k1.v[0]; n1.v[1] += k1.v[1];
+                n0[i].v[0] += k0.v[0]; n0[i].v[1] += k0.v[1]; n1[i].v[0] += k1.v[0]; n1[i].v[1] += k1.v[1];
                 *m0 = z; *m1 = z;
             }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qi = lane + kSvcLanes * i;
+        if (qi < nq) {
+            *reinterpret_cast<VecU<2>*>(&v.Aj[base[i]]) = z; *reinterpret_cast<VecU<2>*>(&v.Aj[base[i] + 2]) = z;
             VecF<4> g;
-            g.v[0] = (float)(int)n0.v[0] * unit; g.v[1] = (float)(int)n0.v[1] * unit;
-            g.v[2] = (float)(int)n1.v[0] * unit; g.v[3] = (float)(int)n1.v[1] * unit;
-            stgv<4>(v.gradj, ((unsigned)row * (unsigned)v.W + 4u * (unsigned)c4) << 2, g);
+            g.v[0] = (float)(int)n0[i].v[0] * unit; g.v[1] = (float)(int)n0[i].v[1] * unit;
+            g.v[2] = (float)(int)n1[i].v[0] * unit; g.v[3] = (float)(int)n1[i].v[1] * unit;
+            stgv<4>(v.gradj, ((unsigned)lo * (unsigned)v.W + 4u * (unsigned)qi) << 2, g);
         }
     }
     const int row = lo + lane;

@@ -152,6 +152,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
             for (int t = 0; t < kThreads; ++t) {
                 const Rec& nx = items[it + 1].f[fr[t]];
                 if (!service) load_stage<PXT>(vw[fr[t]], lanes[t], nx.s_lo, nx.s_hi, nxt[t].sv);
+                else if (g_service == 2) load_stage_nosel<PXT>(vw[fr[t]], lanes[t], nx.s_lo, nx.s_hi, nxt[t].sv);
             }
             if (service)
                 for (int f = 0; f < 2; ++f) {
@@ -185,8 +186,13 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
                     for (int f = 0; f < 2; ++f)
                         for (int sl = 0; sl < kSvcLanes; ++sl) {
                             const Rec& me = items[it].f[f];
-                            regs[f * kFrameThreads + svc0 + sl].bad = !svc_stage<MODE, kEmulNQ>(vw[f], sl, me.s_lo, me.s_hi, svc[f][sl]) || regs[f * kFrameThreads + svc0 + sl].bad;
+                            if (g_service == 1) regs[f * kFrameThreads + svc0 + sl].bad = !svc_stage<MODE, kEmulNQ>(vw[f], sl, me.s_lo, me.s_hi, svc[f][sl]) || regs[f * kFrameThreads + svc0 + sl].bad;
                             svc_flush<kEmulNQ>(vw[f], sl, me.fl_lo, me.fl_hi);
+                        }
+                    if (g_service == 2)     // round 5's split: rows ENTER through every thread's own columns, LEAVE through the service wave
+                        for (int t = 0; t < kThreads; ++t) {
+                            const Rec& me = items[it].f[fr[t]];
+                            regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], me.s_lo, me.s_hi, regs[t].sv) || regs[t].bad;
                         }
                 } else
                 for (int t = 0; t < kThreads; ++t) {
@@ -240,7 +246,7 @@ int sweep_emul_fan_in(const int* geo, const float* ff, const float* fb, const fl
 }
 
 void sweep_emul_set_order(int order) { g_order = order ? 1 : 0; }
-void sweep_emul_set_service(int on) { g_service = on ? 1 : 0; }
+void sweep_emul_set_service(int on) { g_service = on; }   // 1: rows enter and leave through the service wave; 2: they leave through it
 void sweep_emul_set_fast(int on) { g_fast = on ? 1 : 0; }
 
 // geometry as the kernel would choose it: out[0..11] = the Geo fields; ring_rows > 0 overrides R (to force tiny rings)
