@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void finalize_total_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------- profiling hook
-// bench.py brackets the fused pass (the main loss kernel only) with HIP events recorded on the
+// bench.py brackets the fused pass (row sweep: EVERYTHING the call enqueues; tile kernels: the gradient kernels) with HIP events recorded on the
 // stream the kernel is launched on; events are pre-created by cd_profile_begin so recording
 // costs ~1 us and never synchronises.  Not thread-safe; meant for one profiling thread.
 struct Profiler {
@@ -212,12 +212,11 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         }
         g_prof.pending_batch = B;
         const int cap = (g_force_overflow_cap >= 0 && g_force_overflow_cap < w.ovf_cap) ? g_force_overflow_cap : w.ovf_cap;
-        if (use_sweep)
-            rc = launch_sweep(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.ovf, cap,
-                              s, prof_before, prof_after, intr, extr, mask_sum, lambda_r, lambda_b);
-        else
-            rc = launch_slab(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.slabs,
-                             w.ovf, cap, s, prof_before, prof_after);
+        if (use_sweep)      // ONE kernel: gradient, per-pair losses and their mean are complete when it is (loss_sweep.hip)
+            return launch_sweep(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, grad, w.ovf, cap, s, prof_before,
+                                prof_after, intr, extr, mask_sum, lambda_r, lambda_b, reproj, disp, total);
+        rc = launch_slab(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.slabs,
+                         w.ovf, cap, s, prof_before, prof_after);
         if (rc != CD_OK) return rc;
         // device-side fallback: idle unless the overflow list overflowed (then it recomputes the gradient)
         const int* flag = owner_fallback_flag(w.ovf);
@@ -227,7 +226,7 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
             return rc;
         alt_flag = flag;
         alt_nparts = v1_blocks_per_plane(HW, fb_vec4 ? 4 : 1);
-        nparts = use_sweep ? 1 : owner_ntiles(H, W);
+        nparts = owner_ntiles(H, W);
     }
     hipLaunchKernelGGL(finalize_pairs_kernel, dim3(B), dim3(kWave), 0, s, w.partial, w.cams, nparts, lambda_r, lambda_b, reproj, disp,
                        alt_flag, w.partial_fb, alt_nparts);

@@ -35,11 +35,13 @@ int launch_sweep_plan(const float* ff, const float* fb, const float* mf, const f
 bool sweep_supported(int H, int W);
 bool sweep_preferred(int B, int H, int W);
 void set_sweep_pxt(int pxt);
-int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, const void* cams,
-                 const void* blob, int mode, bool reproj, int B, int H, int W, float* partial, float* grad, void* ovf_mem,
-                 int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t),
-                 const float* prep_intr = nullptr, const float* prep_extr = nullptr, const float* prep_mask_sum = nullptr,
-                 float lambda_r = 0.f, float lambda_b = 0.f);   // prep_intr: compute the per-pair constants (`cams`) here instead of a prep_kernel launch in front
+// ONE kernel per call: per-pair constants, sweep, the pair's overflow entries, exact mode for pairs the sweep cannot take, per-pair
+// losses and their batch mean (reproj / disp / total are complete when it is).  ovf_mem: 256-byte header + idx[cap] + val[cap], the list
+// is cut into B per-pair segments.  before / after: the profiling hooks around everything the call enqueues.
+int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, void* cams,
+                 const void* blob, int mode, bool reproj, int B, int H, int W, float* grad, void* ovf_mem, int ovf_cap, hipStream_t s,
+                 void (*before)(hipStream_t), void (*after)(hipStream_t), const float* intr, const float* extr, const float* mask_sum,
+                 float lambda_r, float lambda_b, float* reproj_out, float* disp_out, float* total_out);
 
 // ---- v3 (loss_slab.hip): source pass + gather pass; slabs = slab_floats(B,H,W) floats of scratch
 size_t slab_floats(int B, int H, int W);

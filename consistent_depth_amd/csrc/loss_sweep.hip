@@ -8,6 +8,7 @@
 // have 2 * B * tiles workgroups to spread.
 #include "loss_tiles.h"
 #include "loss_sweep_core.h"
+#include "loss_v1_pixel.h"
 
 namespace cd {
 
@@ -120,66 +121,53 @@ int launch_sweep_plan(const float* ff, const float* fb, const float* mf, const f
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
-// ---------------------------------------------------------------- accumulator units (per launch: they depend on the depths)
-// PairPrep (non-null intr): the per-(pair, direction) constants are computed HERE, by the pair's own workgroup, instead of by a
-// one-workgroup prep_kernel launch in front (loss_api.hip) -- the same code on the same inputs (fbar by the same block_sum over the
-// same 256 threads: identical bits), one launch less on the path of every gradient launch.
+// ---------------------------------------------------------------- per-pair constants and accumulator units
+// Computed by the pair's own workgroup in the sweep kernel's prologue (pair_constants below): round 2-4 launched them in front
+// (prep_kernel, then sweep_units_kernel: 18.6 us of latency chains per gradient call) -- the same code on the same inputs (fbar by
+// the same sum over the same 256 threads, the unit samples summed in index order by one thread: identical bits).
 struct PairPrep { const float* intr; const float* extr; const float* mask_sum; float lambda_r, lambda_b; };
 
-template <int MODE>
-__global__ __launch_bounds__(kUnitGrid * kUnitGrid) void sweep_units_kernel(const float* __restrict__ depth, const float* __restrict__ ff,
-                                                                            const float* __restrict__ fb, const float* __restrict__ mf,
-                                                                            const float* __restrict__ mb, PairCam* __restrict__ cams, int H, int W,
-                                                                            const PairPrep pp, int B) {
-    constexpr int NS = kUnitGrid * kUnitGrid;
-    static_assert(NS == kBlock, "fbar is reduced exactly like prep_kernel does");
-    __shared__ float sd[2][NS], ss[2][NS];
-    __shared__ int sn[2][NS];
-    const int b = blockIdx.x, t = threadIdx.x, HW = H * W;
-    if (pp.intr != nullptr) {
-        __shared__ float lds[kBlock / kWave];
-        __shared__ float fbar_s[2];
-        for (int k = 0; k < 2; ++k) {      // = prep_kernel (loss_api.hip)
-            float acc = 0.f;
-            for (int bb = threadIdx.x; bb < B; bb += kBlock) acc += pp.intr[(bb * 2 + k) * 4 + 0] + pp.intr[(bb * 2 + k) * 4 + 1];
-            acc = block_sum(acc, lds);
-            if (threadIdx.x == 0) fbar_s[k] = acc / (2.f * (float)B);
-            __syncthreads();
-        }
-        if (t == 0) prep_pair(pp.intr + b * 8, pp.extr + b * 24, pp.mask_sum + b * 2, fbar_s, pp.lambda_r, pp.lambda_b, B, H, W, cams + b * 2);
-        __syncthreads();      // the pair's constants are visible to the workgroup
-    }
-    for (int j = 0; j < 2; ++j) {
-        const UnitSample u = unit_sample_at<MODE>(cams + b * 2, depth + (size_t)b * 2 * HW, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW,
-                                                  mf + (size_t)b * HW, mb + (size_t)b * HW, H, W, j, t);
-        sd[j][t] = u.direct; ss[j][t] = u.scatter; sn[j][t] = u.valid;
-    }
-    __syncthreads();
-    if (t == 0) {   // 256 samples: summed in index order by one thread -- the order of the host emulation, bit-reproducible
-        float D[2] = {0.f, 0.f}, S[2] = {0.f, 0.f};
-        int n[2] = {0, 0};
-        for (int j = 0; j < 2; ++j)
-            for (int i = 0; i < NS; ++i) { D[j] += sd[j][i]; S[j] += ss[j][i]; n[j] += sn[j][i]; }
-        units_from_samples(cams + b * 2, D, S, n);
-    }
-}
-
-static int launch_sweep_units(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, PairCam* cams, int mode,
-                              int B, int H, int W, const PairPrep& pp, hipStream_t s) {
-    const dim3 grid(B), block(kUnitGrid * kUnitGrid);
-    if (mode == CD_DEPTH_EXP) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_EXP>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W, pp, B);
-    else if (mode == CD_DEPTH_RECIPROCAL) hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_RECIPROCAL>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W, pp, B);
-    else hipLaunchKernelGGL(sweep_units_kernel<CD_DEPTH_IDENTITY>, grid, block, 0, s, depth, ff, fb, mf, mb, cams, H, W, pp, B);
-    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
-}
-
 // ---------------------------------------------------------------- the sweep
+// Round 5: the call is ONE kernel.  A workgroup owns its pair from the per-pair constants to the pair's loss: nothing it needs is
+// produced by another workgroup, so
+//   * its overflow entries live in the pair's own SEGMENT of the list (count in LDS, no global atomic per push) and are applied by the
+//     workgroup itself after its last row has left the rings;
+//   * a pair that cannot be swept (no plan, a degenerate depth, a full segment) is recomputed by its own workgroup in the EXACT mode
+//     (exact_pair: the v1 per-pixel body with global atomics on the pair's two planes) -- no launch-wide fallback pass;
+//   * the pair's reprojection / disparity loss is written by the workgroup, the batch mean by whichever workgroup finishes last.
+// Round 4's call was 2 memsets + 7 kernels (units, sweep, overflow apply, guarded zero, guarded v1, two finalize kernels): 319 us
+// for 276 us of sweep (profiles/rocprofv3_loss_sweep_b256_r04.txt).
+struct WgState {           // in LDS (the `red` scratch behind the rings)
+    PairCam cam[2];
+    float wave_part[2 * kThreads / kWave];
+    unsigned ovf_n;        // pushes attempted by this workgroup
+    int redo;              // the pair must be recomputed in the exact mode
+    int is_last;
+    float fbar[2];
+    float red4[4];
+};
+static_assert(sizeof(WgState) <= kLdsReserve, "WgState must fit the LDS reserve behind the rings");
+
 struct DevEnv {
-    Overflow* ovf; unsigned* oidx; float* oval;
+    WgState* st; unsigned* oidx; float* oval; int seg_cap;     // oidx / oval: the pair's segment
     __device__ __forceinline__ static void add32(unsigned* p, int v) { atomicAdd(p, (unsigned)v); }   // ds_add_u32, no return
     __device__ __forceinline__ static bool any(bool x) { return __any(x) != 0; }
-    __device__ __forceinline__ void push(bool need, unsigned idx, float v) { ovf_push(need, ovf, oidx, oval, idx, v); }
-    __device__ __forceinline__ void degenerate() { ovf->degenerate = 1; }
+    // wave-aggregated append: ONE returning LDS atomic per wave and call; all lanes of the wave must call it (convergent)
+    __device__ __forceinline__ void push(bool need, unsigned idx, float v) {
+        const unsigned long long mask = __ballot(need);
+        if (mask == 0ull) return;  // wave-uniform
+        const int lane = threadIdx.x & (kWave - 1);
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned base = 0u;
+        if (lane == leader) base = atomicAdd(&st->ovf_n, (unsigned)__popcll(mask));
+        base = (unsigned)__shfl((int)base, leader, kWave);
+        if (need) {
+            const unsigned i = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            if (i < (unsigned)seg_cap) { oidx[i] = idx; oval[i] = v; }
+            else st->redo = 1;
+        }
+    }
+    __device__ __forceinline__ void degenerate() { st->redo = 1; }
 };
 
 struct SweepShape { Geo g; size_t stride, plan_off; };
@@ -201,12 +189,90 @@ static bool static_geometry_holds(const Geo& c) {
            kStaticH % 4 == 0;
 }
 
+struct SweepOut { float* reproj; float* disp; float* total; int* done; };     // per-pair losses [B], batch mean [1], the launch's finished-pairs counter
+
+// fbar (batch mean of (fx + fy) / 2 of the ref frames, consistency_loss.py:178), the pair's PairCam[2] (prep_pair) and the accumulator
+// units (units_from_samples) -> st.cam; scratch: 24 floats of LDS.  All kThreads threads call it.
+template <int MODE>
+__device__ __forceinline__ void pair_constants(WgState& st, float* scratch, const PairPrep& pp, const float* __restrict__ depth_p,
+                                               const float* __restrict__ ff, const float* __restrict__ fb, const float* __restrict__ mf,
+                                               const float* __restrict__ mb, int b, int B, int H, int W) {
+    constexpr int NS = kUnitGrid * kUnitGrid;
+    static_assert(NS == kBlock, "fbar is reduced like prep_kernel does: 256 threads, 4 wave sums added in order");
+    const int t = threadIdx.x, lane = t & (kWave - 1), wid = t / kWave;
+    for (int k = 0; k < 2; ++k) {
+        float acc = 0.f;
+        if (t < kBlock)
+            for (int bb = t; bb < B; bb += kBlock) acc += pp.intr[(bb * 2 + k) * 4 + 0] + pp.intr[(bb * 2 + k) * 4 + 1];
+        acc = wave_sum(acc);
+        if (t < kBlock && lane == 0) st.red4[wid] = acc;
+        __syncthreads();
+        if (t == 0) st.fbar[k] = (((0.f + st.red4[0]) + st.red4[1]) + st.red4[2] + st.red4[3]) / (2.f * (float)B);
+        __syncthreads();
+    }
+    if (t == 0) prep_pair(pp.intr + b * 8, pp.extr + b * 24, pp.mask_sum + b * 2, st.fbar, pp.lambda_r, pp.lambda_b, B, H, W, st.cam);
+    __syncthreads();
+    // The unit samples: 256 per direction, one per thread of waves 0..7; their sums by wave shuffles, then the 4 wave sums of a
+    // direction in wave order by one thread -- a fixed order (bit-reproducible; the host emulation sums in index order: the estimate
+    // is floored to a power of two, any estimate gives a correct gradient).
+    UnitSample u;
+    u.direct = u.scatter = 0.f; u.valid = 0;
+    if (t < 2 * NS) u = unit_sample_at<MODE>(st.cam, depth_p, ff, fb, mf, mb, H, W, t / NS, t % NS);
+    const float wd = wave_sum(u.direct), ws = wave_sum(u.scatter), wn = wave_sum((float)u.valid);
+    if (t < 2 * NS && lane == 0) { scratch[wid * 3] = wd; scratch[wid * 3 + 1] = ws; scratch[wid * 3 + 2] = wn; }
+    __syncthreads();
+    if (t == 0) {
+        float D[2] = {0.f, 0.f}, S[2] = {0.f, 0.f};
+        int n[2] = {0, 0};
+        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < NS / kWave; ++i) {
+                const int w = j * (NS / kWave) + i;
+                D[j] += scratch[w * 3]; S[j] += scratch[w * 3 + 1]; n[j] += (int)scratch[w * 3 + 2];
+            }
+        units_from_samples(st.cam, D, S, n);
+    }
+    __syncthreads();
+}
+
+// The EXACT mode of one pair, by its own workgroup: both gradient planes are zeroed and every source goes through the v1 per-pixel
+// body (global atomics, ~4 % of the HBM roofline: for the pairs the sweep cannot take -- no plan, a depth that is not a positive
+// finite number, a full overflow segment).  Returns the loss partial sums of direction f in (sr, sd) on thread f * kFrameThreads.
+template <int MODE, bool REPROJ>
+__device__ __forceinline__ void exact_pair(WgState& st, const float* __restrict__ dpair, const float* __restrict__ ffp, const float* __restrict__ fbp,
+                                           const float* __restrict__ mfp, const float* __restrict__ mbp, float* gpair, int H, int W,
+                                           float& sr, float& sd) {
+    const int HW = H * W, t = threadIdx.x;
+    float4* g4 = reinterpret_cast<float4*>(gpair);       // (planes are 16-byte aligned and HW * 4 % 16 == 0: run_loss's sweep_aligned)
+    for (int i = t; i < 2 * HW / 4; i += kThreads) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();       // (waits for the stores' acknowledgements: the atomics below reach the same L2 lines after them)
+    const int f = t / kFrameThreads, lt = t - f * kFrameThreads;
+    const PairCam cam = st.cam[f];
+    const float* v_ref = dpair + (f ? HW : 0); const float* v_tgt = dpair + (f ? 0 : HW);
+    const float* fl = f ? fbp : ffp; const float* mk = f ? mbp : mfp;
+    float* g_ref = gpair + (f ? HW : 0); float* g_tgt = gpair + (f ? 0 : HW);
+    float acc_r = 0.f, acc_d = 0.f;
+    for (int p = lt; p < HW; p += kFrameThreads) {
+        const int y = p / W, x = p - y * W;
+        v1_pixel<true, MODE, REPROJ, true>(cam, v_tgt, v_ref[p], fl[p], fl[HW + p], mk[p], (float)x, (float)y, p, H, W, g_ref, g_tgt, acc_r, acc_d);
+    }
+    acc_r = wave_sum(acc_r); acc_d = wave_sum(acc_d);
+    const int lane = t & (kWave - 1), wid = t / kWave;
+    if (lane == 0) { st.wave_part[wid * 2] = acc_r; st.wave_part[wid * 2 + 1] = acc_d; }
+    __syncthreads();
+    sr = sd = 0.f;
+    if (lt == 0) {
+        const int w0 = f * (kFrameThreads / kWave);
+        for (int i = 0; i < kFrameThreads / kWave; ++i) { sr += st.wave_part[(w0 + i) * 2]; sd += st.wave_part[(w0 + i) * 2 + 1]; }
+    }
+}
+
 template <int MODE, bool REPROJ, int PXT, int SG>
 __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const float* __restrict__ depth, const float* __restrict__ ff, const float* __restrict__ fb, const float* __restrict__ mf,
-    const float* __restrict__ mb, const PairCam* __restrict__ cams, const char* __restrict__ blob, float* __restrict__ partial,
-    float* __restrict__ grad, Overflow* ovf, unsigned* __restrict__ oidx, float* __restrict__ oval, const SweepShape sh) {
-    extern __shared__ __align__(16) unsigned smem[];   // [2][ring] accumulators, [2][ring] depths, reduction scratch
+    const float* __restrict__ mb, PairCam* __restrict__ cams, const char* __restrict__ blob, float* __restrict__ grad,
+    unsigned* __restrict__ oidx_all, float* __restrict__ oval_all, int seg_cap, const SweepShape sh, const PairPrep pp, int B,
+    const SweepOut out) {
+    extern __shared__ __align__(16) unsigned smem[];   // [2][ring] accumulators, [2][ring] depths, WgState
     const Geo g = SG == 1 ? make_geo(kStaticH, kStaticW, kStaticPXT) : sh.g;
     const int b = blockIdx.x, HW = g.H * g.W, ring = ring_rows(g) * g.RW;
     const int f = uni((int)(threadIdx.x / kFrameThreads)), k = 1 - f;   // whole waves serve one frame: everything derived from f is scalar
@@ -220,15 +286,20 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     float* D0 = reinterpret_cast<float*>(smem + 2 * ring);
     v.Aj = smem + (f ? ring : 0); v.Ak = smem + (f ? 0 : ring);
     v.Dj = D0 + (f ? ring : 0); v.Dk = D0 + (f ? 0 : ring);
-    float* red = D0 + 2 * ring;
+    WgState& st = *reinterpret_cast<WgState*>(D0 + 2 * ring);
+    if (threadIdx.x == 0) { st.ovf_n = 0u; st.redo = 0; st.is_last = 0; }
+    // ---- the pair's constants
+    pair_constants<MODE>(st, st.wave_part, pp, dpair, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW,
+                         mf + (size_t)b * HW, mb + (size_t)b * HW, b, B, g.H, g.W);
+    if (threadIdx.x < 2 * (int)(sizeof(PairCam) / sizeof(float)))      // (kept in the workspace: debugging, the tile kernels' format)
+        reinterpret_cast<float*>(cams + b * 2)[threadIdx.x] = reinterpret_cast<const float*>(st.cam)[threadIdx.x];
     {   // the direction's constants, once, into scalar registers
-        const PairCam& pc = cams[b * 2 + f];
-        Cam c = make_cam(pc);
+        Cam c = make_cam(st.cam[f]);
         float* cf = reinterpret_cast<float*>(&c);
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(Cam) / sizeof(float)); ++i) cf[i] = uni(cf[i]);
         v.cj = c;
-        v.unit_k_s = uni(cams[b * 2 + k].unit) * (1.f / SWEEP_FX_ONE_F);
+        v.unit_k_s = uni(st.cam[k].unit) * (1.f / SWEEP_FX_ONE_F);
     }
     v.gbj = (unsigned)b * 2u * (unsigned)HW + (f ? (unsigned)HW : 0u);
     v.gbk = (unsigned)b * 2u * (unsigned)HW + (f ? 0u : (unsigned)HW);
@@ -236,21 +307,17 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const PlanItem* __restrict__ items = reinterpret_cast<const PlanItem*>(ph + 1);
     const int n_items = ph->n_items;
     v.limit = uni(ph->limit);
-    if (n_items <= 0 || ph->G != g.G || ph->R != g.R || ph->PXT != g.PXT) {
-        // no plan (the planner's item backstop), or one made for another geometry (cd_debug_set_loss_sweep changed after the
-        // blob was cached): this pair cannot be swept -- raise the degenerate flag, the guarded exact v1 pass recomputes the
-        // gradient and the loss of the launch (loss_api.hip).  Uniform per workgroup: no barrier has been passed yet.
-        if (threadIdx.x == 0) ovf->degenerate = 1;
-        if ((threadIdx.x & (kFrameThreads - 1)) == 0) {
-            float* o = partial + (size_t)(b * 2 + f) * 2;
-            o[0] = o[1] = 0.f;
-        }
-        return;
-    }
-    DevEnv env{ovf, oidx, oval};
-    const Lane<PXT> l = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);
+    // no plan (the planner's item backstop, a fan-in beyond the accumulators' range), or one made for another geometry
+    // (cd_debug_set_loss_sweep changed after the blob was cached): this pair cannot be swept -> the exact mode below.  Workgroup-uniform.
+    const bool has_plan = !(n_items <= 0 || ph->G != g.G || ph->R != g.R || ph->PXT != g.PXT);
+    unsigned* oidx = oidx_all + (size_t)b * seg_cap;
+    float* oval = oval_all + (size_t)b * seg_cap;
+    __syncthreads();       // (pair_constants' scratch is free: the rings can be cleared)
     Regs<PXT> r;
     init_regs<PXT>(r);
+    if (has_plan) {
+    DevEnv env{&st, oidx, oval, seg_cap};
+    const Lane<PXT> l = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);
     for (int i = threadIdx.x; i < 2 * ring; i += kThreads) smem[i] = 0u;
     const int init_hi = init_stage_hi(g);
     for (int lo = 0; lo < init_hi; lo += kStagePasses * g.RP) {     // prologue: the initial window [0, R)
@@ -319,11 +386,16 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         // can fold back into "load right before the first use").  Round 4 issued them at the END of item t -- right before the barrier
         // -- and waited for them at the top of item t + 1: every wave of the workgroup then sat out one full memory latency per item
         // at the same time (all of them have just passed the barrier), with nothing left on the CU to cover it.
+        // The plan records are scalar loads: the record of item t + 2 is requested at the top of item t and first used at the top of
+        // item t + 1 (the loads of item t + 1's inputs need its row right away: a record read at the top of its own use exposed a
+        // scalar-cache latency per item on every wave at once).
+        Rec nx = items[n_items > 1 ? 1 : 0].f[f];
+        int nwk = items[n_items > 1 ? 1 : 0].f[k].w, nnvk = items[n_items > 1 ? 1 : 0].f[k].nv;
         auto item = [&](int it, const Inputs<PXT>& cur, Inputs<PXT>& nxt) {
             const bool more = it + 1 < n_items;
-            const int nt = more ? it + 1 : it;
-            const Rec nx = items[nt].f[f];
-            const int nwk = items[nt].f[k].w, nnvk = items[nt].f[k].nv;
+            const int t2 = it + 2 < n_items ? it + 2 : n_items - 1;
+            const Rec n2 = items[t2].f[f];
+            const int n2wk = items[t2].f[k].w, n2nvk = items[t2].f[k].nv;
             if constexpr (FAST) load_inputs_all<PXT>(v, lf, nx.p > 0 ? nx.p : 0, nxt);      // (an item without a group, and the last one: row 0, unused)
             else load_inputs<PXT>(v, l, more ? nx.p : -1, 0, nxt);
             if (SRC_STAGES) {      // the depth rows entering now were requested during the previous item; request the next ones
@@ -339,6 +411,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
             } else process_rows<MODE, REPROJ, PXT>(v, env, r, l, cur, me.p, 0, wk, nvk);
             __syncthreads();
             me = nx; wk = nwk; nvk = nnvk;
+            nx = n2; nwk = n2wk; nnvk = n2nvk;
         };
         for (int it = 0; it < n_items; it += 2) {
             item(it, inA, inB);
@@ -363,24 +436,74 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     }
     }
     if (env.any(r.bad) && (threadIdx.x & (kWave - 1)) == 0) env.degenerate();
-    // loss partial sums: one (reprojection, disparity) pair per (pair, direction)
-    float ar = wave_sum((float)r.acc_r), ad = wave_sum((float)r.acc_d);
-    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    if (lane == 0) { red[wid * 2] = ar; red[wid * 2 + 1] = ad; }
+    // loss partial sums: one (reprojection, disparity) pair per wave
+    {
+        const float ar = wave_sum((float)r.acc_r), ad = wave_sum((float)r.acc_d);
+        const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+        if (lane == 0) { st.wave_part[wid * 2] = ar; st.wave_part[wid * 2 + 1] = ad; }
+    }
+    }                      // has_plan
+    // (No fence: the gradient rows this workgroup stored and the atomics it may add to them below go through the same L1 -> L2 path of
+    // this CU, and the barrier waits for the stores' acknowledgements.  An agent-scope fence here writes back the XCD's whole L2 --
+    // megabytes of freshly written gradient -- and cost ~100 us per workgroup when every thread issued one: 0.232 -> 0.332 ms.)
     __syncthreads();
-    if ((threadIdx.x & (kFrameThreads - 1)) == 0) {
-        const int w0 = f * (kFrameThreads / kWave);
-        float sr = 0.f, sd = 0.f;
-        for (int i = 0; i < kFrameThreads / kWave; ++i) { sr += red[(w0 + i) * 2]; sd += red[(w0 + i) * 2 + 1]; }
-        float* o = partial + (size_t)(b * 2 + f) * 2;
-        o[0] = sr; o[1] = sd;
+    float sr = 0.f, sd = 0.f;       // the pair's loss partial sums of direction f, on thread f * kFrameThreads
+    if (!has_plan || st.redo != 0) {        // workgroup-uniform (read after the barrier)
+        __syncthreads();
+        exact_pair<MODE, REPROJ>(st, dpair, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW, mf + (size_t)b * HW, mb + (size_t)b * HW,
+                                 grad + (size_t)b * 2 * HW, g.H, g.W, sr, sd);
+    } else {
+        // the pair's overflow entries (taps outside the rings, values beyond the fixed-point range): written by this workgroup, applied by it
+        const unsigned n = st.ovf_n;
+        for (unsigned i = threadIdx.x; i < n; i += kThreads) atomic_add_f32(grad + oidx[i], oval[i]);
+        if ((threadIdx.x & (kFrameThreads - 1)) == 0) {
+            const int w0 = f * (kFrameThreads / kWave);
+            for (int i = 0; i < kFrameThreads / kWave; ++i) { sr += st.wave_part[(w0 + i) * 2]; sd += st.wave_part[(w0 + i) * 2 + 1]; }
+        }
+    }
+    // ---- the pair's losses (what finalize_pairs_kernel does for the tile kernels: fixed order, fp64), then the batch mean by the
+    // workgroup that finishes last (finalize_total_kernel's order: 256 strided fp64 sums, LDS tree)
+    if ((threadIdx.x & (kFrameThreads - 1)) == 0) { st.red4[f * 2] = sr; st.red4[f * 2 + 1] = sd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double rr[2], qq[2];
+        for (int kk = 0; kk < 2; ++kk) {
+            rr[kk] = (double)st.red4[kk * 2] * (double)st.cam[kk].invS;
+            qq[kk] = (double)st.cam[kk].fbar * ((double)st.red4[kk * 2 + 1] * (double)st.cam[kk].invS);
+        }
+        // Hand-off to the workgroup that finishes last, WITHOUT fences (a release fence writes back every dirty line of the XCD's L2):
+        // write-through (sc1) stores of the two numbers, drained, then the device-scope counter; the reader uses sc1 loads
+        // (MI355X_MICROARCH.md, inter-workgroup visibility: "sc0 sc1 stores and loads both sides").
+        __hip_atomic_store(out.reproj + b, pp.lambda_r > 0.f ? (float)((double)pp.lambda_r * (rr[0] + rr[1]) * 0.5) : 0.f, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(out.disp + b, pp.lambda_b > 0.f ? (float)((double)pp.lambda_b * (qq[0] + qq[1]) * 0.5) : 0.f, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st.is_last = __hip_atomic_fetch_add(out.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == B - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (st.is_last != 0) {
+        double* ld = reinterpret_cast<double*>(smem);
+        if (threadIdx.x < kBlock) {
+            double acc = 0.0;
+            for (int bb = threadIdx.x; bb < B; bb += kBlock)
+                acc += (double)__hip_atomic_load(out.reproj + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                       (double)__hip_atomic_load(out.disp + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ld[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        for (int s2 = kBlock / 2; s2 > 0; s2 >>= 1) {
+            if ((int)threadIdx.x < s2) ld[threadIdx.x] += ld[threadIdx.x + s2];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out.total[0] = (float)(ld[0] / (double)B);
     }
 }
 
 struct SweepArgs {
     const float* depth; const float* ff; const float* fb; const float* mf; const float* mb;
-    const PairCam* cams; const char* blob; float* partial; float* grad; Overflow* ovf; unsigned* oidx; float* oval;
-    SweepShape sh;
+    PairCam* cams; const char* blob; float* grad; unsigned* oidx; float* oval; int seg_cap;
+    SweepShape sh; PairPrep pp; int B; SweepOut out;
 };
 
 template <int MODE, bool REPROJ, int PXT, int SG>
@@ -393,7 +516,7 @@ static int launch_sweep_sg(const SweepArgs& a, int B, size_t lds, hipStream_t s)
         configured = true;
     }
     hipLaunchKernelGGL((loss_sweep_kernel<MODE, REPROJ, PXT, SG>), dim3(B), dim3(kThreads), lds, s, a.depth, a.ff, a.fb, a.mf, a.mb,
-                       a.cams, a.blob, a.partial, a.grad, a.ovf, a.oidx, a.oval, a.sh);
+                       a.cams, a.blob, a.grad, a.oidx, a.oval, a.seg_cap, a.sh, a.pp, a.B, a.out);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -435,38 +558,35 @@ bool sweep_preferred(int B, int H, int W) {
     return sweep_supported(H, W) && g.R >= 24 && B >= 96;
 }
 
-// Enqueues: overflow header reset, [before_main] sweep [after_main], overflow apply.  Partial sums: partial[(b*2+k)*2 + {0,1}].
+// Enqueues: [before] reset of the finished-pairs counter, the sweep [after].  The per-pair losses, their batch mean and the whole gradient
+// are complete when the kernel is: nothing follows it (loss_api.hip).
 static const bool g_sweep_env_read = [] {
     const char* e = getenv("CD_AMD_SWEEP_STATIC_GEO");
     if (e && e[0] == '0') g_sweep_static_geo = false;
     return true;
 }();
 
-int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, const void* cams,
-                 const void* blob, int mode, bool reproj, int B, int H, int W, float* partial, float* grad, void* ovf_mem,
-                 int ovf_cap, hipStream_t s, void (*before_main)(hipStream_t), void (*after_main)(hipStream_t), const float* prep_intr,
-                 const float* prep_extr, const float* prep_mask_sum, float lambda_r, float lambda_b) {
+int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, void* cams,
+                 const void* blob, int mode, bool reproj, int B, int H, int W, float* grad, void* ovf_mem, int ovf_cap, hipStream_t s,
+                 void (*before)(hipStream_t), void (*after)(hipStream_t), const float* intr, const float* extr, const float* mask_sum,
+                 float lambda_r, float lambda_b, float* reproj_out, float* disp_out, float* total_out) {
     const Geo g = sweep_geo(H, W);
-    if (!sweep_supported(H, W)) return CD_ERR_UNSUPPORTED;
+    if (!sweep_supported(H, W) || !intr || !extr || !mask_sum) return CD_ERR_UNSUPPORTED;
     Overflow* ovf = (Overflow*)ovf_mem;
     unsigned* oidx = (unsigned*)((char*)ovf_mem + 256);
     float* oval = (float*)(oidx + ovf_cap);
-    if (hipMemsetAsync(ovf, 0, sizeof(Overflow), s) != hipSuccess) return CD_ERR_LAUNCH;
-    if (hipMemsetD32Async((hipDeviceptr_t)&ovf->cap, ovf_cap, 1, s) != hipSuccess) return CD_ERR_LAUNCH;
-    SweepArgs prm{depth, ff, fb, mf, mb, (const PairCam*)cams, (const char*)blob, partial, grad, ovf, oidx, oval,
-                  SweepShape{g, pair_record_bytes(H, W), plan_offset(H, W)}};
+    if (before) before(s);
+    if (hipMemsetAsync(&ovf->count, 0, sizeof(int), s) != hipSuccess) return CD_ERR_LAUNCH;     // the finished-pairs counter
+    SweepArgs prm{depth, ff, fb, mf, mb, (PairCam*)cams, (const char*)blob, grad, oidx, oval, ovf_cap / B,
+                  SweepShape{g, pair_record_bytes(H, W), plan_offset(H, W)}, PairPrep{intr, extr, mask_sum, lambda_r, lambda_b}, B,
+                  SweepOut{reproj_out, disp_out, total_out, &ovf->count}};
     const size_t lds = ring_lds_bytes(g);
-    const PairPrep pp{prep_intr, prep_extr, prep_mask_sum, lambda_r, lambda_b};     // prep_intr == nullptr: `cams` is already filled (prep_kernel)
-    if (launch_sweep_units(depth, ff, fb, mf, mb, (PairCam*)const_cast<void*>(cams), mode, B, H, W, pp, s) != CD_OK) return CD_ERR_LAUNCH;
-    if (before_main) before_main(s);
     int rc;
     if (mode == CD_DEPTH_EXP) rc = launch_sweep_mode<CD_DEPTH_EXP>(reproj, prm, B, lds, s);
     else if (mode == CD_DEPTH_RECIPROCAL) rc = launch_sweep_mode<CD_DEPTH_RECIPROCAL>(reproj, prm, B, lds, s);
     else rc = launch_sweep_mode<CD_DEPTH_IDENTITY>(reproj, prm, B, lds, s);
-    if (after_main) after_main(s);
-    if (rc != CD_OK) return rc;
-    launch_overflow_apply(ovf_mem, ovf_cap, grad, s);
-    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+    if (after) after(s);
+    return rc;
 }
 
 }  // namespace cd
