@@ -146,8 +146,8 @@ def parse():
     ap.add_argument("--no-loss-microbench", action="store_true")
     ap.add_argument("--no-loss-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--traffic-timeout", type=int, default=90, help="seconds each PMC pass may take")
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-timeout", type=int, default=150, help="seconds the CPU-baseline subprocess may take")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed full steps of the CPU baseline (median reported; + 10 loss-only evaluations)")
+    ap.add_argument("--cpu-timeout", type=int, default=240, help="seconds the CPU-baseline subprocess may take")
     ap.add_argument("--miopen-find", action="store_true",
                     help="torch backend only: let MIOpen benchmark-search every conv (minutes of start-up)")
     return ap.parse_args()
@@ -466,7 +466,9 @@ def main():
                 log("loss kernel HBM traffic (2 rocprofv3 --pmc passes)")
                 traffic, traffic_note = loss_traffic_pmc(args.loss_batch, H, W, args.traffic_timeout)
             alg = LOSS_BYTES_PER_PAIR_PX * px * args.loss_batch
-            out["roofline"] = {"kernel": "loss_sweep_kernel (row sweep: one workgroup per pair, one gradient launch)" if sweep else
+            out["roofline"] = {"kernel": "loss_sweep_kernel = the WHOLE gradient call (row sweep, one workgroup per pair: per-pair constants, sweep, overflow "
+                                         "entries, per-pair losses and their mean in ONE kernel + the 4-byte counter reset in front; the HIP events bracket "
+                                         "everything cd_consistency_loss_fwd_bwd enqueues)" if sweep else
                                          "loss_source_kernel + loss_gather4_kernel (one gradient launch)",
                                "bound": "hbm", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -506,16 +508,21 @@ def main():
                                  "images": images_np, "batch": b_np, "steps": args.cpu_steps, "threads": cores}, f)
                 code = ("import pickle,sys,torch;sys.path.insert(0,%r);from oracle import cpu_step;"
                         "d=pickle.load(open(%r,'rb'));"
-                        "print('SEC',cpu_step.time_steps(d['state'],d['images'],d['batch'],n_steps=d['steps'],warmup=1,threads=d['threads']))"
+                        "f,l,a=cpu_step.time_steps(d['state'],d['images'],d['batch'],n_steps=d['steps'],warmup=1,threads=d['threads'],loss_steps=10);"
+                        "print('SEC',f,l,min(a),max(a))"
                         % (REPO, blob))
                 env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
                 try:
                     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
-                    sec = float([ln for ln in r.stdout.splitlines() if ln.startswith("SEC")][-1].split()[1])
+                    sec, loss_sec, smin, smax = [float(x) for x in [ln for ln in r.stdout.splitlines() if ln.startswith("SEC")][-1].split()[1:5]]
                     out["cpu_baseline"] = {"value": round(B / sec, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                                           "sample": f"{args.cpu_steps} full steps (+1 warm-up; per-step time extrapolated to pairs/s) on the first "
+                                           "loss_only": {"value": round(B / loss_sec, 3), "unit": "frame-pairs/s", "ms_per_call": round(loss_sec * 1e3, 2),
+                                                         "sample": f"10 evaluations (+1 warm-up) of loss + d loss / d depth on the same BS{B} batch, C oracle "
+                                                                   "(oracle/cd_oracle.c, fp32, one thread per pair-direction), median"},
+                                           "sample": f"{args.cpu_steps} full steps (+1 warm-up), MEDIAN per-step time extrapolated to pairs/s, on the first "
                                                      f"BS{B} batch of the same clip: torch CPU fp32 hourglass fwd+bwd (train-mode BN) + "
-                                                     f"C-oracle loss + torch Adam, {sec:.2f} s/step, {cores} threads"}
+                                                     f"C-oracle loss + torch Adam, {sec:.2f} s/step (min {smin:.2f}, max {smax:.2f}), {cores} threads = the "
+                                                     f"cgroup's CPU quota"}
                 except (subprocess.TimeoutExpired, IndexError, ValueError) as e:
                     out["cpu_baseline"] = {"value": None, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                            "sample": f"not completed within {args.cpu_timeout}s ({type(e).__name__})"}

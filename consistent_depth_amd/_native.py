@@ -13,7 +13,7 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # CD_AMD_LIB: load another build of the SAME library (A/B measurements of kernel variants, tools/exp/build_variants.sh); not a fallback
 SO_PATH = os.environ.get("CD_AMD_LIB") or os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 
 _lib = None
@@ -41,6 +41,7 @@ SIGNATURES = {
     "cd_flow_consistency_masks": (c_i, [c_p, c_p, c_p, c_p, c_i, ctypes.c_double, ctypes.c_double, c_i, c_i, c_i, c_p, c_p, c_p]),
     "cd_warp_image": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "cd_depth_to_points": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "cd_frame_median_scales": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "cd_conv2d_packed_weight_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "cd_conv2d_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "cd_conv2d_pack_weights_table": (c_i, [c_p, c_i, c_p]),

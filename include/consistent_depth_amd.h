@@ -49,7 +49,7 @@ typedef enum cd_depth_mode {
  * cd_conv2d_fwd_multi added, cd_bn_relu_bwd's last
  * argument became a flags bitfield, cd_debug_set_loss_variant(2) is refused).
  * The loader (consistent_depth_amd/_native.py) refuses a library whose cd_abi_version() differs from this constant. */
-#define CD_ABI_VERSION 6
+#define CD_ABI_VERSION 7
 int cd_abi_version(void);
 
 /* Batch-statistics buffers (the `stats` arguments below) hold CD_BN_STAT_SLOTS partial copies:
@@ -203,6 +203,15 @@ int cd_warp_image(const float* images, const float* depths, const float* intrins
  * sums over the pixels -> sums_out[N][3] (fp64, zeroed inside) -- the scene centres of geometry.py:142-176 calibrate_scale. */
 int cd_depth_to_points(const float* depths, const float* intrinsics, int N, int H, int W, float* points_out,
                        double* sums_out, void* stream);
+
+/* Per-frame median scale of the initial depth maps against COLMAP's dense depth (scale_calibration.py:253-278: the stage that
+ * produces scales.csv and metadata_scaled.npz, the camera file the fine-tuning path reads).  inv_src, inv_cmp (N,H,W): inverse
+ * depths of the depth model and of COLMAP (NaN where COLMAP has no value), same resolution.  Per frame: scales_out[i] =
+ * np.median((inv_src / inv_cmp)[isfinite(inv_cmp)]) -- EXACT, bit for bit numpy's float32 result incl. the mean of the two middle
+ * values for an even count (NaN when no pixel is valid or a selected ratio is NaN); n_valid_out[i] = number of finite COLMAP pixels
+ * (the caller applies --dense_pixel_ratio); scaled_out (N,H,W) or NULL = inv_src / scale. */
+int cd_frame_median_scales(const float* inv_src, const float* inv_cmp, int N, int H, int W, float* scales_out, int* n_valid_out,
+                           float* scaled_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Depth CNN layers (reference: the un-vendored Mannequin-Challenge hourglass called at

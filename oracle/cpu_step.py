@@ -54,13 +54,26 @@ class CpuFineTuner:
         return out, depth.detach()
 
 
-def time_steps(state_dict, images, batch, n_steps=2, warmup=1, threads=None):
+def time_steps(state_dict, images, batch, n_steps=5, warmup=1, threads=None, loss_steps=10):
+    """Seconds per full step and per loss-only evaluation (loss + d loss / d depth of the same batch) -- MEDIANS over the timed
+    repetitions (>= 3 full + >= 10 loss-only steps).  Returns (full_s, loss_s, all full-step times)."""
     if threads:
         torch.set_num_threads(threads)
     ft = CpuFineTuner(state_dict)
+    depth = None
     for _ in range(warmup):
-        ft.step(images, batch)
-    t0 = time.perf_counter()
+        _, depth = ft.step(images, batch)
+    full = []
     for _ in range(n_steps):
-        ft.step(images, batch)
-    return (time.perf_counter() - t0) / n_steps
+        t0 = time.perf_counter()
+        _, depth = ft.step(images, batch)
+        full.append(time.perf_counter() - t0)
+    d = depth.numpy()
+    loss = []
+    for i in range(loss_steps + 1):
+        t0 = time.perf_counter()
+        oracle.consistency_loss(d, batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], ft.lambda_r, ft.lambda_b,
+                                dtype=np.float32)
+        if i:            # (the first evaluation is the warm-up)
+            loss.append(time.perf_counter() - t0)
+    return float(np.median(full)), float(np.median(loss)) if loss else float("nan"), full

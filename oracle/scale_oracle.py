@@ -1,0 +1,138 @@
+"""TEST INFRASTRUCTURE ONLY -- the reference's per-frame scale stage on the CPU, two ways:
+
+  * `reference_stage(...)`: EXECUTES /root/reference/scale_calibration.py's own source lines 228-311 ("Compute per-frame scales" to
+    the np.savez of metadata_scaled.npz) -- they sit in the middle of a 240-line function that starts by running COLMAP, so they cannot
+    be called; the lines are read from the reference file (unmodified, build container only), de-indented and exec'd in a namespace
+    that provides what the function's earlier part would have defined (video, out_dir, args, frame_range, the two depth formats, ...)
+    and the stubs of SURVEY.md section 8c (cv2.resize INTER_NEAREST restated over numpy, visualisation = no-op).
+  * `numpy_stage(...)`: the same arithmetic restated in numpy (what the GPU tests compare with on the GPU box, where
+    /root/reference does not exist); oracle/gen_golden_scale.py pins it to `reference_stage` on seeded inputs.
+Nothing here is reachable from consistent_depth_amd/.
+"""
+import os
+import sys
+import textwrap
+import types
+from os.path import join as pjoin
+
+import numpy as np
+
+REF = "/root/reference"
+
+
+def nearest_resize(img, dsize):
+    """cv2.resize(img, dsize=(W, H), interpolation=INTER_NEAREST): OpenCV's resizeNN, index arithmetic in double."""
+    W, H = dsize
+    h, w = img.shape[:2]
+    ys = np.minimum(np.floor(np.arange(H) * (1.0 / (H / float(h)))).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(W) * (1.0 / (W / float(w)))).astype(np.int64), w - 1)
+    return img[ys][:, xs]
+
+
+def numpy_stage(inv_src, inv_cmp, dense_pixel_ratio=0.3):
+    """inv_src, inv_cmp: {frame: (H,W) float32} -> ({frame: float scale}, {frame: scaled inverse depth}) -- scale_calibration.py:253-278."""
+    scales, scaled = {}, {}
+    for i in sorted(inv_src):
+        if i not in inv_cmp:
+            continue
+        a = inv_src[i]
+        c = nearest_resize(inv_cmp[i], a.shape[:2][::-1])
+        ix = np.isfinite(c)
+        if np.sum(ix) / ix.size < dense_pixel_ratio:
+            continue
+        with np.errstate(all="ignore"):
+            s = np.median((a / c)[ix])
+            scales[i] = float(s)
+            scaled[i] = a / s
+    return scales, scaled
+
+
+def scaled_metadata(intrinsics, extrinsics, scales):
+    """:286-311 -> (src_to_colmap_scales (M,2) float64, extrinsics with translations / mean scale)."""
+    xs = sorted(scales.keys())
+    table = np.stack((np.array(xs), np.array([scales[x] for x in xs])), axis=-1)
+    ext = np.array(extrinsics, copy=True)
+    ext[..., -1] /= table[:, 1].mean()
+    return table, ext
+
+
+def reference_stage(path, out_dir, frames, model_type="mc", dense_frame_ratio=0.95, dense_pixel_ratio=0.3):
+    """Run the reference's own lines 228-311 on the directory layout they expect; returns what they wrote."""
+    src = open(pjoin(REF, "scale_calibration.py")).read().splitlines()
+    first = next(i for i, ln in enumerate(src) if 'print_banner("Compute per-frame scales")' in ln)
+    last = next(i for i, ln in enumerate(src) if "scales=src_to_colmap_scales," in ln) + 1          # ... the closing parenthesis of np.savez
+    body = textwrap.dedent("\n".join(src[first:last + 1]))
+    sys.path.insert(0, REF)
+    try:
+        cv2 = types.ModuleType("cv2")
+        cv2.INTER_NEAREST = 0
+        cv2.resize = lambda img, dsize, interpolation=0: nearest_resize(img, dsize)
+        sys.modules.setdefault("cv2", cv2)
+        from utils import image_io                      # the reference's own .raw codec
+
+        class _Quiet:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+        def check_frames(*a, **k):
+            return False                                # nothing cached: compute
+        ns = {
+            "np": np, "os": os, "pjoin": pjoin, "cv2": sys.modules["cv2"], "image_io": image_io, "logging": __import__("logging"),
+            "print_banner": lambda s: None, "SuppressedStdout": _Quiet, "check_frames": check_frames,
+            "visualization": types.SimpleNamespace(visualize_depth_dir=lambda *a, **k: None),
+            "video": types.SimpleNamespace(path=path), "out_dir": out_dir,
+            "args": types.SimpleNamespace(model_type=model_type, dense_frame_ratio=dense_frame_ratio, dense_pixel_ratio=dense_pixel_ratio),
+            "frame_range": types.SimpleNamespace(frames=lambda: list(frames)),
+            "converted_depth_fmt": pjoin(path, "depth_colmap_dense", "depth", "frame_{:06d}.raw"),
+            "converted_depth_dir": pjoin(path, "depth_colmap_dense", "depth"),
+            "src_meta_file": pjoin(out_dir, "metadata.npz"),
+        }
+        exec(compile(body, "scale_calibration.py[228-311]", "exec"), ns)
+    finally:
+        sys.path.remove(REF)
+    with np.load(pjoin(out_dir, "metadata_scaled.npz")) as z:
+        meta = {k: z[k] for k in z.files}
+    scaled = {}
+    from consistent_depth_amd.utils import image_io as my_io
+    for i in frames:
+        fn = pjoin(out_dir, "depth_scaled_by_colmap_dense", "depth", f"frame_{i:06d}.raw")
+        if os.path.isfile(fn):
+            scaled[i] = my_io.load_raw_float32_image(fn)
+    return {"scales_csv": np.loadtxt(pjoin(out_dir, "scales.csv"), delimiter=",").reshape(-1, 2), "meta": meta, "scaled": scaled}
+
+
+def make_case(seed=0, n_frames=6, H=48, W=40):
+    """Seeded inputs of the stage with every branch in them: a COLMAP map at half resolution (frame 2: nearest-neighbour resize), one
+    with too few finite pixels (frame 3: invalid), a frame without a COLMAP map (frame 5), a COLMAP value of 0 (frame 1: an infinite
+    ratio), even and odd numbers of valid pixels.  -> (inv_src {frame: (H,W)}, inv_cmp {frame: (h,w)}, intrinsics, extrinsics)."""
+    rng = np.random.default_rng(seed)
+    inv_src, inv_cmp = {}, {}
+    for i in range(n_frames):
+        a = rng.uniform(0.2, 2.0, (H, W)).astype(np.float32)
+        hh, ww = (H // 2, W // 2) if i == 2 else (H, W)
+        c = rng.uniform(0.3, 2.5, (hh, ww)).astype(np.float32)
+        c[rng.random((hh, ww)) < (0.9 if i == 3 else 0.2)] = np.nan
+        if i == 1:
+            c[0, :4] = 0.0
+        if i == 4 and np.isfinite(c).sum() % 2 == 0:      # frame 4: an odd count whatever the seed
+            c.flat[int(np.flatnonzero(np.isfinite(c.ravel()))[0])] = np.nan
+        inv_src[i] = a
+        if i != 5:
+            inv_cmp[i] = c
+    return inv_src, inv_cmp, rng.random((n_frames, 4)), rng.random((n_frames, 3, 4))
+
+
+def write_case(path, out_dir, inv_src, inv_cmp, intrinsics, extrinsics, model_type="mc"):
+    """The directory layout scale_calibration.py:228-311 reads."""
+    from consistent_depth_amd.utils import image_io
+    os.makedirs(pjoin(path, f"depth_{model_type}", "depth"), exist_ok=True)
+    os.makedirs(pjoin(path, "depth_colmap_dense", "depth"), exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
+    for i, a in inv_src.items():
+        image_io.save_raw_float32_image(pjoin(path, f"depth_{model_type}", "depth", f"frame_{i:06d}.raw"), a)
+    for i, c in inv_cmp.items():
+        image_io.save_raw_float32_image(pjoin(path, "depth_colmap_dense", "depth", f"frame_{i:06d}.raw"), c)
+    np.savez(pjoin(out_dir, "metadata.npz"), intrinsics=intrinsics, extrinsics=extrinsics)
