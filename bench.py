@@ -129,9 +129,13 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("CD_AMD_MC_BACKEND", "hip"), choices=["torch", "hip"],
                     help="convolutions: hip = hand-written gfx950 engine (BASELINE configs[2]); "
                          "torch = PyTorch-ROCm/MIOpen (configs[1], ~2 min of MIOpen start-up)")
-    ap.add_argument("--frames", type=int, default=244,
-                    help="frames of the synthetic clip, resident on every GPU (BASELINE configs[2]: 244 -> 715 pairs, the default at every "
-                         "--gpus; configs[3] is --frames 1000 -> 2979 pairs, 7.2 GB per GPU and ~2 min of synthetic-data generation per rank)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames of the synthetic clip, resident on every GPU.  0 = by --gpus: 244 (BASELINE configs[2]: 715 pairs) on one GPU, "
+                         "1000 (BASELINE configs[3]: 2979 pairs, 7.2 GB per GPU) with --gpus > 1")
+    ap.add_argument("--generator", choices=["auto", "host", "device"], default="auto",
+                    help="synthetic clip: numpy on the host (the clip every single-GPU line of rounds 1-4 ran on) or torch on the device "
+                         "(same recipe, same cameras and surface, its own noise / mask / colour stream; seconds instead of minutes for 1000 "
+                         "frames).  auto = host for <= 244 frames, device beyond")
     ap.add_argument("--max-pairs", type=int, default=0, help="keep only the first N pairs of the clip (quick runs)")
     ap.add_argument("--loss-batch", type=int, default=256,
                     help="pairs per launch of the roofline micro-benchmark (256 = one pair per CU, 0.88 GB: the launch every round has "
@@ -293,9 +297,15 @@ def main():
     step = GraphedFineTuneStep(eager_step, eager_steps=max(1, min(2, args.warmup - 1))) if args.graph else eager_step
     # the clip, resident in HBM on every rank (replicated like the reference's dataset on every DataLoader worker)
     from consistent_depth_amd.loaders.pair_store import PairStore
-    store = PairStore.synthetic(args.frames, H, W, seed=0, device=device, max_pairs=args.max_pairs or None)
+    if not args.frames:
+        args.frames = 244 if world == 1 else 1000
+    gen_dev = args.generator == "device" or (args.generator == "auto" and args.frames > 244)
+    t_gen = time.perf_counter()
+    store = (PairStore.synthetic_device if gen_dev else PairStore.synthetic)(args.frames, H, W, seed=0, device=device, max_pairs=args.max_pairs or None)
+    torch.cuda.synchronize()
     plans = EpochPlans(len(store), rank, world, B, device, seed=0)
-    log(f"pair store: {args.frames} frames, {len(store)} pairs, {store.nbytes / 1e9:.2f} GB resident")
+    log(f"pair store: {args.frames} frames, {len(store)} pairs, {store.nbytes / 1e9:.2f} GB resident, generated on the "
+        f"{'device' if gen_dev else 'host'} in {time.perf_counter() - t_gen:.1f}s")
     scene_scale = 1.0
     if args.model == "midas2":
         # The reference's scale-calibration stage (scale_calibration.py:305-313) rescales the camera translations so that the
@@ -341,6 +351,11 @@ def main():
         log(f"HIP graph capture not active ({getattr(step, 'capture_error', None) or 'needs >= 3 warm-up steps'}); eager steps")
     if not graphed:   # event records of the in-step loss profiler are not captured into graphs: eager only
         assert lib.cd_profile_begin(args.steps + 8) == 0
+    from consistent_depth_amd import parallel as _par
+    if world > 1:     # HIP events around every step's gradient all-reduce: the first real multi-GPU run diagnoses itself
+        _par.exchange_timer.start(args.steps)
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     step_losses.clear()
     last_loss = run(args.steps)
@@ -350,6 +365,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    exchange_ms = _par.exchange_timer.stop() if world > 1 else []
     # A non-finite loss makes the device-side guard skip the Adam update of that step (the reference skips NaN steps too,
     # depth_fine_tuning.py:372-376): such a step is not a full step, and a timed region containing one is not a measurement.
     # (graph replays return a clone of the static loss buffer: one tensor per step here too)
@@ -415,10 +431,17 @@ def main():
                                   "cores, fp32 accumulate (all convolutions but the RGB stem, fwd/dgrad/wgrad; as close to fp64 as the fp32 MFMA: profiles/mfma_split_exp_r02.txt, "
                                   "tests/test_conv_gpu.py); RGB stem and small-image 1x1 on the fp32 MFMA" if lib.cd_get_conv_arith() >= 1 else "fp32 MFMA (CD_AMD_CONV_ARITH=fp32)")
                    if args.backend == "hip" else "MIOpen fp32",
+                   "clip_generator": "device (torch, PairStore.synthetic_device)" if gen_dev else "host (numpy, PairStore.synthetic)",
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "hip_graph": graphed,
                    **({"dp_exchange": ("all-reduce + Adam inside the step graph (CD_AMD_DP_GRAPH_COLLECTIVE=1)" if getattr(step, "graph_collective", False)
-                                       else "one flat all-reduce of [gradients | loss] + one Adam launch per step, eager, after the graph replay")}
+                                       else "one flat all-reduce of [gradients | loss] + one Adam launch per step, eager, after the graph replay"),
+                       "dp_backend": dist.get_backend(), "dp_ranks": dist.get_world_size(),
+                       "dp_payload_mb": round(eager_step.opt.reduce_buffer.numel() * 4 / 1e6, 2),
+                       # rank 0's HIP events around the collective of every timed step (enqueue -> completion as the step sees it: it
+                       # includes waiting for the slowest rank to arrive); empty when the collective sits inside the step graph
+                       "dp_exchange_ms": ({"mean": round(float(np.mean(exchange_ms)), 4), "min": round(float(np.min(exchange_ms)), 4),
+                                           "max": round(float(np.max(exchange_ms)), 4), "steps": len(exchange_ms)} if exchange_ms else None)}
                       if world > 1 else {}),
                    "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 2),
                    "last_loss": float(last_loss.item()), "finite_loss_steps": finite_steps,

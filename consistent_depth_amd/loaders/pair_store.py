@@ -45,11 +45,13 @@ class PairStore:
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if dev.type == "cuda" and dev.index is None:      # "cuda" -> "cuda:<current>": tensors report an indexed device
             dev = torch.device("cuda", torch.cuda.current_device())
-        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)  # noqa: E731
+        # (arrays from the host, or tensors that already live on the device: synthetic_device)
+        f32 = lambda a: (a.to(dev, torch.float32).contiguous() if torch.is_tensor(a)  # noqa: E731
+                         else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev))
         self.device = dev
         self.color = f32(color)
         self.flows = f32(flows)
-        self.masks = (torch.as_tensor(np.ascontiguousarray(masks)) > 0).to(torch.uint8).to(dev).contiguous()
+        self.masks = ((masks.to(dev) if torch.is_tensor(masks) else torch.as_tensor(np.ascontiguousarray(masks))) > 0).to(torch.uint8).to(dev).contiguous()
         self.intrinsics = f32(intrinsics)
         self.extrinsics = f32(extrinsics)
         self.pair_frames = torch.as_tensor(np.asarray(pair_frames), dtype=torch.int64).to(dev)
@@ -88,6 +90,71 @@ class PairStore:
             self.masks[s:s + 256, 1] = (m1 > 0).to(torch.uint8)
         self._refresh_constants()
         return self
+
+    @classmethod
+    def synthetic_device(cls, n_frames: int, H: int, W: int, flow_ops=("hierarchical2",), seed: int = 0, device=None,
+                         max_pairs: int = None, noise_px: float = 0.5, mask_keep: float = 0.7, chunk: int = 128):
+        """The recipe of `synthetic` (consistent_depth_amd/synthetic.py: one static height-field surface, a smooth camera path, exact
+        reprojection flows + Gaussian noise, Bernoulli masks of the in-bounds pixels) evaluated ON THE DEVICE with torch in float64 --
+        BASELINE configs[3]'s 1000-frame clip (2979 pairs, 7.2 GB) in seconds instead of the host generator's ~2 minutes per rank.
+        Same cameras and surface as `synthetic(seed)` (they come from the same host RNG stream); colours, flow noise and masks come
+        from a torch generator seeded with `seed`, so they are NOT the host generator's numbers (a different, equally seeded clip:
+        every rank generates the same one).  Plumbing for benchmarks and tests -- synthetic data is not part of the product path."""
+        from .. import synthetic as syn
+        from ..utils import frame_range as fr, frame_sampling as fs
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        rng = np.random.default_rng(seed)
+        K = syn.clip_intrinsics(H, W)
+        extr = syn.camera_path(n_frames, rng, step=0.01, max_angle=0.15)
+        surf = syn.Surface(rng)
+        f64 = dict(dtype=torch.float64, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        y, x = torch.meshgrid(torch.arange(H, **f64), torch.arange(W, **f64), indexing="ij")
+        ray = torch.stack([(x - K[2]) / K[0], -(y - K[3]) / K[1], -torch.ones_like(x)], 0)           # (3,H,W)
+        E = torch.as_tensor(extr, **f64)                                                              # (N,3,4)
+        sk, sph, samp = torch.as_tensor(surf.k, **f64), torch.as_tensor(surf.phase, **f64), torch.as_tensor(surf.amp, **f64)
+
+        def depth_below(px, py):
+            d = torch.full_like(px, surf.mid)
+            for w in range(sk.shape[0]):
+                d = d + samp[w] * torch.sin(sk[w, 0] * px + sk[w, 1] * py + sph[w])
+            return d
+
+        gt = torch.empty(n_frames, H, W, **f64)
+        for s0 in range(0, n_frames, chunk):          # render_depth: fixed-point ray / height-field intersection, 12 iterations
+            R, t = E[s0:s0 + chunk, :, :3], E[s0:s0 + chunk, :, 3]
+            d = torch.einsum("nij,jhw->nihw", R, ray)
+            s = torch.full((R.shape[0], H, W), surf.mid, **f64)
+            for _ in range(12):
+                px, py = t[:, 0, None, None] + s * d[:, 0], t[:, 1, None, None] + s * d[:, 1]
+                s = (depth_below(px, py) + t[:, 2, None, None]) / (-d[:, 2])
+            gt[s0:s0 + chunk] = s
+        color = torch.rand(n_frames, 3, H, W, generator=gen, device=dev, dtype=torch.float32)
+        pairs = sorted(fs.SamplePairs.to_one_way(fs.sample_pairs(fr.FrameRange(fr.OptionalSet(), n_frames), flow_ops)))
+        if max_pairs:
+            pairs = pairs[:max_pairs]
+        P = len(pairs)
+        flows = torch.empty(P, 2, 2, H, W, dtype=torch.float32, device=dev)
+        masks = torch.empty(P, 2, 1, H, W, dtype=torch.uint8, device=dev)
+        pa = torch.as_tensor([p[0] for p in pairs], device=dev)
+        pb = torch.as_tensor([p[1] for p in pairs], device=dev)
+        for s0 in range(0, P, chunk):
+            for k, (ia, ib) in enumerate(((pa[s0:s0 + chunk], pb[s0:s0 + chunk]), (pb[s0:s0 + chunk], pa[s0:s0 + chunk]))):
+                Rr, tr, Rt, tt = E[ia, :, :3], E[ia, :, 3], E[ib, :, :3], E[ib, :, 3]
+                p3 = ray[None] * gt[ia][:, None]                                                  # (n,3,H,W) camera-space points
+                world = torch.einsum("nij,njhw->nihw", Rr, p3) + tr[:, :, None, None]
+                q = torch.einsum("nji,njhw->nihw", Rt, world - tt[:, :, None, None])
+                fx = K[0] * q[:, 0] / (-q[:, 2]) + K[2] - x
+                fy = -(K[1] * q[:, 1] / (-q[:, 2])) + K[3] - y
+                f = torch.stack([fx, fy], 1) + noise_px * torch.randn(fx.shape[0], 2, H, W, generator=gen, **f64)
+                inb = (x + f[:, 0] >= 0) & (x + f[:, 0] <= W - 1) & (y + f[:, 1] >= 0) & (y + f[:, 1] <= H - 1)
+                keep = torch.rand(fx.shape[0], H, W, generator=gen, device=dev) < mask_keep
+                flows[s0:s0 + chunk, k] = f.float()
+                masks[s0:s0 + chunk, k, 0] = (keep & inb).to(torch.uint8)
+        store = cls(color, flows, masks, np.tile(K, (n_frames, 1)), extr, [list(p) for p in pairs], device=dev)
+        store.gt_depth = gt.float().cpu().numpy()
+        return store
 
     def scale_scene_(self, factor: float):
         """Multiply the scene's metric scale by `factor`: camera translations (and the synthetic ground-truth depth, if any)

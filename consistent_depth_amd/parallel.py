@@ -62,10 +62,44 @@ def collective_active() -> bool:
     return dist.is_initialized()
 
 
+class ExchangeTimer:
+    """Optional HIP-event bracket around the step's gradient all-reduce (bench.py: `dp_exchange_ms`), so that the first run on a
+    multi-GPU node says by itself how long the collective takes per step.  Events are recorded on the current stream (the one the
+    collective is enqueued on: ProcessGroupNCCL orders its own stream after it and the current stream after its work) -- the
+    elapsed time is enqueue-to-completion of the exchange as the step sees it.  Off unless `start(n)` was called."""
+
+    def __init__(self):
+        self.events, self.pos = [], 0
+
+    def start(self, n):
+        self.events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        self.pos = 0
+
+    def stop(self):
+        """-> milliseconds of every bracket recorded since start() (call after a device synchronisation)."""
+        ms = [a.elapsed_time(b) for a, b in self.events[:self.pos]]
+        self.events, self.pos = [], 0
+        return ms
+
+    def bracket(self):
+        if self.pos < len(self.events):
+            self.pos += 1
+            return self.events[self.pos - 1]
+        return None
+
+
+exchange_timer = ExchangeTimer()
+
+
 def allreduce_sum_(buf: torch.Tensor):
     """In-place sum over ranks of one flat fp32 buffer (no-op without a process group; see collective_active)."""
     if collective_active():
+        ev = exchange_timer.bracket()
+        if ev is not None:
+            ev[0].record()
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if ev is not None:
+            ev[1].record()
     return buf
 
 
