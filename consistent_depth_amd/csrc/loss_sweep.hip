@@ -288,6 +288,20 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     v.Dj = D0 + (f ? ring : 0); v.Dk = D0 + (f ? 0 : ring);
     WgState& st = *reinterpret_cast<WgState*>(D0 + 2 * ring);
     if (threadIdx.x == 0) { st.ovf_n = 0u; st.redo = 0; st.is_last = 0; }
+    // ---- the accumulators are cleared and the depth rows of the first window requested BEFORE the pair's constants are computed
+    // (neither needs them): the loads' latency and the constants' latency chains (sample -> taps, ~10 us) overlap
+    constexpr int kInitBatches = 4;
+    v.cj = Cam{};
+    const Lane<PXT> l0 = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);      // (only its row / column fields are used here)
+    for (int i = threadIdx.x; i < 2 * ring; i += kThreads) smem[i] = 0u;
+    const int init_hi = init_stage_hi(g);
+    const bool init_batched = init_hi <= kInitBatches * kStagePasses * g.RP;
+    float sv0[kInitBatches][kStagePasses][PXT];
+#pragma unroll
+    for (int j = 0; j < kInitBatches; ++j) {
+        const int lo = j * kStagePasses * g.RP;
+        load_stage_nosel<PXT>(v, l0, lo < init_hi ? lo : 0, init_batched ? min(lo + kStagePasses * g.RP, init_hi) : 0, sv0[j]);
+    }
     // ---- the pair's constants
     pair_constants<MODE>(st, st.wave_part, pp, dpair, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW,
                          mf + (size_t)b * HW, mb + (size_t)b * HW, b, B, g.H, g.W);
@@ -318,13 +332,19 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     if (has_plan) {
     DevEnv env{&st, oidx, oval, seg_cap};
     const Lane<PXT> l = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);
-    for (int i = threadIdx.x; i < 2 * ring; i += kThreads) smem[i] = 0u;
-    const int init_hi = init_stage_hi(g);
-    for (int lo = 0; lo < init_hi; lo += kStagePasses * g.RP) {     // prologue: the initial window [0, R)
-        const int hi = min(lo + kStagePasses * g.RP, init_hi);
-        float sv[kStagePasses][PXT];
-        load_stage<PXT>(v, l, lo, hi, sv);
-        r.bad = !stage_rows<MODE, PXT>(v, l, lo, hi, sv) || r.bad;
+    if (init_batched) {                  // prologue: the initial window [0, R), from the rows requested at the top of the kernel
+#pragma unroll
+        for (int j = 0; j < kInitBatches; ++j) {
+            const int lo = j * kStagePasses * g.RP;
+            if (lo < init_hi) r.bad = !stage_rows<MODE, PXT>(v, l, lo, min(lo + kStagePasses * g.RP, init_hi), sv0[j]) || r.bad;
+        }
+    } else {
+        for (int lo = 0; lo < init_hi; lo += kStagePasses * g.RP) {
+            const int hi = min(lo + kStagePasses * g.RP, init_hi);
+            float sv[kStagePasses][PXT];
+            load_stage<PXT>(v, l, lo, hi, sv);
+            r.bad = !stage_rows<MODE, PXT>(v, l, lo, hi, sv) || r.bad;
+        }
     }
     // One barrier per item.  During item t three things run side by side, on disjoint ring rows by construction of the plan:
     //   rows [fl_lo, fl_hi) -- which no source of item t or later touches -- leave ring j (accumulator -> gradient row),
