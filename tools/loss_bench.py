@@ -70,6 +70,7 @@ def main():
         res.append({"variant": args.variant, "pxt": args.pxt, "pairs": B, "avg_ms": float(ms.mean()), "min_ms": float(ms.min()),
                     "GBps_avg": float(per_pair * B / (ms.mean() * 1e-3) / 1e9), "GBps_best": float(gbs.max()),
                     "frac_of_8TBps": float(per_pair * B / (ms.mean() * 1e-3) / 1e9 / 8000.0)})
+        res[-1]["ms_sorted"] = [round(float(x), 4) for x in np.sort(ms)]
         print(json.dumps(res[-1]), flush=True)
         del depth, x, flows, masks
         torch.cuda.empty_cache()
