@@ -265,8 +265,11 @@ class GraphedEvaluate:
         self.capture_error = None
 
     def __call__(self, store, pair_ids: torch.Tensor):
-        """-> (raw network output (B,2,H,W), {name: (B,)} per-pair losses, metadata of the batch)."""
-        key = (id(store), int(pair_ids.numel()), int(store.tile_windows.shape[1]))
+        """-> (raw network output (B,2,H,W), {name: (B,)} per-pair losses, metadata of the batch).  The three are the graph's STATIC
+        output buffers: consume them (copy, reduce, hand to the writer) before the next call overwrites them."""
+        # keyed by the store's resident colour buffer (an address that lives as long as the store's data), not by id(store): a
+        # collected store's id can be reused by a new one, whose geometry only coincidentally matches a stale graph
+        key = (int(store.color.data_ptr()), int(store.flows.data_ptr()), int(pair_ids.numel()), int(store.tile_windows.shape[1]))
         g = self._graphs.get(key)
         if g is None:
             n = self._seen.get(key, 0)

@@ -57,9 +57,9 @@ def _raw_write(fn, a):
 
 class CpuLoop:
     def __init__(self, dataset, state_dict, out_dir, batch_size=4, lr=4e-4, lambda_r=1.0, lambda_b=0.1,
-                 dtype=torch.float64, val_epoch_freq=1, save_epoch_freq=1):
+                 dtype=torch.float64, val_epoch_freq=1, save_epoch_freq=1, device="cpu"):
         self.ds, self.out_dir, self.bs, self.dtype = dataset, out_dir, batch_size, dtype
-        self.ft = cpu_step.CpuFineTuner(state_dict, lr=lr, lambda_r=lambda_r, lambda_b=lambda_b, dtype=dtype)
+        self.ft = cpu_step.CpuFineTuner(state_dict, lr=lr, lambda_r=lambda_r, lambda_b=lambda_b, dtype=dtype, device=device)
         self.val_epoch_freq, self.save_epoch_freq = val_epoch_freq, save_epoch_freq
         self.total_iters = 0
         self.step_losses = []       # (epoch, pairs, loss) per training step, NaN steps included
@@ -74,10 +74,10 @@ class CpuLoop:
         loss_dict, saved = {"reprojection": {}, "disparity": {}}, set()
         for s0 in range(0, len(self.ds), self.bs):
             images, b = _collate([self.ds[i] for i in range(s0, min(s0 + self.bs, len(self.ds)))])
-            x = torch.as_tensor(images, dtype=self.dtype).reshape((-1,) + images.shape[-3:])
+            x = torch.as_tensor(images, dtype=self.dtype).reshape((-1,) + images.shape[-3:]).to(self.ft.device)
             with torch.no_grad():      # train-mode BN, running statistics updated (see module docstring)
                 pred, _ = hourglass_ref.forward(self.ft.state, x, training=True, update_running_stats=True)
-            depth = torch.exp(pred).reshape(images.shape[0], 2, *pred.shape[-2:]).numpy()
+            depth = torch.exp(pred).reshape(images.shape[0], 2, *pred.shape[-2:]).cpu().numpy()
             out = oracle.consistency_loss(depth, b["flows"], b["masks"], b["intrinsics"], b["extrinsics"],
                                           self.ft.lambda_r, self.ft.lambda_b, dtype=np_dtype, want_grad=False)
             for n, pair in enumerate(b["indices"]):
@@ -113,7 +113,7 @@ class CpuLoop:
             if (epoch + 1) % self.val_epoch_freq == 0:
                 self.validate(epoch + 1, self.total_iters)
             if (epoch + 1) % self.save_epoch_freq == 0:
-                torch.save({k: v.detach().clone() for k, v in self.ft.state.items()},
+                torch.save({k: v.detach().cpu().clone() for k, v in self.ft.state.items()},
                            pjoin(self.out_dir, "checkpoints", f"{epoch + 1:04d}.pth"))
         if (start_epoch + num_epochs) % self.val_epoch_freq != 0:
             self.validate(start_epoch + num_epochs, self.total_iters)
@@ -122,7 +122,7 @@ class CpuLoop:
     def save_depth(self, out_dir, frames, load_color):
         os.makedirs(pjoin(out_dir, "depth"), exist_ok=True)
         for f in frames:
-            x = torch.as_tensor(np.asarray(load_color(f)), dtype=self.dtype)[None]
+            x = torch.as_tensor(np.asarray(load_color(f)), dtype=self.dtype)[None].to(self.ft.device)
             with torch.no_grad():
                 pred, _ = hourglass_ref.forward(self.ft.state, x, training=False)
-            _raw_write(pjoin(out_dir, "depth", "frame_{:06d}.raw".format(f)), 1.0 / torch.exp(pred)[0, 0].numpy())
+            _raw_write(pjoin(out_dir, "depth", "frame_{:06d}.raw".format(f)), 1.0 / torch.exp(pred)[0, 0].cpu().numpy())

@@ -15,9 +15,13 @@ from . import hourglass_ref, oracle
 
 
 class CpuFineTuner:
-    def __init__(self, state_dict, lr=4e-4, lambda_r=1.0, lambda_b=0.1, dtype=torch.float32):
-        self.dtype = dtype
-        self.state = {k: v.detach().clone().to("cpu", dtype if v.is_floating_point() else v.dtype)
+    def __init__(self, state_dict, lr=4e-4, lambda_r=1.0, lambda_b=0.1, dtype=torch.float32, device="cpu"):
+        """`device`: where torch evaluates the hourglass and Adam (the loss stays the plain-C oracle on the host).  "cpu" is the
+        reference path; "cuda" runs the SAME torch program (ATen's own fp64 kernels, nothing of consistent_depth_amd) on the GPU
+        -- used only to produce long fp64 ground-truth runs in minutes instead of hours (oracle/gen_golden_loop_384.py, where it is
+        cross-checked against the CPU run epoch by epoch)."""
+        self.dtype, self.device = dtype, torch.device(device)
+        self.state = {k: v.detach().clone().to(self.device, dtype if v.is_floating_point() else v.dtype)
                       for k, v in state_dict.items()}
         self.param_keys = [k for k in self.state if k.endswith(".weight") or k.endswith(".bias")]
         for k in self.param_keys:
@@ -34,22 +38,22 @@ class CpuFineTuner:
             v = exp_avg_sq.get(k)
             self.opt.state[p] = {
                 "step": torch.tensor(float(step)),
-                "exp_avg": (torch.zeros_like(p) if m is None else m.detach().to("cpu", self.dtype).reshape(p.shape).clone()),
-                "exp_avg_sq": (torch.zeros_like(p) if v is None else v.detach().to("cpu", self.dtype).reshape(p.shape).clone()),
+                "exp_avg": (torch.zeros_like(p) if m is None else m.detach().to(self.device, self.dtype).reshape(p.shape).clone()),
+                "exp_avg_sq": (torch.zeros_like(p) if v is None else v.detach().to(self.device, self.dtype).reshape(p.shape).clone()),
             }
 
     def step(self, images, batch):
         """images (B,2,3,H,W) numpy/tensor; batch: dict with flows/masks/intrinsics/extrinsics (numpy)."""
         np_dtype = np.float64 if self.dtype == torch.float64 else np.float32
-        x = torch.as_tensor(images, dtype=self.dtype).reshape((-1,) + tuple(images.shape[-3:]))
+        x = torch.as_tensor(images, dtype=self.dtype).reshape((-1,) + tuple(images.shape[-3:])).to(self.device)
         pred, _ = hourglass_ref.forward(self.state, x, training=True, update_running_stats=True)
         B = images.shape[0]
         depth = torch.exp(pred).reshape(B, 2, *pred.shape[-2:])
-        out = oracle.consistency_loss(depth.detach().numpy(), batch["flows"], batch["masks"], batch["intrinsics"],
+        out = oracle.consistency_loss(depth.detach().cpu().numpy(), batch["flows"], batch["masks"], batch["intrinsics"],
                                       batch["extrinsics"], self.lambda_r, self.lambda_b, dtype=np_dtype)
         self.opt.zero_grad()
         if not np.isnan(out["total"][0]):
-            depth.backward(torch.as_tensor(out["grad_depth"]))
+            depth.backward(torch.as_tensor(out["grad_depth"]).to(self.device))
             self.opt.step()
         return out, depth.detach()
 
@@ -68,7 +72,7 @@ def time_steps(state_dict, images, batch, n_steps=5, warmup=1, threads=None, los
         t0 = time.perf_counter()
         _, depth = ft.step(images, batch)
         full.append(time.perf_counter() - t0)
-    d = depth.numpy()
+    d = depth.cpu().numpy()
     loss = []
     for i in range(loss_steps + 1):
         t0 = time.perf_counter()

@@ -196,15 +196,17 @@ def stage_snapshot(spec, dst):
         print(f"[{spec}] product epoch {e} mean", prod[f"val_e{e}_mean"].tolist())
 
 
-def _cpu_run(spec, src, dtype):
+def _cpu_run(spec, src, dtype, device="cpu"):
     """oracle/cpu_loop.py continued from the snapshot in `src` for T epochs in `dtype`; returns (artefacts, snapshot checksums, extras).
-    The run lives in <src>/cpu_<spec>_<dtype>; if that directory already holds a run (finished or interrupted) it is COLLECTED, not redone."""
+    The run lives in <src>/cpu_<spec>_<dtype>; if that directory already holds a run (finished or interrupted) it is COLLECTED, not redone.
+    device = "cuda": the SAME torch program evaluated by ATen on the GPU (its own fp64 kernels; the loss stays the C oracle on the host) --
+    a 200-step fp64 continuation takes minutes there and ~7 hours on the build container's 8 cores; see stage_golden_gpu."""
     import make_synthetic_dataset as msd
     from consistent_depth_amd.loaders.video_dataset import VideoDataset, load_color
     from oracle import conv64, cpu_loop
     S = SPECS[spec]
     K, T, CLIP = S["K"], S["T"], S["clip"]
-    conv64.ENABLED = True        # the dgemm formulation of the fp64 convolution: 5x faster on the build container's 8 cores
+    conv64.ENABLED = device == "cpu"     # the dgemm formulation of the fp64 convolution: 5x faster on the build container's 8 cores
     z = np.load(os.path.join(src, f"snap_{spec}.npz"))
     tables = json.loads(str(z["tables"]))
     snap = {part: _unpack(z[part], tables[part]) for part in ("state", "m1", "m2")}
@@ -215,7 +217,7 @@ def _cpu_run(spec, src, dtype):
     cs = checksums(snap)
     for name, v in cs.items():
         assert np.array_equal(v, z["checksum_" + name]), name
-    work = os.path.join(src, f"cpu_{spec}_{'f64' if dtype == torch.float64 else 'f32'}")
+    work = os.path.join(src, f"cpu_{spec}_{'f64' if dtype == torch.float64 else 'f32'}" + ("" if device == "cpu" else "_gpu"))
     path = os.path.join(work, "clip")
     out = os.path.join(work, "cpu")
     fresh = not os.path.exists(out)
@@ -227,7 +229,7 @@ def _cpu_run(spec, src, dtype):
     if fresh:
         ds_idx = {tuple(int(v) for v in pr): i for i, pr in enumerate(ds.flow_indices)}
         plans = {e: [[ds_idx[tuple(pr)] for pr in batch] for batch in p] for e, p in plans.items()}
-        lp = cpu_loop.CpuLoop(ds, snap["state"], out, dtype=dtype)
+        lp = cpu_loop.CpuLoop(ds, snap["state"], out, dtype=dtype, device=device)
         lp.ft.set_adam_state(snap["m1"], snap["m2"], snap["k"])
         lp.total_iters = K * len(ds)
         lp.fine_tune(T, lambda e: plans[K + e], start_epoch=K)
@@ -285,6 +287,39 @@ def stage_golden(spec, src):
             print(f"[{spec}] product (snapshot run) vs fp64, epoch {e}: " + "  ".join(f"{k} {v:.3e}" for k, v in row.items()))
 
 
+def stage_golden_gpu(spec, src):
+    """The fp64 ground truth computed by the oracle's torch program ON THE GPU (ATen's fp64 kernels -- im2col + dgemm convolutions --
+    not a line of consistent_depth_amd; the loss is still the plain-C oracle on the host).  fp64 arithmetic differs between devices
+    only in summation order (1e-13 per operation); `crosscheck` measures it against whatever the CPU run has finished and stores the
+    distances in the golden.  (Why: 200 fp64 steps at 384x224 are ~7 hours on the build container's 8 cores.)"""
+    res, cs, extras = _cpu_run(spec, src, torch.float64, device="cuda")
+    res.update(extras)
+    res["truth_device"] = np.array("cuda: oracle/cpu_loop.py's torch program on ATen fp64 kernels, C-oracle loss on the host")
+    for name, v in cs.items():
+        res["checksum_" + name] = v
+    out = golden_path(spec)
+    np.savez_compressed(out, **res)
+    print("wrote", out, os.path.getsize(out) / 1e6, "MB; epochs", res["epochs"].tolist())
+
+
+def stage_crosscheck(spec, src):
+    """Distances of the golden (GPU fp64) to the CPU fp64 run of the same continuation, for every epoch the CPU run has completed
+    (build container; the CPU run may be interrupted).  Stored in the golden as cpu64_crosscheck_{epochs, mean, perpair, evaldepth, ckpt}."""
+    S = SPECS[spec]
+    out = golden_path(spec)
+    z = dict(np.load(out))
+    work = os.path.join(src, f"cpu_{spec}_f64", "cpu")
+    cpu = collect(work, len(z["pair_order"]), S["K"], S["T"])
+    epochs = [int(e) for e in cpu["epochs"] if int(e) in set(z["epochs"].tolist())]
+    rows = distances(cpu, z, epochs)
+    for e, row in rows.items():
+        print(f"[{spec}] CPU fp64 vs golden (GPU fp64), epoch {e}: " + "  ".join(f"{k} {v:.3e}" for k, v in row.items()))
+    z["cpu64_crosscheck_epochs"] = np.array(epochs, np.int64)
+    for name in ("mean", "perpair", "evaldepth", "ckpt"):
+        z["cpu64_crosscheck_" + name] = np.array([rows[e][name] for e in epochs], np.float64)
+    np.savez_compressed(out, **z)
+
+
 def stage_ref32(spec, src):
     """The YARDSTICK: the same continuation in the reference's own arithmetic (fp32 on the CPU) -- how far the reference is from its
     fp64 self on every artefact.  Stored next to the fp64 golden as `ref32dist_<artefact>` (distances only: the fp32 artefacts
@@ -310,4 +345,5 @@ def stage_run32(spec, src):
 
 
 if __name__ == "__main__":
-    {"snapshot": stage_snapshot, "golden": stage_golden, "ref32": stage_ref32, "run32": stage_run32}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {"snapshot": stage_snapshot, "golden": stage_golden, "golden_gpu": stage_golden_gpu, "crosscheck": stage_crosscheck, "ref32": stage_ref32,
+     "run32": stage_run32}[sys.argv[1]](sys.argv[2], sys.argv[3])

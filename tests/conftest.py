@@ -115,13 +115,42 @@ def pytest_sessionstart(session):
     _T0[0] = time.monotonic()
 
 
+BUDGET_SKIPPED = []     # nodeids of the heavy tests skipped for the time budget in this session (also appended to by tests that stop mid-way)
+
+
 def pytest_runtest_setup(item):
     if _T0[0] is None or not _heavy_cost(item.nodeid):
         return
     budget = float(os.environ.get("CD_AMD_TEST_BUDGET_S", "1050"))
     why = budget_verdict(item.nodeid, _process_age(), budget)
     if why:
-        pytest.skip(why)
+        BUDGET_SKIPPED.append(item.nodeid)
+        pytest.skip("BUDGET-SKIP " + why)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """A green suite must say whether its heaviest parity tests ran: one line with a COUNT (0 in a normal run), the names, and -- with
+    CD_AMD_TEST_STRICT_BUDGET=1 -- a failing exit status when the count is not 0.  The same line goes to gpurun_out/budget_skips.txt
+    when that directory exists (the GPU box), so that it is merged back with the run's artefacts."""
+    heavy = [k for k in _HEAVY]
+    line = (f"BUDGET-SKIPPED heavy live-reference tests: {len(BUDGET_SKIPPED)} of {len(heavy)}"
+            + (f" ({', '.join(n.split('::')[-1] for n in BUDGET_SKIPPED)})" if BUDGET_SKIPPED else ""))
+    terminalreporter.write_line(line)
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        try:
+            with open(os.path.join(out, "budget_skips.txt"), "w") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+    if BUDGET_SKIPPED and os.environ.get("CD_AMD_TEST_STRICT_BUDGET") == "1":
+        terminalreporter.write_line("CD_AMD_TEST_STRICT_BUDGET=1: treating budget skips as a failure")
+        config._cd_budget_failure = True
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if getattr(session.config, "_cd_budget_failure", False) and session.exitstatus == 0:
+        session.exitstatus = 1
 
 
 _BG = {}

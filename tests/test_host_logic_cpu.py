@@ -321,3 +321,49 @@ def test_gpu_suite_runs_the_live_cpu_references_last_and_within_the_budget(monke
     assert conftest.budget_left() == float("inf")
     monkeypatch.setenv("CD_AMD_TEST_BUDGET_S", "100000")
     assert 0 < conftest.budget_left() < 100000                                    # counts from the start of the interpreter
+
+
+def test_mc_checkpoint_layout_compatibility(tmp_path):
+    """`checkpoints/mc.pth` as the reference's adapter consumes it (/root/reference/monodepth/mannequin_challenge_model.py:34-41: the file is
+    handed to Pix2PixModel.load_network as-is; :71-73 saves netG.state_dict()): the key list and shapes of this repo's parameter container,
+    of the oracle's independent restatement (oracle/hourglass_ref.py: the keys oracle/ref_loop.py serves to the reference adapter as the
+    "downloaded" checkpoint) and of a round trip through both prefix conventions -- upstream wraps netG in nn.DataParallel, so real files
+    carry `module.` on every key; files written by `save` of a single-device model do not.  (The upstream file itself is not available
+    offline: what is pinned here is that every layout the adapter can meet loads, and that anything else is refused, not half-loaded.)"""
+    import torch
+    from consistent_depth_amd.monodepth.hourglass import HourglassModel, load_state_dict_any_prefix
+    from oracle import hourglass_ref
+    torch.manual_seed(3)
+    net = HourglassModel(3)
+    sd = net.state_dict()
+    # ---- the container's layout = the architecture of SURVEY.md A.3: 157 convolutions, 155 BatchNorms, 5 357 730 parameters
+    convs = [k for k in sd if k.endswith(".weight") and sd[k].dim() == 4]
+    assert len(convs) == 157 and sum(p.numel() for p in net.parameters()) == 5357730
+    assert sum(1 for k in sd if k.endswith("running_mean")) == 155 and sum(1 for k in sd if k.endswith("num_batches_tracked")) == 155
+    assert {"seq.0.weight", "seq.0.bias", "seq.1.weight", "seq.1.bias", "seq.1.running_mean", "pred_layer.weight", "pred_layer.bias",
+            "uncertainty_layer.0.weight", "uncertainty_layer.0.bias"} <= set(sd)
+    assert tuple(sd["seq.0.weight"].shape) == (128, 3, 7, 7) and tuple(sd["pred_layer.weight"].shape) == (1, 64, 3, 3)
+    # ---- every key the oracle's functional restatement reads exists with the shape it needs: a forward through it is the check
+    x = torch.rand(1, 3, 32, 32, dtype=torch.float64)
+    pred, _ = hourglass_ref.forward({k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, x, training=False)
+    assert tuple(pred.shape) == (1, 1, 32, 32) and torch.isfinite(pred).all()
+    # ---- both prefix conventions load, bit for bit
+    for prefix in ("", "module."):
+        fn = str(tmp_path / f"mc_{len(prefix)}.pth")
+        torch.save({prefix + k: v for k, v in sd.items()}, fn)
+        other = HourglassModel(3)
+        load_state_dict_any_prefix(other, torch.load(fn, map_location="cpu"))
+        for k, v in other.state_dict().items():
+            assert torch.equal(v, sd[k]), (prefix, k)
+    # ---- anything else is refused: a missing key, an unexpected key, a wrong shape
+    bad = dict(sd); bad.pop("pred_layer.bias")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        load_state_dict_any_prefix(HourglassModel(3), bad)
+    bad = dict(sd); bad["seq.9.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        load_state_dict_any_prefix(HourglassModel(3), bad)
+    bad = dict(sd); bad["seq.0.weight"] = torch.zeros(128, 3, 5, 5)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        load_state_dict_any_prefix(HourglassModel(3), bad)
+    # ---- and the adapter's own save() writes the un-prefixed layout the reference's adapter writes (:71-73)
+    assert list(torch.load(str(tmp_path / "mc_0.pth"), map_location="cpu")) == list(sd)

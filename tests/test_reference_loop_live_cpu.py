@@ -105,7 +105,11 @@ def test_committed_golden_is_what_the_reference_produces(ref_run):
     for k, v in live.items():
         g = z["ref64_" + k]
         if v.dtype.kind in "fc":
-            np.testing.assert_allclose(g, v, rtol=1e-9, atol=1e-12, err_msg=k)
+            # depth maps are float32 FILES (.raw): the fp64 run's last bits depend on the OpenMP team size (summation order), and a
+            # value next to a rounding boundary then lands on the neighbouring float32 -- one ulp (6e-8 relative), seen on 27 of 18432
+            # pixels when the suite ran on 2 cores instead of 8
+            rtol = 2e-7 if (k == "depth" or k.startswith("evaldepth")) else 1e-9
+            np.testing.assert_allclose(g, v, rtol=rtol, atol=1e-12, err_msg=k)
         else:
             assert (g == v).all(), k
 
