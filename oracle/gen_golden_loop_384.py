@@ -106,12 +106,21 @@ def run_product(spec, work_dir, extra_args=()):
 
 
 def checksums(snap):
-    """Order-independent fingerprints of a snapshot (fp64 sums of the fp32 values: exact enough to expose a single flipped bit)."""
+    """EXACT, order-independent fingerprints of a snapshot: integer sums over the float32 BIT PATTERNS of every tensor (sum, sum of
+    squares of the low 16 bits, xor-fold) -- the same numbers on any host, with any thread count.  (Rounds 4's fingerprints were fp64
+    sums of the values: their last bits depend on the summation order, i.e. on the host's core count -- the same snapshot file failed
+    its own check under a 2-core affinity mask.)"""
     out = {}
     for part in ("state", "m1", "m2"):
-        vals = [v.double() for v in snap[part].values() if v.is_floating_point()]
-        out[part] = np.array([sum(float(v.sum()) for v in vals), sum(float(v.abs().sum()) for v in vals),
-                              sum(float((v * v).sum()) for v in vals)], np.float64)
+        s1 = s2 = x = 0
+        for v in snap[part].values():
+            if not v.is_floating_point():
+                continue
+            bits = v.detach().cpu().contiguous().float().view(torch.int32).to(torch.int64).reshape(-1)
+            s1 += int(bits.sum())
+            s2 += int(((bits & 0xffff) * (bits & 0xffff)).sum())
+            x ^= int(bits.sum() * 2654435761 % (1 << 61)) ^ int(bits.numel())
+        out[part] = np.array([s1, s2, x], np.int64)
     return out
 
 
@@ -216,7 +225,8 @@ def _cpu_run(spec, src, dtype, device="cpu"):
     plans = {int(e): p for e, p in json.loads(str(z["plans"])).items()}
     cs = checksums(snap)
     for name, v in cs.items():
-        assert np.array_equal(v, z["checksum_" + name]), name
+        if z["checksum_" + name].dtype == np.int64:          # (snapshots written before the exact fingerprints carry fp64 sums: not compared)
+            assert np.array_equal(v, z["checksum_" + name]), name
     work = os.path.join(src, f"cpu_{spec}_{'f64' if dtype == torch.float64 else 'f32'}" + ("" if device == "cpu" else "_gpu"))
     path = os.path.join(work, "clip")
     out = os.path.join(work, "cpu")

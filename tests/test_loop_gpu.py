@@ -252,7 +252,7 @@ def test_full_length_run_within_1e_3(tmp_path, spec):
     assert snap["k"] == int(z["k_steps"])
     cs = G.checksums(snap)
     same_state = all(np.array_equal(cs[n], z["checksum_" + n]) for n in cs)
-    drift = max(float(np.abs(cs[n] - z["checksum_" + n]).max() / np.abs(z["checksum_" + n]).max()) for n in cs)
+    drift = 0 if same_state else 1          # (exact integer fingerprints: equal or not)
     got = G.collect(ft.out_dir, n_pairs, S["K"], S["T"])
     for e in epochs:
         assert (got[f"val_e{e}_pairs"] == z[f"val_e{e}_pairs"]).all()
