@@ -541,7 +541,7 @@ def main():
                     out["cpu_baseline"] = {"value": round(B / sec, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                            "loss_only": {"value": round(B / loss_sec, 3), "unit": "frame-pairs/s", "ms_per_call": round(loss_sec * 1e3, 2),
                                                          "sample": f"10 evaluations (+1 warm-up) of loss + d loss / d depth on the same BS{B} batch, C oracle "
-                                                                   "(oracle/cd_oracle.c, fp32, one thread per pair-direction), median"},
+                                                                   "(oracle/cd_oracle.c, fp32, single-threaded), median"},
                                            "sample": f"{args.cpu_steps} full steps (+1 warm-up), MEDIAN per-step time extrapolated to pairs/s, on the first "
                                                      f"BS{B} batch of the same clip: torch CPU fp32 hourglass fwd+bwd (train-mode BN) + "
                                                      f"C-oracle loss + torch Adam, {sec:.2f} s/step (min {smin:.2f}, max {smax:.2f}), {cores} threads = the "
