@@ -176,24 +176,22 @@ class DepthFineTuner:
             # the epoch to learn which steps the device-side NaN guard skipped
             epoch_losses = torch.zeros(max(1, len(plan)), dtype=torch.float32, device=store.device)
             sizes = self._global_step_sizes(epoch, len(plan))
-            # The reference advances total_iters BEFORE it logs a step (:285-288), so every training point has its own global
-            # step.  The authoritative counter is corrected for NaN steps once per epoch (below, no per-step sync); the logging
-            # position runs along on the host and leaves out the NaN steps it gets to see (the print steps, whose loss is read).
-            log_iters = total_iters
+            # The reference advances total_iters BEFORE it logs a step (:285-288), and its `continue` on a NaN loss skips that advance
+            # (:278-280): a training point's global step = the pairs of all non-NaN steps up to and including it.  Which steps were NaN
+            # is known on the host only for the print steps (whose loss is read) -- the others are read ONCE at the end of the epoch --
+            # so the scalars of the print steps are buffered and written after the epoch's NaN mask is known, at their exact positions.
+            pending = []        # (step index, loss value, loss_meta) of the print steps
             for it, ids in enumerate(plan):
                 loss, loss_meta, metadata = step.step_from_store(store, plan_dev[it])
                 epoch_losses[it:it + 1].copy_(loss.reshape(1))
-                log_iters += sizes[it]
                 if p.print_freq > 0 and (it % max(1, p.print_freq) == 0) and self.rank == 0:
                     pairs = metadata["geometry_consistency"]["indices"].tolist()
                     lv = loss.item()  # the only host sync, every print_freq steps
                     print(f"Epoch = {epoch}, pairs = {pairs}, loss = {lv}")
                     if lv != lv:
                         print("Loss is NaN. Skipping.")  # already skipped on the device
-                        log_iters -= sizes[it]           # the reference's `continue` comes before its `total_iters +=`
                     elif writer is not None:
-                        writer.add_scalar("Train/loss", lv, log_iters)
-                        log_loss_stats(writer, "Train/loss", loss_meta, log_iters)
+                        pending.append((it, lv, {k: v.detach().clone() for k, v in loss_meta.items()}))
             torch.cuda.synchronize()
             # the reference's `continue` on a NaN loss also skips `total_iters += batch` (:278-285); total_iters counts pairs
             # over all ranks and names the validation files.  (With world > 1 the guard acts on the all-reduced loss: a NaN on
@@ -202,6 +200,15 @@ class DepthFineTuner:
             if self.world > 1 and len(plan):
                 parallel.allreduce_sum_(bad)
             bad = bad.cpu().numpy() > 0
+            if pending:         # exact global steps of the buffered training points
+                pos, at = total_iters, {}
+                for i, (n, b) in enumerate(zip(sizes, bad)):
+                    if not b:
+                        pos += n
+                    at[i] = pos
+                for it, lv, meta in pending:
+                    writer.add_scalar("Train/loss", lv, at[it])
+                    log_loss_stats(writer, "Train/loss", meta, at[it])
             total_iters += int(sum(n for n, b in zip(sizes, bad) if not b))
             self.epoch_losses = epoch_losses[:len(plan)].cpu().numpy()
             if self.rank == 0:

@@ -236,6 +236,39 @@ def test_training_scalars_are_logged_at_the_running_pair_count(tmp_path):
     assert got == want, (got, want)
 
 
+def test_training_scalars_skip_nan_steps_between_prints(tmp_path):
+    """A NaN loss skips the step AND the `total_iters` advance in the reference (depth_fine_tuning.py:278-285): the training points after it
+    keep their exact positions also when the NaN step was not a print step (its loss is only read at the end of the epoch) -- the scalars
+    of an epoch are written once its NaN mask is known (round 4 corrected the running position on print steps only)."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_dataset as msd
+    from consistent_depth_amd.depth_fine_tuning import DepthFineTuner
+    from consistent_depth_amd.loaders.pair_store import PairStore
+    from consistent_depth_amd.params import Video3dParamsParser
+    path = str(tmp_path / "clip")
+    range_dir, pairs = msd.write_dataset(path, n_frames=8, H=64, W=48, seed=3)
+    params = Video3dParamsParser().parse(["--path", path, "--num_epochs", "2", "--batch_size", "2", "--print_freq", "2"])
+    store = PairStore.from_directory(path, os.path.join(range_dir, "metadata_scaled.npz"))
+    poisoned = 5
+    store.flows[poisoned, 0, 0, 3, 3] = float("nan")          # every batch holding this pair has a NaN loss
+    ft = DepthFineTuner(range_dir, list(range(8)), params, store=store)
+    log = _ScalarLog()
+    ft.fine_tune(writer=log)
+    got = [n for tag, n in log.points if tag == "Train/loss"]
+    want, pos = [], 0
+    for epoch in range(2):
+        for it, ids in enumerate(ft.epoch_plan(epoch)):
+            bad = poisoned in ids
+            if not bad:
+                pos += len(ids)
+            if it % 2 == 0 and not bad:
+                want.append(pos)
+    assert got == want and len(got) > 4, (got, want)
+    # the validation files carry the same counter
+    assert os.path.exists(os.path.join(ft.out_dir, "eval", f"loss_e0002_iter{pos:06d}.json"))
+
+
 def test_parameter_only_objective_validates_without_per_pair_entries(tmp_path):
     """lambda_reprojection = lambda_view_baseline = 0, lambda_parameter > 0: JointLoss has no ConsistencyLoss term
     (joint_loss.py:20-24), so the validation sweep has no per-pair entries to index (round 3 raised KeyError)."""
