@@ -67,7 +67,7 @@ def reference_stage(path, out_dir, frames, model_type="mc", dense_frame_ratio=0.
         cv2 = types.ModuleType("cv2")
         cv2.INTER_NEAREST = 0
         cv2.resize = lambda img, dsize, interpolation=0: nearest_resize(img, dsize)
-        sys.modules.setdefault("cv2", cv2)
+        sys.modules.setdefault("cv2", cv2)              # (utils.image_io imports cv2 at module scope; another test's stub may already be there)
         from utils import image_io                      # the reference's own .raw codec
 
         class _Quiet:
@@ -80,7 +80,7 @@ def reference_stage(path, out_dir, frames, model_type="mc", dense_frame_ratio=0.
         def check_frames(*a, **k):
             return False                                # nothing cached: compute
         ns = {
-            "np": np, "os": os, "pjoin": pjoin, "cv2": sys.modules["cv2"], "image_io": image_io, "logging": __import__("logging"),
+            "np": np, "os": os, "pjoin": pjoin, "cv2": cv2, "image_io": image_io, "logging": __import__("logging"),
             "print_banner": lambda s: None, "SuppressedStdout": _Quiet, "check_frames": check_frames,
             "visualization": types.SimpleNamespace(visualize_depth_dir=lambda *a, **k: None),
             "video": types.SimpleNamespace(path=path), "out_dir": out_dir,
