@@ -438,6 +438,9 @@ template <int PXT> CD_HD void load_stage(const View& v, const Lane<PXT>& l, int 
 template <int PXT> CD_HD void load_stage_nosel(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, float (*sv)[PXT]) {
 #pragma unroll
     for (int s = 0; s < kStagePasses; ++s) {
+        // an ordinary item moves its window by RP rows: the passes beyond the first are skipped by a WAVE-UNIFORM branch (the rows of
+        // the tail / slide-only items need them); stage_rows never reads the registers of a pass without rows
+        if (s > 0 && s_hi - s_lo <= s * v.RP) continue;
         const int row = s_lo + s * v.RP + l.rr;
         const bool ok = row < s_hi && row < v.H;
         const unsigned off = ok ? ((unsigned)(s_lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2 : 0u;
