@@ -215,7 +215,7 @@ def loss_microbench(lib, B, H, W, iters, device):
     depth.requires_grad_(True)
     call = lambda: CL.consistency_loss(depth, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=CL.DEPTH_EXP,  # noqa: E731
                                        tile_windows=twin)
-    for _ in range(2):
+    for _ in range(5):      # untimed warm-up calls (plans, workspace, clocks)
         call()
     torch.cuda.synchronize()
     assert lib.cd_profile_begin(iters) == 0
@@ -497,7 +497,9 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "traffic_source": traffic_note,
                                "traffic_over_algorithmic": round(traffic / alg, 4) if traffic else None,
-                               "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5), "algorithmic_bytes_per_launch": alg,
+                               "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5), "median_ms": round(float(np.median(ms)), 5),
+                               "min_ms": round(float(np.min(ms)), 5), "max_ms": round(float(np.max(ms)), 5), "calls": int(len(ms)),
+                               "algorithmic_bytes_per_launch": alg,
                                "lib": lib.cd_build_info().decode()}
             if sweep:
                 # The row sweep gives every CU ONE pair at a time; at 256 pairs = 256 CUs the launch lasts as long as its slowest pair
