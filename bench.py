@@ -140,7 +140,7 @@ def parse():
     ap.add_argument("--loss-batch", type=int, default=256,
                     help="pairs per launch of the roofline micro-benchmark (256 = one pair per CU, 0.88 GB: the launch every round has "
                          "quoted; a second, 4x larger launch is reported next to it as roofline.sustained)")
-    ap.add_argument("--loss-iters", type=int, default=20)
+    ap.add_argument("--loss-iters", type=int, default=40)
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CD_AMD_STEP_GRAPH", "1")),
                     help="1: replay the step from a HIP graph after the eager warm-up steps (GraphedFineTuneStep); 0: eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -199,7 +199,10 @@ def profile_collect(lib, cap):
     return np.array(ms[:n.value]), np.array(bs[:n.value])
 
 
-def loss_microbench(lib, B, H, W, iters, device):
+LOSS_WARM_CALLS = 100
+
+
+def loss_microbench(lib, B, H, W, iters, device, warm=LOSS_WARM_CALLS):
     """Fused loss kernel at an HBM-saturating batch: per-launch ms from HIP events on the stream."""
     from consistent_depth_amd import synthetic
     from consistent_depth_amd.loss import consistency_loss as CL
@@ -215,7 +218,10 @@ def loss_microbench(lib, B, H, W, iters, device):
     depth.requires_grad_(True)
     call = lambda: CL.consistency_loss(depth, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=CL.DEPTH_EXP,  # noqa: E731
                                        tile_windows=twin)
-    for _ in range(5):      # untimed warm-up calls (plans, workspace, clocks)
+    # untimed warm-up calls: plans, workspace -- and the clocks.  A cold series of 0.2 ms calls starts fast, sags for ~20 calls and settles
+    # (profiles/loss_sweep_variants_r05.txt: 3 warm-up calls 0.2347 ms, 100 calls 0.2082 ms on the same box); ~20 ms of calls reach the
+    # settled state the timed calls then stay in.
+    for _ in range(warm):
         call()
     torch.cuda.synchronize()
     assert lib.cd_profile_begin(iters) == 0
@@ -499,13 +505,14 @@ def main():
                                "traffic_over_algorithmic": round(traffic / alg, 4) if traffic else None,
                                "launch_pairs": args.loss_batch, "avg_ms": round(avg, 5), "median_ms": round(float(np.median(ms)), 5),
                                "min_ms": round(float(np.min(ms)), 5), "max_ms": round(float(np.max(ms)), 5), "calls": int(len(ms)),
+                               "warmup_calls": LOSS_WARM_CALLS,
                                "algorithmic_bytes_per_launch": alg,
                                "lib": lib.cd_build_info().decode()}
             if sweep:
                 # The row sweep gives every CU ONE pair at a time; at 256 pairs = 256 CUs the launch lasts as long as its slowest pair
                 # (plans differ in length) -- with several pairs per CU the workgroups balance.  The same kernel at 4x the pairs:
                 try:
-                    ms4 = loss_microbench(lib, 4 * args.loss_batch, H, W, max(4, args.loss_iters // 2), device)
+                    ms4 = loss_microbench(lib, 4 * args.loss_batch, H, W, max(4, args.loss_iters // 2), device, warm=LOSS_WARM_CALLS // 4)
                     avg4 = float(np.mean(ms4))
                     ach4 = LOSS_BYTES_PER_PAIR_PX * px * 4 * args.loss_batch / (avg4 * 1e-3) / 1e9
                     out["roofline"]["sustained"] = {"launch_pairs": 4 * args.loss_batch, "avg_ms": round(avg4, 5), "achieved": round(ach4, 1),

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void sweep_plan_kernel(const float* __restr
         PlanHeader* ph = reinterpret_cast<PlanHeader*>(blob + (size_t)b * stride + plan_off);
         int n = plan_items(g, lo_s, hi_s, suf, items);
         if (n > 0 && fan_in > SWEEP_MAX_FAN_IN) n = -3;     // a 32-bit accumulator could wrap: no plan, the exact fallback path
-        if (n > 0) expand_plan(g, items, n, reinterpret_cast<PlanItem*>(ph + 1));
+        if (n > 0) expand_plan(g, items, n, reinterpret_cast<PlanItem*>(ph + 1), lo_s, hi_s);
         ph->n_items = n; ph->G = g.G; ph->R = g.R; ph->PXT = g.PXT;
         ph->fan_in = fan_in; ph->limit = sweep_limit_scaled(fan_in); ph->pad[0] = ph->pad[1] = 0;
     }
@@ -144,14 +144,17 @@ struct WgState {           // in LDS (the `red` scratch behind the rings)
     int redo;              // the pair must be recomputed in the exact mode
     int is_last;
     float fbar[2];
-    float red4[4];
+    float red4[8];
+    float prep_in[34];     // the pair's intrinsics [2][4], extrinsics [2][3][4], mask sums [2] (pair_constants)
 };
 static_assert(sizeof(WgState) <= kLdsReserve, "WgState must fit the LDS reserve behind the rings");
 
 struct DevEnv {
     WgState* st; unsigned* oidx; float* oval; int seg_cap;     // oidx / oval: the pair's segment
     __device__ __forceinline__ static void add32(unsigned* p, int v) { atomicAdd(p, (unsigned)v); }   // ds_add_u32, no return
-    __device__ __forceinline__ static bool any(bool x) { return __any(x) != 0; }
+    __device__ __forceinline__ static bool any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+    __device__ __forceinline__ static unsigned long long vote(bool x) { return __builtin_amdgcn_ballot_w64(x); }   // lane mask (scalar)
+    __device__ __forceinline__ static bool any_vote(unsigned long long m) { return m != 0ull; }
     // wave-aggregated append: ONE returning LDS atomic per wave and call; all lanes of the wave must call it (convergent)
     __device__ __forceinline__ void push(bool need, unsigned idx, float v) {
         const unsigned long long mask = __ballot(need);
@@ -200,24 +203,45 @@ __device__ __forceinline__ void pair_constants(WgState& st, float* scratch, cons
     constexpr int NS = kUnitGrid * kUnitGrid;
     static_assert(NS == kBlock, "fbar is reduced like prep_kernel does: 256 threads, 4 wave sums added in order");
     const int t = threadIdx.x, lane = t & (kWave - 1), wid = t / kWave;
-    for (int k = 0; k < 2; ++k) {
-        float acc = 0.f;
-        if (t < kBlock)
-            for (int bb = t; bb < B; bb += kBlock) acc += pp.intr[(bb * 2 + k) * 4 + 0] + pp.intr[(bb * 2 + k) * 4 + 1];
-        acc = wave_sum(acc);
-        if (t < kBlock && lane == 0) st.red4[wid] = acc;
-        __syncthreads();
-        if (t == 0) st.fbar[k] = (((0.f + st.red4[0]) + st.red4[1]) + st.red4[2] + st.red4[3]) / (2.f * (float)B);
-        __syncthreads();
+    // Everything this function READS from global memory is requested up front: the unit samples' inputs (two dependent latencies: flow ->
+    // tap positions -> sampled depths; no camera needed), the batch's focal lengths, the pair's intrinsics / extrinsics / mask sums (into
+    // LDS for thread 0).  The arithmetic then follows in its old order -- same numbers -- on data that is already there.
+    const int HW = H * W;
+    float f0[2] = {0.f, 0.f}, f1[2] = {0.f, 0.f};        // the first round of the focal-length sums (requested before the samples' chain)
+    if (t < kBlock && t < B)
+        for (int k = 0; k < 2; ++k) { f0[k] = pp.intr[(t * 2 + k) * 4 + 0]; f1[k] = pp.intr[(t * 2 + k) * 4 + 1]; }
+    int sx = 0, sy = 0;
+    UnitLoads ul{};
+    if (t < 2 * NS) {
+        const int j = t / NS;
+        unit_sample_xy(H, W, t % NS, &sx, &sy);
+        ul = unit_sample_load(depth_p + (j ? HW : 0), depth_p + (j ? 0 : HW), j ? fb : ff, j ? mb : mf, H, W, sx, sy);
     }
-    if (t == 0) prep_pair(pp.intr + b * 8, pp.extr + b * 24, pp.mask_sum + b * 2, st.fbar, pp.lambda_r, pp.lambda_b, B, H, W, st.cam);
+    if (t >= 2 * NS && t < 2 * NS + 34) {      // intr [8], extr [24], mask sums [2] of the pair
+        const int i = t - 2 * NS;
+        st.prep_in[i] = i < 8 ? pp.intr[b * 8 + i] : (i < 32 ? pp.extr[b * 24 + (i - 8)] : pp.mask_sum[b * 2 + (i - 32)]);
+    }
+    float acc[2] = {0.f, 0.f};
+    if (t < kBlock)
+        for (int k = 0; k < 2; ++k) {
+            acc[k] += f0[k] + f1[k];
+            for (int bb = t + kBlock; bb < B; bb += kBlock) acc[k] += pp.intr[(bb * 2 + k) * 4 + 0] + pp.intr[(bb * 2 + k) * 4 + 1];
+        }
+    acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]);
+    if (t < kBlock && lane == 0) { st.red4[wid] = acc[0]; st.red4[4 + wid] = acc[1]; }
+    __syncthreads();
+    if (t == 0) {
+        for (int k = 0; k < 2; ++k)
+            st.fbar[k] = (((0.f + st.red4[4 * k]) + st.red4[4 * k + 1]) + st.red4[4 * k + 2] + st.red4[4 * k + 3]) / (2.f * (float)B);
+        prep_pair(st.prep_in, st.prep_in + 8, st.prep_in + 32, st.fbar, pp.lambda_r, pp.lambda_b, B, H, W, st.cam);
+    }
     __syncthreads();
     // The unit samples: 256 per direction, one per thread of waves 0..7; their sums by wave shuffles, then the 4 wave sums of a
     // direction in wave order by one thread -- a fixed order (bit-reproducible; the host emulation sums in index order: the estimate
     // is floored to a power of two, any estimate gives a correct gradient).
     UnitSample u;
     u.direct = u.scatter = 0.f; u.valid = 0;
-    if (t < 2 * NS) u = unit_sample_at<MODE>(st.cam, depth_p, ff, fb, mf, mb, H, W, t / NS, t % NS);
+    if (t < 2 * NS) u = unit_sample_eval<MODE>(st.cam[t / NS], ul, sx, sy);
     const float wd = wave_sum(u.direct), ws = wave_sum(u.scatter), wn = wave_sum((float)u.valid);
     if (t < 2 * NS && lane == 0) { scratch[wid * 3] = wd; scratch[wid * 3 + 1] = ws; scratch[wid * 3 + 2] = wn; }
     __syncthreads();
@@ -272,7 +296,10 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     const float* __restrict__ mb, PairCam* __restrict__ cams, const char* __restrict__ blob, float* __restrict__ grad,
     unsigned* __restrict__ oidx_all, float* __restrict__ oval_all, int seg_cap, const SweepShape sh, const PairPrep pp, int B,
     const SweepOut out) {
-    extern __shared__ __align__(16) unsigned smem[];   // [2][ring] accumulators, [2][ring] depths, WgState
+    // [2][ring] depths, [2][ring] accumulators, WgState.  Depths FIRST: a source's four depth taps are ds_read2_b32 (offsets of at most
+    // 255 words: {0, 1} and {RW, RW + 1} fit), its accumulator adds ds_add_u32 with 16-bit byte offsets -- so ONE address register,
+    // the tap's depth address, serves all eight (accumulators first cost a v_add per read pair)
+    extern __shared__ __align__(16) unsigned smem[];
     const Geo g = SG == 1 ? make_geo(kStaticH, kStaticW, kStaticPXT) : sh.g;
     const int b = blockIdx.x, HW = g.H * g.W, ring = ring_rows(g) * g.RW;
     const int f = uni((int)(threadIdx.x / kFrameThreads)), k = 1 - f;   // whole waves serve one frame: everything derived from f is scalar
@@ -283,17 +310,18 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     v.flj = (f ? fb : ff) + (size_t)b * 2 * HW;
     v.mkj = (f ? mb : mf) + (size_t)b * HW;
     v.gradj = grad + (size_t)b * 2 * HW + (f ? HW : 0);
-    float* D0 = reinterpret_cast<float*>(smem + 2 * ring);
-    v.Aj = smem + (f ? ring : 0); v.Ak = smem + (f ? 0 : ring);
+    float* D0 = reinterpret_cast<float*>(smem);
+    unsigned* A0 = smem + 2 * ring;
+    v.Aj = A0 + (f ? ring : 0); v.Ak = A0 + (f ? 0 : ring);
     v.Dj = D0 + (f ? ring : 0); v.Dk = D0 + (f ? 0 : ring);
-    WgState& st = *reinterpret_cast<WgState*>(D0 + 2 * ring);
+    WgState& st = *reinterpret_cast<WgState*>(smem + 4 * ring);
     if (threadIdx.x == 0) { st.ovf_n = 0u; st.redo = 0; st.is_last = 0; }
     // ---- the accumulators are cleared and the depth rows of the first window requested BEFORE the pair's constants are computed
     // (neither needs them): the loads' latency and the constants' latency chains (sample -> taps, ~10 us) overlap
     constexpr int kInitBatches = 4;
     v.cj = Cam{};
     const Lane<PXT> l0 = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);      // (only its row / column fields are used here)
-    for (int i = threadIdx.x; i < 2 * ring; i += kThreads) smem[i] = 0u;
+    for (int i = threadIdx.x; i < 2 * ring; i += kThreads) A0[i] = 0u;
     const int init_hi = init_stage_hi(g);
     const bool init_batched = init_hi <= kInitBatches * kStagePasses * g.RP;
     float sv0[kInitBatches][kStagePasses][PXT];
@@ -364,6 +392,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         constexpr int NQ = kStaticSvcQuads;     // kStagePasses * RP rows of W / 4 quads (launch_sweep_inst checks it against the geometry)
         const int sl = (int)threadIdx.x - f * kFrameThreads - g.RP * g.CG;
         SvcRegs<NQ> q;
+        const SvcLane<NQ> slc = make_svc_lane<NQ>(v, sl);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) q.v[i][0] = q.v[i][1] = q.v[i][2] = q.v[i][3] = 0.f;
         Rec me = items[0].f[f];
@@ -378,7 +407,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
             const bool more = it + 1 < n_items;
             const Rec nx = items[more ? it + 1 : it].f[f];
             if (!SRC_STAGES) svc_load<NQ>(v, sl, nx.s_lo, more ? nx.s_hi : nx.s_lo, q);
-            svc_flush<NQ>(v, sl, me.fl_lo, me.fl_hi);
+            svc_flush<NQ>(v, slc, sl, me.fl_lo, me.fl_hi);
             __syncthreads();
             me = nx;
         }
@@ -419,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
             if constexpr (FAST) load_inputs_all<PXT>(v, lf, nx.p > 0 ? nx.p : 0, nxt);      // (an item without a group, and the last one: row 0, unused)
             else load_inputs<PXT>(v, l, more ? nx.p : -1, 0, nxt);
             if (SRC_STAGES) {      // the depth rows entering now were requested during the previous item; request the next ones
-                r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
+                r.bad = !stage_rows<MODE, PXT, false>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;     // (pad columns: written by the prologue, constant)
                 load_stage_nosel<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
             } else if (!SVC) {
                 r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
@@ -427,7 +456,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
                 flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);
             }
             if constexpr (FAST) {
-                if (me.p >= 0) process_rows_fast<MODE, REPROJ, PXT>(v, cf, env, r, l, lf, cur, me.p, wk, nvk);     // wave-uniform branch
+                if (me.p >= 0) process_rows_fast<MODE, REPROJ, PXT>(v, cf, env, r, l, lf, cur, me.p, wk, nvk, me.inw != 0);     // wave-uniform branch
             } else process_rows<MODE, REPROJ, PXT>(v, env, r, l, cur, me.p, 0, wk, nvk);
             __syncthreads();
             me = nx; wk = nwk; nvk = nnvk;
@@ -458,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     if (env.any(r.bad) && (threadIdx.x & (kWave - 1)) == 0) env.degenerate();
     // loss partial sums: one (reprojection, disparity) pair per wave
     {
-        const float ar = wave_sum((float)r.acc_r), ad = wave_sum((float)r.acc_d);
+        const float ar = wave_sum((float)loss_sum_r<PXT>(r)), ad = wave_sum((float)loss_sum_d<PXT>(r));
         const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
         if (lane == 0) { st.wave_part[wid * 2] = ar; st.wave_part[wid * 2 + 1] = ad; }
     }

@@ -198,7 +198,9 @@ struct Rec {
     int fl_lo, fl_hi;  // rows [fl_lo, fl_hi) leave the ring at the start of this item ...
     int fl_slot;       // ... fl_lo sits in this slot
     int s_lo, s_hi;    // rows [s_lo, s_hi) enter the ring during this item (row H = the pad row)
-    int pad[3];
+    int inw;           // 1: EVERY tap of every valid source of this item's group lies in rows of the other ring this item can use
+                       // (the planner knows the groups' tap-row bounds: the fast source pass then needs neither clamp nor vote)
+    int pad[2];
 };
 static_assert(sizeof(Rec) == 48, "Rec layout");
 struct PlanItem { Rec f[2]; };
@@ -218,7 +220,8 @@ CD_HD unsigned mad24(unsigned a, unsigned b, unsigned c) { return a * b + c; }
 // rows [0, init_hi) are staged by the kernel's prologue (window of item 0 = [0, R))
 CD_HD int init_stage_hi(const Geo& g) { return g.R < g.H + 1 ? g.R : g.H + 1; }
 
-CD_HD void expand_plan(const Geo& g, const Item* items, int n, PlanItem* out) {
+// lo / hi: the planner's tap-row bounds (plan_items); without them no item claims `inw`
+CD_HD void expand_plan(const Geo& g, const Item* items, int n, PlanItem* out, const short* lo = nullptr, const short* hi = nullptr) {
     int wprev[2] = {0, 0}, wsprev[2] = {0, 0}, staged[2];
     staged[0] = staged[1] = init_stage_hi(g);
     for (int t = 0; t < n; ++t) {
@@ -228,7 +231,7 @@ CD_HD void expand_plan(const Geo& g, const Item* items, int n, PlanItem* out) {
             r.ws = wrap_slot(wsprev[f] + (r.w - wprev[f]), g.R);
             r.p = items[t].p[f];
             r.nv = wprev[f] + g.R - r.w;
-            r.pad[0] = r.pad[1] = r.pad[2] = 0;
+            r.inw = 0; r.pad[0] = r.pad[1] = 0;
             r.fl_lo = wprev[f];
             r.fl_hi = r.w < g.H ? r.w : g.H;
             if (r.fl_hi < r.fl_lo) r.fl_hi = r.fl_lo;
@@ -240,6 +243,16 @@ CD_HD void expand_plan(const Geo& g, const Item* items, int n, PlanItem* out) {
             wprev[f] = r.w; wsprev[f] = r.ws;
             out[t].f[f] = r;
         }
+        if (lo != nullptr && hi != nullptr)
+            for (int f = 0; f < 2; ++f) {
+                Rec& r = out[t].f[f];
+                const Rec& o = out[t].f[1 - f];
+                if (r.p < 0) continue;
+                const int gi = f * g.NG + r.p / g.G;
+                // the fast pass addresses rows ya and ya + 1 (hi holds ya + 1): both inside [o.w, o.w + o.nv).  A group without a
+                // valid source (lo = kNoRow, hi = -1) qualifies: its lanes are all mask-0 lanes, for which any resident row does.
+                r.inw = (o.nv >= 2 && (int)lo[gi] >= o.w && (int)hi[gi] <= o.w + o.nv - 1) ? 1 : 0;
+            }
     }
 }
 
@@ -254,23 +267,35 @@ constexpr int kUnitGrid = 16;
 
 struct UnitSample { float direct, scatter; int valid; };
 
-// one sample source (x, y) of direction j: c = its PairCam, vj / vk the raw depth planes of its frame / the other frame
+// one sample source (x, y) of direction j, in two steps: what it READS (mask, flow, own depth, the four sampled depths -- the tap
+// positions need no camera: sx, sy are W / (W - 1), H / (H - 1)) and what it COMPUTES from them with the pair's PairCam.  The kernel
+// issues the reads of all samples before the pair's constants exist (their two dependent memory latencies then overlap the
+// constants' own chain); the host emulation calls them back to back.  vj / vk: the raw depth planes of its frame / the other frame.
+struct UnitLoads { float m, fx, fy, vj, v00, v01, v10, v11; Taps t; };
+CD_HD UnitLoads unit_sample_load(const float* vj, const float* vk, const float* fl, const float* mk, int H, int W, int x, int y) {
+    UnitLoads l;
+    const int HW = H * W, p = y * W + x;
+    l.m = mk[p]; l.fx = fl[p]; l.fy = fl[HW + p]; l.vj = vj[p];
+    l.t = tap_coords((float)x, (float)y, l.fx, l.fy, (float)W / (float)(W - 1), (float)H / (float)(H - 1), W, H);   // (= PairCam::sx, sy)
+    l.v00 = vk[l.t.ya * W + l.t.xa]; l.v01 = vk[l.t.ya * W + l.t.xb];
+    l.v10 = vk[l.t.yb * W + l.t.xa]; l.v11 = vk[l.t.yb * W + l.t.xb];
+    return l;
+}
 template <int MODE>
-CD_HD UnitSample unit_sample(const PairCam& c, const float* vj, const float* vk, const float* fl, const float* mk, int H, int W, int x, int y) {
+CD_HD UnitSample unit_sample_eval(const PairCam& c, const UnitLoads& l, int x, int y) {
     UnitSample u;
     u.direct = u.scatter = 0.f; u.valid = 0;
-    const int HW = H * W, p = y * W + x;
-    const float m = mk[p];
+    const float m = l.m;
     if (m == 0.f) return u;
-    const float d = to_depth<MODE>(vj[p]);
-    const Taps t = tap_coords((float)x, (float)y, fl[p], fl[HW + p], c.sx, c.sy, W, H);
-    const float d00 = to_depth<MODE>(vk[t.ya * W + t.xa]), d01 = to_depth<MODE>(vk[t.ya * W + t.xb]);
-    const float d10 = to_depth<MODE>(vk[t.yb * W + t.xa]), d11 = to_depth<MODE>(vk[t.yb * W + t.xb]);
+    const float d = to_depth<MODE>(l.vj);
+    const Taps& t = l.t;
+    const float d00 = to_depth<MODE>(l.v00), d01 = to_depth<MODE>(l.v01);
+    const float d10 = to_depth<MODE>(l.v10), d11 = to_depth<MODE>(l.v11);
     const float r0 = ((float)x - c.cx_r) * c.ifx_r, r1 = -((float)y - c.cy_r) * c.ify_r;
     const float a0 = c.M[0] * r0 + c.M[1] * r1 - c.M[2], a1 = c.M[3] * r0 + c.M[4] * r1 - c.M[5], a2 = c.M[6] * r0 + c.M[7] * r1 - c.M[8];
     const float X = d * a0 + c.c[0], Y = d * a1 + c.c[1], Z = d * a2 + c.c[2];
     const float iZ = 1.f / Z;
-    const float ex = (c.cx_t - c.fx_t * X * iZ) - ((float)x + fl[p]), ey = (c.cy_t + c.fy_t * Y * iZ) - ((float)y + fl[HW + p]);
+    const float ex = (c.cx_t - c.fx_t * X * iZ) - ((float)x + l.fx), ey = (c.cy_t + c.fy_t * Y * iZ) - ((float)y + l.fy);
     const float e2 = ex * ex + ey * ey;
     const float ie = e2 > 0.f ? 1.f / sqrtf(e2) : 0.f;
     const float dpx = c.fx_t * iZ * (X * a2 * iZ - a0), dpy = c.fy_t * iZ * (a1 - Y * a2 * iZ);
@@ -317,7 +342,12 @@ CD_HD UnitSample unit_sample_at(const PairCam* cams, const float* depth_p, const
     const int iy = t / kUnitGrid, ix = t - iy * kUnitGrid;
     const int x = (2 * ix + 1) * W / (2 * kUnitGrid), y = (2 * iy + 1) * H / (2 * kUnitGrid);
     const int HW = H * W;
-    return unit_sample<MODE>(cams[j], depth_p + (j ? HW : 0), depth_p + (j ? 0 : HW), j ? fb : ff, j ? mb : mf, H, W, x, y);
+    return unit_sample_eval<MODE>(cams[j], unit_sample_load(depth_p + (j ? HW : 0), depth_p + (j ? 0 : HW), j ? fb : ff, j ? mb : mf, H, W, x, y), x, y);
+}
+// (the kernel's two steps of unit_sample_at)
+CD_HD void unit_sample_xy(int H, int W, int t, int* x, int* y) {
+    const int iy = t / kUnitGrid, ix = t - iy * kUnitGrid;
+    *x = (2 * ix + 1) * W / (2 * kUnitGrid); *y = (2 * iy + 1) * H / (2 * kUnitGrid);
 }
 
 // ---------------------------------------------------------------- execution state
@@ -394,15 +424,21 @@ template <int PXT> struct Inputs { float fx[PXT], fy[PXT], m[PXT]; };   // flow 
 
 template <int PXT> struct Regs {
     float sv[kStagePasses][PXT];         // raw depth of the rows entering the ring
-    double acc_r, acc_d;                 // loss partial sums of this thread (its frame = direction)
+    double acc_r, acc_d;                 // loss partial sums of this thread (its frame = direction) ...
+    float pend_r, pend_d;                // ... plus what the fast source pass of the previous item left (added in straight-line code at the
+                                         // top of the next pass: an fp64 add behind the pass's slow-path branch costs register copies per item)
     bool bad;                            // a staged depth was not a positive finite number (see stage_rows)
 };
 template <int PXT> CD_HD void init_regs(Regs<PXT>& r) {
     for (int i = 0; i < PXT; ++i)
         for (int s = 0; s < kStagePasses; ++s) r.sv[s][i] = 0.f;
     r.acc_r = r.acc_d = 0.0;
+    r.pend_r = r.pend_d = 0.f;
     r.bad = false;
 }
+// the thread's loss partial sums (what the kernel's epilogue reads)
+template <int PXT> CD_HD double loss_sum_r(const Regs<PXT>& r) { return r.acc_r + (double)r.pend_r; }
+template <int PXT> CD_HD double loss_sum_d(const Regs<PXT>& r) { return r.acc_d + (double)r.pend_d; }
 
 // does pass q of the row group at p give this thread a source row?  (p < 0: the item has no group for this frame)
 template <int PXT> CD_HD bool pass_row_ok(const View& v, const Lane<PXT>& l, int p, int q) {
@@ -442,17 +478,24 @@ template <int PXT> CD_HD void load_stage_nosel(const View& v, const Lane<PXT>& l
         // the tail / slide-only items need them); stage_rows never reads the registers of a pass without rows
         if (s > 0 && s_hi - s_lo <= s * v.RP) continue;
         const int row = s_lo + s * v.RP + l.rr;
-        const bool ok = row < s_hi && row < v.H;
-        const unsigned off = ok ? ((unsigned)(s_lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2 : 0u;
+        const int rc = row < v.H ? row : v.H - 1;       // (a lane beyond s_hi reads a row it does not stage: in bounds, never used)
+        const unsigned off = mad24((unsigned)rc, (unsigned)v.W << 2, l.x0 << 2);
         const VecF<PXT> a = ldgv<PXT>(v.vj, off);
 #pragma unroll
         for (int i = 0; i < PXT; ++i) sv[s][i] = a.v[i];
     }
 }
 
+// (keeps a rare wave-uniform branch a branch: without it the compiler folds the branch into per-lane selects on the hot path)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CD_KEEP_BRANCH() asm volatile("" ::: "memory")
+#else
+#define CD_KEEP_BRANCH() ((void)0)
+#endif
 // rows [s_lo, s_hi) enter the ring (their values are in sv; row r -> slot r & (R - 1)).  Returns false if a staged depth
 // is not a positive finite number (such an input takes the exact v1 path: see process_rows, "lenient").
-template <int MODE, int PXT>
+// PADS = false: the pad column(s) are left alone -- their value (1) never changes once the prologue has written every slot.
+template <int MODE, int PXT, bool PADS = true>
 CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, const float (*sv)[PXT]) {
     bool good = true;
 #pragma unroll
@@ -460,16 +503,19 @@ CD_HD bool stage_rows(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, con
         const int row = s_lo + s * v.RP + l.rr;
         if (l.on && row < s_hi) {
             const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW);
-            const bool img = row < v.H;         // row H is the pad row: finite depth, only ever sampled with weight 0
             VecF<PXT> d;
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) {
-                d.v[i] = img ? to_depth<MODE>(sv[s][i]) : 1.f;
-                good = good && (d.v[i] > 0.f && d.v[i] < INFINITY);
+            for (int i = 0; i < PXT; ++i) d.v[i] = to_depth<MODE>(sv[s][i]);
+            if (s_hi > v.H) {                   // wave-uniform, the last item(s) only: row H is the pad row -- finite depth, only ever sampled with weight 0
+                CD_KEEP_BRANCH();
+#pragma unroll
+                for (int i = 0; i < PXT; ++i) d.v[i] = row < v.H ? d.v[i] : 1.f;
             }
+#pragma unroll
+            for (int i = 0; i < PXT; ++i) good = good && (d.v[i] > 0.f && d.v[i] < INFINITY);
             *reinterpret_cast<VecF<PXT>*>(&v.Dj[base + l.x0]) = d;
             if (base == 0u) *reinterpret_cast<VecF<PXT>*>(&v.Dj[(unsigned)(v.R * v.RW) + l.x0]) = d;      // slot R mirrors slot 0
-            if (l.x0 == 0u)
+            if (PADS && l.x0 == 0u)
                 for (int c = v.W; c < v.RW; ++c) {
                     v.Dj[base + (unsigned)c] = 1.f;   // the pad column(s)
                     if (base == 0u) v.Dj[(unsigned)(v.R * v.RW + c)] = 1.f;
@@ -580,32 +626,44 @@ template <int MODE, int NQ> CD_HD bool svc_stage(const View& v, int lane, int s_
 }
 
 // rows [lo, hi) leave the ring (cf. flush_rows).  Round 5: ONE wave per frame does this for everybody, so it is bound by how fast a
-// single wave issues instructions and by the latency chain LDS read -> convert -> store: all reads of the call are issued before the
-// first use, and the mirror of slot 0 (one row in R) is folded in by a separate, wave-uniform rare branch.
-template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) {
+// single wave issues instructions and by the latency chain LDS read -> convert -> store.  Measured at the end of round 5 (256 pairs):
+// with the sources doing nothing but their loads the call still took 0.194 of 0.208 ms -- this wave WAS the other critical path.
+// Hence: everything that depends only on the lane (a quad's row inside the run, its column, its offset in the gradient rows) is
+// computed once per kernel (SvcLane); the quads of an item are cut off by a WAVE-UNIFORM bound (an ordinary item moves 4 of the
+// SMAX = 8 rows: 4 of 7 quads -- the old per-lane test ran all 7 with an empty exec mask); whether a row of slot 0 is among the rows
+// (its mirror slot has to be folded in) is scalar arithmetic on [lo, hi); all LDS reads of the call are issued before the first use.
+// The pad column(s) of the accumulators are not touched: a tap in a pad column carries weight 0, its fixed-point addend is 0.
+template <int NQ> struct SvcLane { unsigned rq[NQ], cw[NQ], go[NQ]; };   // quad lane + 64 i of a run of rows: row, first column (words), byte offset
+template <int NQ> CD_HD SvcLane<NQ> make_svc_lane(const View& v, int lane) {
+    SvcLane<NQ> s;
     const int QW = v.W >> 2;
-    const int nq = (hi - lo) * QW;
+    for (int i = 0; i < NQ; ++i) {
+        const int qi = lane + kSvcLanes * i, rr = qi / QW;
+        s.rq[i] = (unsigned)rr; s.cw[i] = 4u * (unsigned)(qi - rr * QW); s.go[i] = 16u * (unsigned)qi;
+    }
+    return s;
+}
+template <int NQ> CD_HD void svc_flush(const View& v, const SvcLane<NQ>& sl, int lane, int lo, int hi) {
+    const int nq = (hi - lo) * (v.W >> 2);
     const float unit = v.cj.unit_s;
+    float* grow = v.gradj + (size_t)lo * (size_t)v.W;            // (wave-uniform)
     VecU<2> n0[NQ], n1[NQ];
     unsigned base[NQ];
-    bool any_mirror = false;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        const int qi = lane + kSvcLanes * i, rr = qi / QW, c4 = qi - rr * QW, row = lo + rr;
-        const unsigned slot = (unsigned)(row & (v.R - 1));
-        base[i] = slot * (unsigned)v.RW + 4u * (unsigned)c4;
-        n0[i].v[0] = n0[i].v[1] = n1[i].v[0] = n1[i].v[1] = 0u;
-        if (qi < nq) {
+        if (i * kSvcLanes >= nq) break;                           // wave-uniform
+        base[i] = mad24(((unsigned)lo + sl.rq[i]) & (unsigned)(v.R - 1), (unsigned)v.RW, sl.cw[i]);
+        if (lane + kSvcLanes * i < nq) {
             n0[i] = *reinterpret_cast<const VecU<2>*>(&v.Aj[base[i]]); n1[i] = *reinterpret_cast<const VecU<2>*>(&v.Aj[base[i] + 2]);
-            any_mirror = any_mirror || slot == 0u;
         }
     }
     VecU<2> z; z.v[0] = z.v[1] = 0u;
-    if (any_mirror) {      // (per lane; a row of slot 0 leaves once in R rows) what the fast pass added to the mirror of slot 0
+    if (((-lo) & (v.R - 1)) < hi - lo) {      // wave-uniform: a row of slot 0 is among [lo, hi) (once in R rows) -- what the fast pass added to its mirror
+        CD_KEEP_BRANCH();
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int qi = lane + kSvcLanes * i;
-            if (qi < nq && base[i] < (unsigned)v.RW) {
+            if (i * kSvcLanes >= nq) break;
+            if (lane + kSvcLanes * i < nq && base[i] < (unsigned)v.RW) {
                 VecU<2>* m0 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + base[i]]);
                 VecU<2>* m1 = reinterpret_cast<VecU<2>*>(&v.Aj[(unsigned)(v.R * v.RW) + base[i] + 2]);
                 const VecU<2> k0 = *m0, k1 = *m1;
@@ -616,21 +674,18 @@ template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) 
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        const int qi = lane + kSvcLanes * i;
-        if (qi < nq) {
+        if (i * kSvcLanes >= nq) break;
+        if (lane + kSvcLanes * i < nq) {
             *reinterpret_cast<VecU<2>*>(&v.Aj[base[i]]) = z; *reinterpret_cast<VecU<2>*>(&v.Aj[base[i] + 2]) = z;
             VecF<4> g;
             g.v[0] = (float)(int)n0[i].v[0] * unit; g.v[1] = (float)(int)n0[i].v[1] * unit;
             g.v[2] = (float)(int)n1[i].v[0] * unit; g.v[3] = (float)(int)n1[i].v[1] * unit;
-            stgv<4>(v.gradj, ((unsigned)lo * (unsigned)v.W + 4u * (unsigned)qi) << 2, g);
+            stgv<4>(grow, sl.go[i], g);
         }
     }
-    const int row = lo + lane;
-    if (row < hi)
-        for (int c = v.W; c < v.RW; ++c) {
-            v.Aj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 0u;
-            if ((row & (v.R - 1)) == 0) v.Aj[(unsigned)(v.R * v.RW + c)] = 0u;
-        }
+}
+template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) {      // (the host emulation: no per-kernel state)
+    svc_flush<NQ>(v, make_svc_lane<NQ>(v, lane), lane, lo, hi);
 }
 
 // Evaluate pass q of the source rows [p, p + G) of the wave's frame j: loss partials, direct gradient -> ring j, the 4 tap
@@ -648,8 +703,10 @@ template <int NQ> CD_HD void svc_flush(const View& v, int lane, int lo, int hi) 
 // sample a resident row (any finite positive depth gives the same 0), and stage_rows watches the ONLY inputs for which this
 // could differ from the reference: if any depth of the pair is not a positive finite number, the kernel raises the fallback
 // flag and the exact v1 pass recomputes gradient and loss (loss_api.hip).
+// (process_rows_sums: the pass itself, its loss partial sums returned; process_rows adds them to the thread's fp64 sums)
 template <int MODE, bool REPROJ, int PXT, class Env>
-CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& l, const Inputs<PXT>& in, int p, int q, int wk, int nvk) {
+CD_HD void process_rows_sums(const View& v, Env& env, const Lane<PXT>& l, const Inputs<PXT>& in, int p, int q, int wk, int nvk,
+                             float& sum_r, float& sum_d) {
     const int y = p + q * v.RP + l.rr;
     const bool rowok = pass_row_ok<PXT>(v, l, p, q);
     const Cam& cj = v.cj;
@@ -662,7 +719,7 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
     if (rowok) dv = *reinterpret_cast<const VecF<PXT>*>(&v.Dj[own]);
     // at most 2 pixels share the staged registers (a 1024-thread workgroup has 128 VGPRs per lane); PXT = 4 runs two batches
     constexpr int NB = PXT < 2 ? PXT : 2;
-    float sum_r = 0.f, sum_d = 0.f;
+    sum_r = 0.f; sum_d = 0.f;
 #pragma unroll
     for (int b0 = 0; b0 < PXT; b0 += NB) {
         // ---- stage 0: own depth, sampling coordinates, ring addresses
@@ -779,6 +836,11 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
             }
         }
     }
+}
+template <int MODE, bool REPROJ, int PXT, class Env>
+CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& l, const Inputs<PXT>& in, int p, int q, int wk, int nvk) {
+    float sum_r, sum_d;
+    process_rows_sums<MODE, REPROJ, PXT>(v, env, l, in, p, q, wk, nvk, sum_r, sum_d);
     r.acc_r += (double)sum_r; r.acc_d += (double)sum_d;
 }
 
@@ -799,24 +861,23 @@ CD_HD void process_rows(const View& v, Env& env, Regs<PXT>& r, const Lane<PXT>& 
 // (overflow list, global taps) live in one place.  Fast and general passes differ in the last bits of the algebra (both are within
 // the fp32 class of the oracle; tests/test_sweep_cpu.py runs the goldens through both).
 struct CamF {
-    float b1x, b2x, b1y, b2y, b1z, b2z;   // row part of a' = (fx_t a0, fy_t a1, a2):  a' = A'(x) + b1 * r1 - b2
+    float kx, ky, kz;                      // a'(x, p + rr) = LaneF::a(x, rr) + p * k  (k = -b1 / fy_r: a' is linear in the row)
     float cX, cY, cZ;                      // fx_t c0, fy_t c1, c2
-    float cx_t, cy_t, cy_r, ify_r, sx, sy;
+    float cx_t, cy_t, sx, sy;
     float drs, dbs, scs;
 };
 CD_HD CamF make_camf(const Cam& c) {
     CamF f;
-    f.b1x = c.fx_t * c.M[1]; f.b2x = c.fx_t * c.M[2];
-    f.b1y = c.fy_t * c.M[4]; f.b2y = c.fy_t * c.M[5];
-    f.b1z = c.M[7]; f.b2z = c.M[8];
+    f.kx = -(c.fx_t * c.M[1]) * c.ify_r; f.ky = -(c.fy_t * c.M[4]) * c.ify_r; f.kz = -c.M[7] * c.ify_r;
     f.cX = c.fx_t * c.c[0]; f.cY = c.fy_t * c.c[1]; f.cZ = c.c[2];
-    f.cx_t = c.cx_t; f.cy_t = c.cy_t; f.cy_r = c.cy_r; f.ify_r = c.ify_r; f.sx = c.sx; f.sy = c.sy;
+    f.cx_t = c.cx_t; f.cy_t = c.cy_t; f.sx = c.sx; f.sy = c.sy;
     f.drs = c.drs; f.dbs = c.dbs; f.scs = c.scs;
     return f;
 }
 template <int PXT> struct LaneF {
-    float ax[PXT], ay[PXT], az[PXT];   // column part of a': fx_t M[0] r0(x), fy_t M[3] r0(x), M[6] r0(x)
+    float ax[PXT], ay[PXT], az[PXT];   // a' = (fx_t a0, fy_t a1, a2) of the lane's pixels in row rr (the group at p = 0)
     float xf[PXT];                     // the columns as floats
+    float rrf;                         // rr as a float
     unsigned own;                      // rr * RW + x0: element index of the lane's own pixels in ring row 0
     unsigned goff;                     // (rr * W + x0) * 4: byte offset of the lane's pixels inside a row group
     int rr;
@@ -826,10 +887,14 @@ template <int PXT> CD_HD LaneF<PXT> make_lanef(const View& v, const Lane<PXT>& l
     for (int i = 0; i < PXT; ++i) {
         const float x = (float)(l.x0 + i);
         const float r0 = (x - v.cj.cx_r) * v.cj.ifx_r;
-        f.ax[i] = v.cj.fx_t * v.cj.M[0] * r0; f.ay[i] = v.cj.fy_t * v.cj.M[3] * r0; f.az[i] = v.cj.M[6] * r0;
+        const float r1 = (v.cj.cy_r - (float)l.rr) * v.cj.ify_r;
+        f.ax[i] = cd_fma(v.cj.fx_t * v.cj.M[0], r0, cd_fma(v.cj.fx_t * v.cj.M[1], r1, -(v.cj.fx_t * v.cj.M[2])));
+        f.ay[i] = cd_fma(v.cj.fy_t * v.cj.M[3], r0, cd_fma(v.cj.fy_t * v.cj.M[4], r1, -(v.cj.fy_t * v.cj.M[5])));
+        f.az[i] = cd_fma(v.cj.M[6], r0, cd_fma(v.cj.M[7], r1, -v.cj.M[8]));
         f.xf[i] = x;
     }
     f.rr = l.rr;
+    f.rrf = (float)l.rr;
     f.own = (unsigned)(l.rr * v.RW) + l.x0;
     f.goff = (l.rrW + l.x0) << 2;
     return f;
@@ -855,25 +920,24 @@ CD_HD int cd_med3i(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : 
 CD_HD float cd_sign(float x) { return cd_clamp(x * 8.5070592e37f /* 2^126 */, -1.f, 1.f); }
 
 // Evaluate the source rows [p, p + RP) (p >= 0: wave-uniform) of the wave's frame j.  wk / nvk: first resident row of ring k and the
-// number of rows usable by this item (Rec::w, Rec::nv of the other frame).
+// number of rows usable by this item (Rec::w, Rec::nv of the other frame).  inw (wave-uniform, Rec::inw): the planner guarantees that
+// the taps of every valid source of these rows are usable rows of ring k -- no clamp, no vote (a mask-0 lane reads whatever slot
+// its row number maps to: a resident depth, finite and positive, and its contributions are exact zeros like everywhere else).
 template <int MODE, bool REPROJ, int PXT, class Env>
 CD_HD void process_rows_fast(const View& v, const CamF& cf, Env& env, Regs<PXT>& r, const Lane<PXT>& l, const LaneF<PXT>& lf,
-                             const Inputs<PXT>& in, int p, int wk, int nvk) {
+                             const Inputs<PXT>& in, int p, int wk, int nvk, bool inw) {
     static_assert(PXT == 2, "the fast pass handles the two adjacent pixels of a lane as one batch");
     const int R = v.R, RW = v.RW, W = v.W, H = v.H;
-    const int y = p + lf.rr;
-    const float yf = (float)y;
+    r.acc_r += (double)r.pend_r; r.acc_d += (double)r.pend_d;          // the previous fast pass's sums (see Regs)
+    const float pf = (float)p;
+    const float yf = pf + lf.rrf;                                      // (exact: small integers)
     const unsigned own = lf.own + (unsigned)((p & (R - 1)) * RW);      // rows of a group share p's slot run: (p + rr) & (R - 1) = (p & (R - 1)) + rr
     const VecF<PXT> dv = *reinterpret_cast<const VecF<PXT>*>(&v.Dj[own]);
-    const float r1 = (cf.cy_r - yf) * cf.ify_r;
-    const float bx = cd_fma(cf.b1x, r1, -cf.b2x), by = cd_fma(cf.b1y, r1, -cf.b2y), bz = cd_fma(cf.b1z, r1, -cf.b2z);
-    const int hi = wk + (nvk >= 2 ? nvk - 2 : 0);                      // last row whose lower neighbour is usable too (scalar)
-    const bool window = nvk >= 2;
     // ---- stage 0: sampling coordinates, ring address of the upper-left tap
     float tx[PXT], ty[PXT], mx[PXT], my[PXT];
     unsigned i0[PXT];
     int ya[PXT], xa[PXT];
-    bool need_slow = false;
+    unsigned long long slow = 0ull;      // lane masks of the votes (scalar registers: a bool merged across the branches below becomes 0 / 1 selects)
 #pragma unroll
     for (int i = 0; i < PXT; ++i) {
         mx[i] = cd_fadd(lf.xf[i], in.fx[i]); my[i] = cd_fadd(yf, in.fy[i]);
@@ -881,10 +945,19 @@ CD_HD void process_rows_fast(const View& v, const CamF& cf, Env& env, Regs<PXT>&
         const float iy = cd_clamp(cd_fma(my[i], cf.sy, -0.5f), 0.f, (float)(H - 1));
         tx[i] = cd_fract(ix); ty[i] = cd_fract(iy);
         xa[i] = (int)ix; ya[i] = (int)iy;
-        const int ra = cd_med3i(ya[i], wk, hi);
-        const bool inside = window && ra == ya[i];
-        need_slow = need_slow || (!inside && in.m[i] != 0.f);
-        i0[i] = mad24((unsigned)ra & (unsigned)(R - 1), (unsigned)RW, (unsigned)xa[i]);
+    }
+    if (inw) {
+#pragma unroll
+        for (int i = 0; i < PXT; ++i) i0[i] = mad24((unsigned)ya[i] & (unsigned)(R - 1), (unsigned)RW, (unsigned)xa[i]);
+    } else {
+        const int hi = wk + (nvk >= 2 ? nvk - 2 : 0);                  // last row whose lower neighbour is usable too (scalar)
+        const bool window = nvk >= 2;
+#pragma unroll
+        for (int i = 0; i < PXT; ++i) {
+            const int ra = cd_med3i(ya[i], wk, hi);
+            slow |= env.vote((!window || ra != ya[i]) && in.m[i] != 0.f);
+            i0[i] = mad24((unsigned)ra & (unsigned)(R - 1), (unsigned)RW, (unsigned)xa[i]);
+        }
     }
     // ---- stage 1: the 4 depth taps of frame k (the row under slot s is slot s + 1: View::dup)
     float d00[PXT], d01[PXT], d10[PXT], d11[PXT];
@@ -895,7 +968,7 @@ CD_HD void process_rows_fast(const View& v, const CamF& cf, Env& env, Regs<PXT>&
 #pragma unroll
     for (int i = 0; i < PXT; ++i) {
         const float d = dv.v[i], m = in.m[i];
-        const float a0 = lf.ax[i] + bx, a1 = lf.ay[i] + by, a2 = lf.az[i] + bz;
+        const float a0 = cd_fma(pf, cf.kx, lf.ax[i]), a1 = cd_fma(pf, cf.ky, lf.ay[i]), a2 = cd_fma(pf, cf.kz, lf.az[i]);
         const float X = cd_fma(d, a0, cf.cX), Y = cd_fma(d, a1, cf.cY), Z = cd_fma(d, a2, cf.cZ);
         const float iZ = cd_rcp(Z);
         float g1 = 0.f;      // direct term before the depth head's jacobian, in units of ring j (times 2^20)
@@ -930,14 +1003,13 @@ CD_HD void process_rows_fast(const View& v, const CamF& cf, Env& env, Regs<PXT>&
             c10[i] = ngz * w10 * depth_jac<MODE>(d10[i]); c11[i] = ngz * w11 * depth_jac<MODE>(d11[i]);
             csum = MODE == kDepthIdentity ? fabsf(ngz) : fabsf(c00[i]) + fabsf(c01[i]) + fabsf(c10[i]) + fabsf(c11[i]);
         }
-        need_slow = need_slow || !(csum + fabsf(gd[i]) <= v.limit);       // (NaN fails the test)
+        slow |= env.vote(!(csum + fabsf(gd[i]) <= v.limit));              // (NaN fails the test)
     }
-    if (__builtin_expect(env.any(need_slow), 0)) {     // the exact paths: the general pass redoes this wave's pass from scratch
-        process_rows<MODE, REPROJ, PXT>(v, env, r, l, in, p, 0, wk, nvk);
-        return;
-    }
-    // ---- stage 3: 5 integer LDS atomics per pixel, loss partial sums
     float sum_r = 0.f, sum_d = 0.f;
+    if (__builtin_expect(env.any_vote(slow), 0)) {     // the exact paths: the general pass redoes this wave's pass from scratch
+        process_rows_sums<MODE, REPROJ, PXT>(v, env, l, in, p, 0, wk, nvk, sum_r, sum_d);
+    } else {
+    // ---- stage 3: 5 integer LDS atomics per pixel, loss partial sums
 #pragma unroll
     for (int i = 0; i < PXT; ++i) {
         env.add32(&v.Aj[own + (unsigned)i], sweep_scaled_to_fixed(gd[i]));
@@ -948,7 +1020,8 @@ CD_HD void process_rows_fast(const View& v, const CamF& cf, Env& env, Regs<PXT>&
         sum_r = cd_fma(in.m[i], er[i], sum_r);           // multiply, not select: 0 * inf = NaN exactly like the reference
         sum_d = cd_fma(in.m[i], ed[i], sum_d);
     }
-    r.acc_r += (double)sum_r; r.acc_d += (double)sum_d;
+    }
+    r.pend_r = sum_r; r.pend_d = sum_d;
 }
 
 // tap-row bounds of one source pixel for the planner (the same tap_coords as the kernels: identical rows)

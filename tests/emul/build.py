@@ -67,7 +67,7 @@ def fan_in(g, flow_fwd, flow_bwd, mask_fwd, mask_bwd):
     return lib().sweep_emul_fan_in(g["_raw"], _p(ff), _p(fb), _p(mf), _p(mb))
 
 
-def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False, order=0, service=False, fast=False):
+def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False, order=0, service=False, fast=False, inw=True):
     c = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
     depth = c(batch["depth"])
     B, _, H, W = depth.shape
@@ -79,6 +79,7 @@ def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False
     lib().sweep_emul_set_order(int(order))
     lib().sweep_emul_set_service(int(service))
     lib().sweep_emul_set_fast(int(fast))
+    lib().sweep_emul_set_inw(int(inw))
     fn = lib().sweep_emul_loss
     fn.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_float, ctypes.c_float] + [ctypes.c_int] * 7 + [ctypes.c_void_p] * 5
     rc = fn(_p(depth), _p(ff), _p(fb), _p(mf), _p(mb), _p(intr), _p(extr), lambda_r, lambda_b, mode, B, H, W, pxt, ring_rows,
@@ -90,3 +91,13 @@ def loss(batch, lambda_r, lambda_b, mode=0, pxt=2, ring_rows=0, force_slow=False
         raise RuntimeError(f"sweep emulation failed: rc={rc}")
     return {"total": total, "reprojection": reproj, "disparity": disp, "grad_depth": grad,
             "slow_lanes": stats[0], "overflow_entries": stats[1], "items": stats[2], "degenerate": bool(stats[3])}
+
+
+def inw_flags(g, flow_fwd, flow_bwd, mask_fwd, mask_bwd):
+    """Rec::inw of every item of ONE pair's plan: (n_items, 2) int32 (1 = every valid tap of the item's group is a usable ring row)."""
+    c = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
+    out = np.zeros((g["max_items"], 2), np.int32)
+    ff, fb, mf, mb = c(flow_fwd), c(flow_bwd), c(mask_fwd), c(mask_bwd)
+    n = lib().sweep_emul_inw(g["_raw"], _p(ff), _p(fb), _p(mf), _p(mb), _p(out))
+    assert n > 0, n
+    return out[:n]

@@ -19,6 +19,7 @@ namespace {
 
 int g_order = 0;   // 0: an item's sources run before its rows enter / leave, 1: after (see run_pair)
 int g_fast = 0;    // 1: source rows go through process_rows_fast (round 5) wherever the geometry allows it, else the general pass
+int g_inw = 1;     // 0: no item claims Rec::inw (the fast pass then clamps and votes everywhere: results must not change)
 int g_service = 0; // 1: rows enter / leave through the frame's service wave (svc_* of loss_sweep_core.h) instead of every thread's own columns
 constexpr int kEmulNQ = 16;
 
@@ -35,6 +36,8 @@ struct HostEnv {
         if (x) ++*n_slow;
         return x || force_slow;
     }   // every thread is its own "wave"
+    static unsigned long long vote(bool x) { return x ? 1ull : 0ull; }
+    bool any_vote(unsigned long long m) { return any(m != 0ull); }
     void push(bool need, unsigned i, float v) {
         if (need) { idx->push_back(i); val->push_back(v); ++*n_push; }
     }
@@ -86,7 +89,13 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
     std::vector<float> D(2 * (size_t)ring, 0.f);
     std::vector<unsigned> A(2 * (size_t)ring, 0u);
     std::vector<PlanItem> items(n_items);
-    expand_plan(g, raw_items, n_items, items.data());
+    {   // the planner's tap-row bounds: which items may claim "every valid tap is a usable row" (Rec::inw)
+        std::vector<short> lo(2 * g.NG), hi(2 * g.NG);
+        group_bounds(g, ff, mf, lo.data(), hi.data());
+        group_bounds(g, fb, mb, lo.data() + g.NG, hi.data() + g.NG);
+        if (g_inw) expand_plan(g, raw_items, n_items, items.data(), lo.data(), hi.data());
+        else expand_plan(g, raw_items, n_items, items.data());
+    }
     View vw[2];
     for (int f = 0; f < 2; ++f) {
         View& v = vw[f];
@@ -173,7 +182,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
                             if (fast) {      // the kernel's source waves: lanes with a row (the others are the service wave), items with a group
                                 if (lanes[t].on && me.p >= 0) {
                                     load_inputs_all<PXT>(vw[f], lanesf[t], me.p, in);
-                                    process_rows_fast<MODE, REPROJ, PXT>(vw[f], camf[f], env, regs[t], lanes[t], lanesf[t], in, me.p, ot.w, ot.nv);
+                                    process_rows_fast<MODE, REPROJ, PXT>(vw[f], camf[f], env, regs[t], lanes[t], lanesf[t], in, me.p, ot.w, ot.nv, me.inw != 0);
                                 }
                                 continue;
                             }
@@ -192,7 +201,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
                     if (g_service == 2)     // round 5's split: rows ENTER through every thread's own columns, LEAVE through the service wave
                         for (int t = 0; t < kThreads; ++t) {
                             const Rec& me = items[it].f[fr[t]];
-                            regs[t].bad = !stage_rows<MODE, PXT>(vw[fr[t]], lanes[t], me.s_lo, me.s_hi, regs[t].sv) || regs[t].bad;
+                            regs[t].bad = !stage_rows<MODE, PXT, false>(vw[fr[t]], lanes[t], me.s_lo, me.s_hi, regs[t].sv) || regs[t].bad;   // (as the kernel: no pad-column writes)
                         }
                 } else
                 for (int t = 0; t < kThreads; ++t) {
@@ -214,7 +223,7 @@ int run_pair(const Geo& g, const float* depth_p, const float* ff, const float* f
     for (size_t i = 0; i < A.size(); ++i)
         if (A[i] != 0u) { fprintf(stderr, "emul: accumulator not drained at %zu\n", i); return -6; }
     double ar[2] = {0, 0}, ad[2] = {0, 0};
-    for (int t = 0; t < kThreads; ++t) { ar[fr[t]] += (float)regs[t].acc_r; ad[fr[t]] += (float)regs[t].acc_d; if (regs[t].bad) env.degenerate(); }
+    for (int t = 0; t < kThreads; ++t) { ar[fr[t]] += (float)loss_sum_r<PXT>(regs[t]); ad[fr[t]] += (float)loss_sum_d<PXT>(regs[t]); if (regs[t].bad) env.degenerate(); }
     for (int f = 0; f < 2; ++f) { partial[f * 2] = (float)ar[f]; partial[f * 2 + 1] = (float)ad[f]; }
     return 0;
 }
@@ -248,6 +257,21 @@ int sweep_emul_fan_in(const int* geo, const float* ff, const float* fb, const fl
 void sweep_emul_set_order(int order) { g_order = order ? 1 : 0; }
 void sweep_emul_set_service(int on) { g_service = on; }   // 1: rows enter and leave through the service wave; 2: they leave through it
 void sweep_emul_set_fast(int on) { g_fast = on ? 1 : 0; }
+void sweep_emul_set_inw(int on) { g_inw = on ? 1 : 0; }
+// Rec::inw of every item: out[n_items][2]
+int sweep_emul_inw(const int* geo, const float* ff, const float* fb, const float* mf, const float* mb, int* out) {
+    Geo g; memcpy(&g, geo, sizeof(g));
+    std::vector<short> lo(2 * g.NG), hi(2 * g.NG), suf(2 * (g.NG + 1));
+    group_bounds(g, ff, mf, lo.data(), hi.data());
+    group_bounds(g, fb, mb, lo.data() + g.NG, hi.data() + g.NG);
+    std::vector<Item> items(g.max_items);
+    const int n = plan_items(g, lo.data(), hi.data(), suf.data(), items.data());
+    if (n <= 0) return n;
+    std::vector<PlanItem> ex(n);
+    expand_plan(g, items.data(), n, ex.data(), lo.data(), hi.data());
+    for (int i = 0; i < n; ++i) { out[i * 2] = ex[i].f[0].inw; out[i * 2 + 1] = ex[i].f[1].inw; }
+    return n;
+}
 
 // geometry as the kernel would choose it: out[0..11] = the Geo fields; ring_rows > 0 overrides R (to force tiny rings)
 int sweep_emul_geo(int H, int W, int pxt, int ring_rows, int* out) {

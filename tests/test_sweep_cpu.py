@@ -287,3 +287,29 @@ def test_mirrored_slot_survives_forced_general_pass():
     b = E.loss(batch, 1.0, 0.1, pxt=2, fast=True, force_slow=True, service=2)         # (the emulation fails on a non-drained accumulator)
     np.testing.assert_array_equal(a["grad_depth"], b["grad_depth"])
     np.testing.assert_array_equal(a["total"], b["total"])
+
+
+@pytest.mark.parametrize("gen,kw", [("scene", {}), ("pair", {"noise_px": 40.0})], ids=["scene", "wild"])
+def test_plan_flag_all_taps_inside_changes_nothing(gen, kw):
+    """Rec::inw (end of round 5): the planner marks the items whose valid sources all sample usable ring rows; the fast pass then skips
+    the window clamp and the slow-path vote.  With the flag withheld the clamp is the identity for those lanes and mask-0 lanes contribute
+    exact zeros from whatever resident row they read: gradients and losses must be BIT-identical with and without it.  Scene flows claim
+    the flag on (almost) every item, wild flows on few -- and the items that do not claim it still take the clamped / voted route."""
+    from consistent_depth_amd import synthetic
+    H, W = 384, 224
+    batch = (synthetic.make_scene_batch if gen == "scene" else synthetic.make_pair_batch)(2, H, W, seed=21, **kw)
+    on = E.loss(batch, 1.0, 0.1, pxt=2, fast=True, service=2)
+    off = E.loss(batch, 1.0, 0.1, pxt=2, fast=True, service=2, inw=False)
+    for k in ("grad_depth", "total", "reprojection", "disparity"):
+        np.testing.assert_array_equal(on[k], off[k])
+    assert on["overflow_entries"] == off["overflow_entries"] and on["slow_lanes"] == off["slow_lanes"]
+    g = E.geo(H, W, 2)
+    flags = E.inw_flags(g, batch["flows"][0][0], batch["flows"][1][0], batch["masks"][0][0], batch["masks"][1][0])
+    items, lo, hi = E.plan(g, batch["flows"][0][0], batch["flows"][1][0], batch["masks"][0][0], batch["masks"][1][0])
+    with_group = items[:, :2] >= 0
+    assert not flags[~with_group].any()                    # only items with a group can claim it
+    share = flags[with_group].mean()
+    if gen == "scene":
+        assert share > 0.9, share
+    else:
+        assert share < 0.9, share

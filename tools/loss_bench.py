@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 = default dispatch, 4 = row sweep, 3 = evaluate-once + slab reduce")
     ap.add_argument("--pxt", type=int, default=0, help="row sweep: pixels per thread (0 = default rule)")
     ap.add_argument("--noise-px", type=float, default=0.25)
+    ap.add_argument("--warm", type=int, default=3, help="untimed warm-up calls per batch size")
+    ap.add_argument("--brief", action="store_true", help="one short line per batch size")
     ap.add_argument("--inconsistent", action="store_true", help="adversarial generator: unrelated depth per frame")
     args = ap.parse_args()
     from consistent_depth_amd import _native, synthetic
@@ -53,7 +55,7 @@ def main():
         msum, twin = CL.mask_sums(masks[0], masks[1]), CL.tile_windows(flows, masks)  # dataset constants, cached
         call = lambda: CL.consistency_loss(x, flows, masks, intr, extr, 1.0, 0.1, mask_sums=msum, depth_mode=args.mode,  # noqa: E731
                                            tile_windows=None if args.fwd_only else twin)
-        for _ in range(3):
+        for _ in range(args.warm):
             call()
         torch.cuda.synchronize()
         assert lib.cd_profile_begin(args.iters) == 0
@@ -70,8 +72,12 @@ def main():
         res.append({"variant": args.variant, "pxt": args.pxt, "pairs": B, "avg_ms": float(ms.mean()), "min_ms": float(ms.min()),
                     "GBps_avg": float(per_pair * B / (ms.mean() * 1e-3) / 1e9), "GBps_best": float(gbs.max()),
                     "frac_of_8TBps": float(per_pair * B / (ms.mean() * 1e-3) / 1e9 / 8000.0)})
-        res[-1]["ms_sorted"] = [round(float(x), 4) for x in np.sort(ms)]
-        print(json.dumps(res[-1]), flush=True)
+        res[-1]["ms_series"] = [round(float(x), 4) for x in ms]      # in call order (a clock ramp shows here)
+        if args.brief:
+            print(f"{B} avg {ms.mean():.4f} frac {res[-1]['frac_of_8TBps']:.4f} min {ms.min():.4f} med {np.median(ms):.4f} max {ms.max():.4f} "
+                  f"first5 {np.round(ms[:5], 4).tolist()} last5 {np.round(ms[-5:], 4).tolist()}", flush=True)
+        else:
+            print(json.dumps(res[-1]), flush=True)
         del depth, x, flows, masks
         torch.cuda.empty_cache()
 
