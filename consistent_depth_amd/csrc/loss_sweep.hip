@@ -387,7 +387,10 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     // The frame's SERVICE wave (loss_sweep_core.h: the eighth wave of each frame has no source pixels at W = 224 and takes over the
     // rows that enter and leave the ring; compile-time geometry only -- the run-time-geometry build keeps every thread on its columns).
     constexpr bool SVC = SG == 1 && PXT == kStaticPXT;
-    constexpr bool SRC_STAGES = SVC;       // the sources stage their own columns, the service wave only flushes (see below)
+#ifndef CD_SWEEP_SRC_STAGES
+#define CD_SWEEP_SRC_STAGES 1
+#endif
+    constexpr bool SRC_STAGES = SVC && CD_SWEEP_SRC_STAGES != 0;       // the sources stage their own columns, the service wave only flushes (see below)
     if (SVC && (int)threadIdx.x - f * kFrameThreads >= g.RP * g.CG) {      // wave-uniform
         constexpr int NQ = kStaticSvcQuads;     // kStagePasses * RP rows of W / 4 quads (launch_sweep_inst checks it against the geometry)
         const int sl = (int)threadIdx.x - f * kFrameThreads - g.RP * g.CG;
@@ -403,10 +406,10 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         // pairs, sources alone 0.181 ms, service waves alone 0.209 ms -- a single wave issues an instruction every ~4-5 cycles and
         // each of its quads is a latency chain (load -> exp -> LDS write; LDS read -> convert -> store).
         for (int it = 0; it < n_items; ++it) {
-            if (!SRC_STAGES) r.bad = !svc_stage<MODE, NQ>(v, sl, me.s_lo, me.s_hi, q) || r.bad;
+            if (!SRC_STAGES) r.bad = !svc_stage<MODE, NQ>(v, slc, sl, me.s_lo, me.s_hi, q) || r.bad;
             const bool more = it + 1 < n_items;
             const Rec nx = items[more ? it + 1 : it].f[f];
-            if (!SRC_STAGES) svc_load<NQ>(v, sl, nx.s_lo, more ? nx.s_hi : nx.s_lo, q);
+            if (!SRC_STAGES) svc_load<NQ>(v, slc, sl, nx.s_lo, more ? nx.s_hi : nx.s_lo, q);
             svc_flush<NQ>(v, slc, sl, me.fl_lo, me.fl_hi);
             __syncthreads();
             me = nx;

@@ -577,62 +577,8 @@ CD_HD bool svc_geometry_ok(const Geo& g) {     // a whole idle wave per frame, r
 }
 CD_HD int svc_quads(const Geo& g) { return (g.SMAX * (g.W / 4) + kSvcLanes - 1) / kSvcLanes; }
 
-// raw depth of the rows [s_lo, s_hi) that enter the ring (cf. load_stage)
-template <int NQ> CD_HD void svc_load(const View& v, int lane, int s_lo, int s_hi, SvcRegs<NQ>& q) {
-    const int QW = v.W >> 2;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int qi = lane + kSvcLanes * i, rr = qi / QW, c4 = qi - rr * QW, row = s_lo + rr;
-        const bool ok = row < s_hi && row < v.H;
-        const VecF<4> a = ldgv<4>(v.vj, ok ? ((unsigned)row * (unsigned)v.W + 4u * (unsigned)c4) << 2 : 0u);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q.v[i][e] = ok ? a.v[e] : 0.f;
-    }
-}
-
-// the rows enter the ring (cf. stage_rows; returns false if a staged depth is not a positive finite number)
-template <int MODE, int NQ> CD_HD bool svc_stage(const View& v, int lane, int s_lo, int s_hi, const SvcRegs<NQ>& q) {
-    const int QW = v.W >> 2;
-    bool good = true;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int qi = lane + kSvcLanes * i, rr = qi / QW, c4 = qi - rr * QW, row = s_lo + rr;
-        if (row < s_hi) {
-            const unsigned base = (unsigned)((row & (v.R - 1)) * v.RW) + 4u * (unsigned)c4;
-            const bool img = row < v.H;
-            VecF<2> d0, d1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = img ? to_depth<MODE>(q.v[i][e]) : 1.f;
-                good = good && (d > 0.f && d < INFINITY);
-                if (e < 2) d0.v[e] = d; else d1.v[e - 2] = d;
-            }
-            *reinterpret_cast<VecF<2>*>(&v.Dj[base]) = d0;
-            *reinterpret_cast<VecF<2>*>(&v.Dj[base + 2]) = d1;
-            if ((row & (v.R - 1)) == 0) {              // slot R mirrors slot 0
-                const unsigned mb = (unsigned)(v.R * v.RW) + 4u * (unsigned)c4;
-                *reinterpret_cast<VecF<2>*>(&v.Dj[mb]) = d0;
-                *reinterpret_cast<VecF<2>*>(&v.Dj[mb + 2]) = d1;
-            }
-        }
-    }
-    const int row = s_lo + lane;                   // the pad column(s): one row per lane
-    if (row < s_hi)
-        for (int c = v.W; c < v.RW; ++c) {
-            v.Dj[(unsigned)((row & (v.R - 1)) * v.RW + c)] = 1.f;
-            if ((row & (v.R - 1)) == 0) v.Dj[(unsigned)(v.R * v.RW + c)] = 1.f;
-        }
-    return good;
-}
-
-// rows [lo, hi) leave the ring (cf. flush_rows).  Round 5: ONE wave per frame does this for everybody, so it is bound by how fast a
-// single wave issues instructions and by the latency chain LDS read -> convert -> store.  Measured at the end of round 5 (256 pairs):
-// with the sources doing nothing but their loads the call still took 0.194 of 0.208 ms -- this wave WAS the other critical path.
-// Hence: everything that depends only on the lane (a quad's row inside the run, its column, its offset in the gradient rows) is
-// computed once per kernel (SvcLane); the quads of an item are cut off by a WAVE-UNIFORM bound (an ordinary item moves 4 of the
-// SMAX = 8 rows: 4 of 7 quads -- the old per-lane test ran all 7 with an empty exec mask); whether a row of slot 0 is among the rows
-// (its mirror slot has to be folded in) is scalar arithmetic on [lo, hi); all LDS reads of the call are issued before the first use.
-// The pad column(s) of the accumulators are not touched: a tap in a pad column carries weight 0, its fixed-point addend is 0.
+// Everything of a quad that depends only on the lane (its row inside a run of rows, its first column, its byte offset inside the run)
+// is computed once per kernel:
 template <int NQ> struct SvcLane { unsigned rq[NQ], cw[NQ], go[NQ]; };   // quad lane + 64 i of a run of rows: row, first column (words), byte offset
 template <int NQ> CD_HD SvcLane<NQ> make_svc_lane(const View& v, int lane) {
     SvcLane<NQ> s;
@@ -643,6 +589,73 @@ template <int NQ> CD_HD SvcLane<NQ> make_svc_lane(const View& v, int lane) {
     }
     return s;
 }
+// raw depth of the rows [s_lo, s_hi) that enter the ring (cf. load_stage): requested one item ahead.  The quads of a run are cut off by a
+// WAVE-UNIFORM bound (an ordinary item moves 4 of the SMAX = 8 rows); a lane beyond the run's last quad reads that last quad (an
+// unconditional load on a clamped offset: a load under a per-lane condition is waited for at once).  Row H (the pad row) has no data.
+template <int NQ> CD_HD void svc_load(const View& v, const SvcLane<NQ>& sl, int lane, int s_lo, int s_hi, SvcRegs<NQ>& q) {
+    const int nq = ((s_hi < v.H ? s_hi : v.H) - s_lo) * (v.W >> 2);
+    const float* srow = v.vj + (size_t)s_lo * (size_t)v.W;      // (wave-uniform)
+    (void)lane;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        if (i * kSvcLanes >= nq) break;                          // wave-uniform
+        const VecF<4> a = ldgv<4>(srow, umin(sl.go[i], 16u * (unsigned)(nq - 1)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.v[i][e] = a.v[e];
+    }
+}
+
+// the rows enter the ring (cf. stage_rows; returns false if a staged depth is not a positive finite number).  The pad column(s) are
+// not written: their value (1) is constant once the prologue has written every slot.
+template <int MODE, int NQ> CD_HD bool svc_stage(const View& v, const SvcLane<NQ>& sl, int lane, int s_lo, int s_hi, const SvcRegs<NQ>& q) {
+    const int nq = (s_hi - s_lo) * (v.W >> 2);
+    const bool mirror = ((-s_lo) & (v.R - 1)) < s_hi - s_lo;      // wave-uniform: a row of slot 0 is among [s_lo, s_hi)
+    bool good = true;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        if (i * kSvcLanes >= nq) break;                           // wave-uniform
+        if (lane + kSvcLanes * i < nq) {
+            const unsigned base = mad24(((unsigned)s_lo + sl.rq[i]) & (unsigned)(v.R - 1), (unsigned)v.RW, sl.cw[i]);
+            float d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = to_depth<MODE>(q.v[i][e]);
+            if (s_hi > v.H) {                                     // wave-uniform, the last item(s): row H is the pad row
+                CD_KEEP_BRANCH();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = (unsigned)s_lo + sl.rq[i] < (unsigned)v.H ? d[e] : 1.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) good = good && (d[e] > 0.f && d[e] < INFINITY);
+            VecF<2> d0, d1;
+            d0.v[0] = d[0]; d0.v[1] = d[1]; d1.v[0] = d[2]; d1.v[1] = d[3];
+            *reinterpret_cast<VecF<2>*>(&v.Dj[base]) = d0;
+            *reinterpret_cast<VecF<2>*>(&v.Dj[base + 2]) = d1;
+            if (mirror) {
+                CD_KEEP_BRANCH();
+                if (base < (unsigned)v.RW) {                      // slot R mirrors slot 0
+                    *reinterpret_cast<VecF<2>*>(&v.Dj[(unsigned)(v.R * v.RW) + base]) = d0;
+                    *reinterpret_cast<VecF<2>*>(&v.Dj[(unsigned)(v.R * v.RW) + base + 2]) = d1;
+                }
+            }
+        }
+    }
+    return good;
+}
+template <int NQ> CD_HD void svc_load(const View& v, int lane, int s_lo, int s_hi, SvcRegs<NQ>& q) {      // (the host emulation: no per-kernel state)
+    svc_load<NQ>(v, make_svc_lane<NQ>(v, lane), lane, s_lo, s_hi, q);
+}
+template <int MODE, int NQ> CD_HD bool svc_stage(const View& v, int lane, int s_lo, int s_hi, const SvcRegs<NQ>& q) {
+    return svc_stage<MODE, NQ>(v, make_svc_lane<NQ>(v, lane), lane, s_lo, s_hi, q);
+}
+
+// rows [lo, hi) leave the ring (cf. flush_rows).  Round 5: ONE wave per frame does this for everybody, so it is bound by how fast a
+// single wave issues instructions and by the latency chain LDS read -> convert -> store.  Measured at the end of round 5 (256 pairs):
+// with the sources doing nothing but their loads the call still took 0.194 of 0.208 ms -- this wave WAS the other critical path.
+// Hence: everything that depends only on the lane (a quad's row inside the run, its column, its offset in the gradient rows) is
+// computed once per kernel (SvcLane); the quads of an item are cut off by a WAVE-UNIFORM bound (an ordinary item moves 4 of the
+// SMAX = 8 rows: 4 of 7 quads -- the old per-lane test ran all 7 with an empty exec mask); whether a row of slot 0 is among the rows
+// (its mirror slot has to be folded in) is scalar arithmetic on [lo, hi); all LDS reads of the call are issued before the first use.
+// The pad column(s) of the accumulators are not touched: a tap in a pad column carries weight 0, its fixed-point addend is 0.
 template <int NQ> CD_HD void svc_flush(const View& v, const SvcLane<NQ>& sl, int lane, int lo, int hi) {
     const int nq = (hi - lo) * (v.W >> 2);
     const float unit = v.cj.unit_s;
