@@ -7,6 +7,18 @@
 
 namespace cd {
 
+// two x-adjacent taps = ONE 8-byte load at a 4-byte-aligned address (see the mask kernel below)
+struct __attribute__((packed, aligned(4))) FloatPair { float a, b; };
+// the four taps of the geometry.sample mapping (xb = min(xa + 1, W - 1), yb = min(ya + 1, H - 1)) of one channel, weighted: the same
+// four products in the same order as four single loads -- the pair starts at min(xa, W - 2); at xa = W - 1 both taps of a row are its
+// second float (xb = xa there)
+__device__ __forceinline__ float sample4(const float* __restrict__ src, int ya, int yb, int xa, int W, float w00, float w01, float w10, float w11) {
+    const int xp = xa < W - 2 ? xa : W - 2;
+    const bool hi = xa > W - 2;
+    const FloatPair n = *reinterpret_cast<const FloatPair*>(src + ya * W + xp), s = *reinterpret_cast<const FloatPair*>(src + yb * W + xp);
+    return (hi ? n.b : n.a) * w00 + n.b * w01 + (hi ? s.b : s.a) * w10 + s.b * w11;
+}
+
 __global__ __launch_bounds__(kBlock) void sample_kernel(const float* __restrict__ data, const float* __restrict__ uv,
                                                         int C, int H, int W, float* __restrict__ out) {
     const int HW = H * W;
@@ -19,12 +31,11 @@ __global__ __launch_bounds__(kBlock) void sample_kernel(const float* __restrict_
     const float iy = fminf(fmaxf(v * sy - 0.5f, 0.f), (float)(H - 1));
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const float tx = ix - fx0, ty = iy - fy0;
-    const int xa = (int)fx0, ya = (int)fy0, xb = min(xa + 1, W - 1), yb = min(ya + 1, H - 1);
+    const int xa = (int)fx0, ya = (int)fy0, yb = min(ya + 1, H - 1);
     const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
     for (int c = 0; c < C; ++c) {
         const float* src = data + ((size_t)b * C + c) * HW;
-        out[((size_t)b * C + c) * HW + p] =
-            src[ya * W + xa] * w00 + src[ya * W + xb] * w01 + src[yb * W + xa] * w10 + src[yb * W + xb] * w11;
+        out[((size_t)b * C + c) * HW + p] = sample4(src, ya, yb, xa, W, w00, w01, w10, w11);
     }
 }
 
@@ -60,17 +71,22 @@ __device__ __forceinline__ TapsB taps_border_grid(double idx_x, double idx_y, in
 
 // The four tap offsets of a pixel, shared by every channel sampled at that position.  Taps outside the image are CLAMPED to a
 // valid address (and their product replaced by an exact 0 afterwards): every gather of a pixel is an unconditional load, so the
-// 20 loads (2 flow + 3 colour channels x 4 taps) are all in flight before the first wait.  Round 1's version loaded the optional
+// 10 pair loads (2 flow + 3 colour channels x 2 rows: round 5, below) are all in flight before the first wait.  Round 1's version loaded the optional
 // taps under their conditions -- a load under a divergent branch is followed by s_waitcnt vmcnt(0): twenty serialised round trips
 // per pixel, 8 % of the HBM rate.
-struct TapIdx { int nw, ne, sw, se; };
+// Round 5: the two taps of a row are adjacent floats -- ONE 8-byte load at a 4-byte-aligned address (gfx950 global loads take it:
+// hipcc emits global_load_dwordx2 for an align-4 pair) instead of two gathers: 10 gather instructions per pixel instead of 20 on a
+// kernel bound by the texture-address path.  The pair starts at min(x0, W - 2): for x0 = W - 1 (only the clamped right border) the
+// west tap is the pair's SECOND float and the east tap carries an exact 0.
+struct TapIdx { int n, s; bool hi; };       // offsets of the two pairs; hi: x0 = W - 1
 __device__ __forceinline__ TapIdx tap_offsets(const TapsB& t, int W) {
-    const int xe = t.in_x1 ? t.x1 : t.x0, ys = t.in_y1 ? t.y1 : t.y0;
-    return TapIdx{t.y0 * W + t.x0, t.y0 * W + xe, ys * W + t.x0, ys * W + xe};
+    const int xp = t.x0 < W - 2 ? t.x0 : W - 2, ys = t.in_y1 ? t.y1 : t.y0;
+    return TapIdx{t.y0 * W + xp, ys * W + xp, t.x0 > W - 2};
 }
 struct TapVals { float nw, ne, sw, se; };
 __device__ __forceinline__ TapVals tap_load(const float* __restrict__ src, const TapIdx& i) {
-    return TapVals{src[i.nw], src[i.ne], src[i.sw], src[i.se]};
+    const FloatPair n = *reinterpret_cast<const FloatPair*>(src + i.n), s = *reinterpret_cast<const FloatPair*>(src + i.s);
+    return TapVals{i.hi ? n.b : n.a, n.b, i.hi ? s.b : s.a, s.b};
 }
 __device__ __forceinline__ float tap_sum(const TapVals& v, const TapsB& t) {
     // ((nw + ne) + sw) + se, each term rounded, taps outside the image contribute nothing
@@ -169,12 +185,11 @@ __global__ __launch_bounds__(kBlock) void warp_image_kernel(const float* __restr
         const float iy = fminf(fmaxf(v * sy - 0.5f, 0.f), (float)(H - 1));
         const float fx0 = floorf(ix), fy0 = floorf(iy);
         const float tx = ix - fx0, ty = iy - fy0;
-        const int xa = (int)fx0, ya = (int)fy0, xb = min(xa + 1, W - 1), yb = min(ya + 1, H - 1);
+        const int xa = (int)fx0, ya = (int)fy0, yb = min(ya + 1, H - 1);
         const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
         for (int ch = 0; ch < C; ++ch) {
             const float* src = images + ((size_t)t * C + ch) * HW;
-            warped[((size_t)i * C + ch) * HW + p] =
-                src[ya * W + xa] * w00 + src[ya * W + xb] * w01 + src[yb * W + xa] * w10 + src[yb * W + xb] * w11;
+            warped[((size_t)i * C + ch) * HW + p] = sample4(src, ya, yb, xa, W, w00, w01, w10, w11);
         }
     }
 }
