@@ -195,32 +195,44 @@ static bool static_geometry_holds(const Geo& c) {
 struct SweepOut { float* reproj; float* disp; float* total; int* done; };     // per-pair losses [B], batch mean [1], the launch's finished-pairs counter
 
 // fbar (batch mean of (fx + fy) / 2 of the ref frames, consistency_loss.py:178), the pair's PairCam[2] (prep_pair) and the accumulator
-// units (units_from_samples) -> st.cam; scratch: 24 floats of LDS.  All kThreads threads call it.
+// units (units_from_samples) -> st.cam; scratch: 24 floats of LDS.  All kThreads threads call both parts.
+// Part 1, at the very top of the kernel -- BEFORE the first window's depth rows are requested: every global read whose address is
+// known at entry (the unit samples' own pixels, the batch's focal lengths, the pair's intrinsics / extrinsics / mask sums).  Measured
+// (tools/exp/sweep_times.py): requested behind the window's 57 KB, the samples' two dependent latencies (flow -> tap positions ->
+// sampled depths; `vmcnt` retires in order) ended 10 us after kernel entry.
+struct PairReq { UnitLoads ul; float f0[2], f1[2], pin; int sx, sy; };
+__device__ __forceinline__ PairReq pair_constants_request(const PairPrep& pp, const float* __restrict__ depth_p, const float* __restrict__ ff,
+                                                          const float* __restrict__ fb, const float* __restrict__ mf,
+                                                          const float* __restrict__ mb, int b, int B, int H, int W) {
+    constexpr int NS = kUnitGrid * kUnitGrid;
+    const int t = threadIdx.x, HW = H * W;
+    PairReq q{};
+    if (t < 2 * NS) {
+        const int j = t / NS;
+        unit_sample_xy(H, W, t % NS, &q.sx, &q.sy);
+        unit_sample_load_own(q.ul, depth_p + (j ? HW : 0), j ? fb : ff, j ? mb : mf, H, W, q.sx, q.sy);
+    }
+    if (t < kBlock && t < B)
+        for (int k = 0; k < 2; ++k) { q.f0[k] = pp.intr[(t * 2 + k) * 4 + 0]; q.f1[k] = pp.intr[(t * 2 + k) * 4 + 1]; }
+    if (t >= 2 * NS && t < 2 * NS + 34) {      // intr [8], extr [24], mask sums [2] of the pair
+        const int i = t - 2 * NS;
+        q.pin = i < 8 ? pp.intr[b * 8 + i] : (i < 32 ? pp.extr[b * 24 + (i - 8)] : pp.mask_sum[b * 2 + (i - 32)]);
+    }
+    return q;
+}
+// Part 2: the sampled depths (their positions need no camera: requested first), then the arithmetic in its old order -- same numbers.
 template <int MODE>
-__device__ __forceinline__ void pair_constants(WgState& st, float* scratch, const PairPrep& pp, const float* __restrict__ depth_p,
-                                               const float* __restrict__ ff, const float* __restrict__ fb, const float* __restrict__ mf,
-                                               const float* __restrict__ mb, int b, int B, int H, int W) {
+__device__ __forceinline__ void pair_constants(WgState& st, float* scratch, const PairPrep& pp, PairReq& q, const float* __restrict__ depth_p,
+                                               int B, int H, int W) {
     constexpr int NS = kUnitGrid * kUnitGrid;
     static_assert(NS == kBlock, "fbar is reduced like prep_kernel does: 256 threads, 4 wave sums added in order");
     const int t = threadIdx.x, lane = t & (kWave - 1), wid = t / kWave;
-    // Everything this function READS from global memory is requested up front: the unit samples' inputs (two dependent latencies: flow ->
-    // tap positions -> sampled depths; no camera needed), the batch's focal lengths, the pair's intrinsics / extrinsics / mask sums (into
-    // LDS for thread 0).  The arithmetic then follows in its old order -- same numbers -- on data that is already there.
     const int HW = H * W;
-    float f0[2] = {0.f, 0.f}, f1[2] = {0.f, 0.f};        // the first round of the focal-length sums (requested before the samples' chain)
-    if (t < kBlock && t < B)
-        for (int k = 0; k < 2; ++k) { f0[k] = pp.intr[(t * 2 + k) * 4 + 0]; f1[k] = pp.intr[(t * 2 + k) * 4 + 1]; }
-    int sx = 0, sy = 0;
-    UnitLoads ul{};
-    if (t < 2 * NS) {
-        const int j = t / NS;
-        unit_sample_xy(H, W, t % NS, &sx, &sy);
-        ul = unit_sample_load(depth_p + (j ? HW : 0), depth_p + (j ? 0 : HW), j ? fb : ff, j ? mb : mf, H, W, sx, sy);
-    }
-    if (t >= 2 * NS && t < 2 * NS + 34) {      // intr [8], extr [24], mask sums [2] of the pair
-        const int i = t - 2 * NS;
-        st.prep_in[i] = i < 8 ? pp.intr[b * 8 + i] : (i < 32 ? pp.extr[b * 24 + (i - 8)] : pp.mask_sum[b * 2 + (i - 32)]);
-    }
+    if (t < 2 * NS) unit_sample_load_taps(q.ul, depth_p + (t / NS ? 0 : HW), H, W, q.sx, q.sy);
+    if (t >= 2 * NS && t < 2 * NS + 34) st.prep_in[t - 2 * NS] = q.pin;
+    const float* f0 = q.f0; const float* f1 = q.f1;
+    const UnitLoads& ul = q.ul;
+    const int sx = q.sx, sy = q.sy;
     float acc[2] = {0.f, 0.f};
     if (t < kBlock)
         for (int k = 0; k < 2; ++k) {
@@ -316,8 +328,10 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     v.Dj = D0 + (f ? ring : 0); v.Dk = D0 + (f ? 0 : ring);
     WgState& st = *reinterpret_cast<WgState*>(smem + 4 * ring);
     if (threadIdx.x == 0) { st.ovf_n = 0u; st.redo = 0; st.is_last = 0; }
-    // ---- the accumulators are cleared and the depth rows of the first window requested BEFORE the pair's constants are computed
-    // (neither needs them): the loads' latency and the constants' latency chains (sample -> taps, ~10 us) overlap
+    // ---- the pair constants' reads first (PairReq), then the accumulators are cleared and the depth rows of the first window requested
+    // -- all of it BEFORE anything is computed: the latencies overlap
+    PairReq req = pair_constants_request(pp, dpair, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW, mf + (size_t)b * HW, mb + (size_t)b * HW,
+                                         b, B, g.H, g.W);
     constexpr int kInitBatches = 4;
     v.cj = Cam{};
     const Lane<PXT> l0 = make_lane<PXT>(v, (int)threadIdx.x - f * kFrameThreads);      // (only its row / column fields are used here)
@@ -330,9 +344,17 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         const int lo = j * kStagePasses * g.RP;
         load_stage_nosel<PXT>(v, l0, lo < init_hi ? lo : 0, init_batched ? min(lo + kStagePasses * g.RP, init_hi) : 0, sv0[j]);
     }
+    // ... and the flow / mask of the first item's source rows (fast pass; consumed at the top of the loop, ~15 us from here)
+    const PlanHeader* ph = reinterpret_cast<const PlanHeader*>(blob + (size_t)b * sh.stride + sh.plan_off);
+    const PlanItem* __restrict__ items = reinterpret_cast<const PlanItem*>(ph + 1);
+    Inputs<PXT> in0;
+    {
+        const int p0 = ph->n_items > 0 ? uni(items[0].f[f].p) : 0;
+        // (lanes without source pixels -- the service wave -- read the group's first pixels: in bounds, never used)
+        load_inputs_goff<PXT>(v, l0.on ? (l0.rrW + l0.x0) << 2 : 0u, min(max(p0, 0), g.H - 1), in0);
+    }
     // ---- the pair's constants
-    pair_constants<MODE>(st, st.wave_part, pp, dpair, ff + (size_t)b * 2 * HW, fb + (size_t)b * 2 * HW,
-                         mf + (size_t)b * HW, mb + (size_t)b * HW, b, B, g.H, g.W);
+    pair_constants<MODE>(st, st.wave_part, pp, req, dpair, B, g.H, g.W);
     if (threadIdx.x < 2 * (int)(sizeof(PairCam) / sizeof(float)))      // (kept in the workspace: debugging, the tile kernels' format)
         reinterpret_cast<float*>(cams + b * 2)[threadIdx.x] = reinterpret_cast<const float*>(st.cam)[threadIdx.x];
     {   // the direction's constants, once, into scalar registers
@@ -345,8 +367,6 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     }
     v.gbj = (unsigned)b * 2u * (unsigned)HW + (f ? (unsigned)HW : 0u);
     v.gbk = (unsigned)b * 2u * (unsigned)HW + (f ? 0u : (unsigned)HW);
-    const PlanHeader* ph = reinterpret_cast<const PlanHeader*>(blob + (size_t)b * sh.stride + sh.plan_off);
-    const PlanItem* __restrict__ items = reinterpret_cast<const PlanItem*>(ph + 1);
     const int n_items = ph->n_items;
     v.limit = uni(ph->limit);
     // no plan (the planner's item backstop, a fan-in beyond the accumulators' range), or one made for another geometry
@@ -429,7 +449,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         float* cff = reinterpret_cast<float*>(&cf);
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(CamF) / sizeof(float)); ++i) cff[i] = uni(cff[i]);
-        load_inputs_all<PXT>(v, lf, me.p > 0 ? me.p : 0, inA);
+        inA = in0;       // (requested at the top of the kernel)
     } else load_inputs<PXT>(v, l, me.p, 0, inA);
     __syncthreads();
     if (!two) {

@@ -272,13 +272,20 @@ struct UnitSample { float direct, scatter; int valid; };
 // issues the reads of all samples before the pair's constants exist (their two dependent memory latencies then overlap the
 // constants' own chain); the host emulation calls them back to back.  vj / vk: the raw depth planes of its frame / the other frame.
 struct UnitLoads { float m, fx, fy, vj, v00, v01, v10, v11; Taps t; };
-CD_HD UnitLoads unit_sample_load(const float* vj, const float* vk, const float* fl, const float* mk, int H, int W, int x, int y) {
-    UnitLoads l;
+// (the reads in their two dependent steps: the sample's own pixel, then -- from its flow -- the four sampled depths)
+CD_HD void unit_sample_load_own(UnitLoads& l, const float* vj, const float* fl, const float* mk, int H, int W, int x, int y) {
     const int HW = H * W, p = y * W + x;
     l.m = mk[p]; l.fx = fl[p]; l.fy = fl[HW + p]; l.vj = vj[p];
+}
+CD_HD void unit_sample_load_taps(UnitLoads& l, const float* vk, int H, int W, int x, int y) {
     l.t = tap_coords((float)x, (float)y, l.fx, l.fy, (float)W / (float)(W - 1), (float)H / (float)(H - 1), W, H);   // (= PairCam::sx, sy)
     l.v00 = vk[l.t.ya * W + l.t.xa]; l.v01 = vk[l.t.ya * W + l.t.xb];
     l.v10 = vk[l.t.yb * W + l.t.xa]; l.v11 = vk[l.t.yb * W + l.t.xb];
+}
+CD_HD UnitLoads unit_sample_load(const float* vj, const float* vk, const float* fl, const float* mk, int H, int W, int x, int y) {
+    UnitLoads l;
+    unit_sample_load_own(l, vj, fl, mk, H, W, x, y);
+    unit_sample_load_taps(l, vk, H, W, x, y);
     return l;
 }
 template <int MODE>
@@ -917,6 +924,12 @@ CD_HD bool fast_geometry_ok(const Geo& g) { return g.ok && g.PXT == 2 && g.G == 
 
 // flow / mask of the source rows [p, p + RP): unconditional loads (p >= 0; the caller clamps) -- nothing to select afterwards, so the
 // compiler has no reason to wait for them before their first use one item later
+template <int PXT> CD_HD void load_inputs_goff(const View& v, unsigned goff, int p, Inputs<PXT>& in) {      // (goff = LaneF::goff)
+    const unsigned off = (unsigned)p * ((unsigned)v.W << 2) + goff;
+    const VecF<PXT> a = ldgv<PXT>(v.flj, off), b = ldgv<PXT>(v.flj + v.HW, off), mm = ldgv<PXT>(v.mkj, off);
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) { in.fx[i] = a.v[i]; in.fy[i] = b.v[i]; in.m[i] = mm.v[i]; }
+}
 template <int PXT> CD_HD void load_inputs_all(const View& v, const LaneF<PXT>& lf, int p, Inputs<PXT>& in) {
     const unsigned off = (unsigned)p * ((unsigned)v.W << 2) + lf.goff;
     const VecF<PXT> a = ldgv<PXT>(v.flj, off), b = ldgv<PXT>(v.flj + v.HW, off), mm = ldgv<PXT>(v.mkj, off);
