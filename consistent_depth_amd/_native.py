@@ -13,7 +13,7 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # CD_AMD_LIB: load another build of the SAME library (A/B measurements of kernel variants, tools/exp/build_variants.sh); not a fallback
 SO_PATH = os.environ.get("CD_AMD_LIB") or os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 
 _lib = None
@@ -86,6 +86,8 @@ SIGNATURES = {
     "cd_avgpool2_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_upsample2x_add_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_upsample2x_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_upsample2x_halfpixel_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_upsample2x_halfpixel_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_add_slice": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_channel_sum": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "cd_adam_step_flat": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),

@@ -299,6 +299,64 @@ __global__ __launch_bounds__(kBlock) void upsample2x_bwd_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------- bilinear x2, half-pixel centres (align_corners=False)
+// F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) -- the last up-sampling of MiDaS' output head
+// (midas_net.py::_Interpolate; upstream intel-isl/MiDaS `Interpolate(scale_factor=2, mode="bilinear")`).  Source index of output o:
+// max(0.5 * (o + 0.5) - 0.5, 0): even o = 2i reads (i - 1, i) with weights (0.25, 0.75), odd o = 2i + 1 reads (i, i + 1) with
+// (0.75, 0.25), the border taps clamped (weight 1 on the edge pixel).  All weights are exact in fp32.
+__device__ __forceinline__ void halfpixel_taps(int o, int n_in, int* i0, int* i1, float* t) {
+    const float s = fmaxf(0.5f * ((float)o + 0.5f) - 0.5f, 0.f);
+    *i0 = min((int)s, n_in - 1);
+    *i1 = min(*i0 + 1, n_in - 1);
+    *t = s - (float)*i0;
+}
+__global__ __launch_bounds__(kBlock) void upsample2x_halfpixel_fwd_kernel(const float* __restrict__ lo, int lo_ctot, int lo_coff,
+                                                                          float* __restrict__ out, int o_ctot, int o_coff, int h, int w) {
+    const int c = blockIdx.y, n = blockIdx.z, H = 2 * h, W = 2 * w;
+    const float* l = lo + ((size_t)n * lo_ctot + lo_coff + c) * h * w;
+    float* o = out + ((size_t)n * o_ctot + o_coff + c) * H * W;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < H * W; i += gridDim.x * kBlock) {
+        const int y = i / W, x = i - y * W;
+        int y0, y1, x0, x1;
+        float ty, tx;
+        halfpixel_taps(y, h, &y0, &y1, &ty);
+        halfpixel_taps(x, w, &x0, &x1, &tx);
+        o[i] = (1.f - ty) * ((1.f - tx) * l[y0 * w + x0] + tx * l[y0 * w + x1]) + ty * ((1.f - tx) * l[y1 * w + x0] + tx * l[y1 * w + x1]);
+    }
+}
+// the adjoint as a GATHER (no atomics): input pixel i receives from the outputs 2i - 1 .. 2i + 2 of its axis -- weight of output o on
+// input i = (i0(o) == i ? 1 - t : 0) + (i1(o) == i ? t : 0), the forward's own arithmetic (borders included)
+__global__ __launch_bounds__(kBlock) void upsample2x_halfpixel_bwd_kernel(const float* __restrict__ dout, int d_ctot, int d_coff,
+                                                                          float* __restrict__ dlo, int l_ctot, int l_coff, int h, int w,
+                                                                          int accumulate) {
+    const int c = blockIdx.y, n = blockIdx.z, H = 2 * h, W = 2 * w;
+    const float* d = dout + ((size_t)n * d_ctot + d_coff + c) * H * W;
+    float* o = dlo + ((size_t)n * l_ctot + l_coff + c) * h * w;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < h * w; i += gridDim.x * kBlock) {
+        const int yy = i / w, xx = i - yy * w;
+        float wx[4], wy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int a, b;
+            float t;
+            const int x = 2 * xx - 1 + q, y = 2 * yy - 1 + q;
+            wx[q] = 0.f; wy[q] = 0.f;
+            if (x >= 0 && x < W) { halfpixel_taps(x, w, &a, &b, &t); wx[q] = (a == xx ? 1.f - t : 0.f) + (b == xx ? t : 0.f); }
+            if (y >= 0 && y < H) { halfpixel_taps(y, h, &a, &b, &t); wy[q] = (a == yy ? 1.f - t : 0.f) + (b == yy ? t : 0.f); }
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = min(max(2 * yy - 1 + r, 0), H - 1);      // (clamped rows / columns carry weight 0)
+            float racc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) racc += wx[q] * d[y * W + min(max(2 * xx - 1 + q, 0), W - 1)];
+            acc += wy[r] * racc;
+        }
+        o[i] = accumulate ? o[i] + acc : acc;
+    }
+}
+
 // dst[:, coff:coff+C] (+)= src[:, scoff:scoff+C]   (gradient fan-in of an activation with several consumers)
 __global__ __launch_bounds__(kBlock) void add_slice_kernel(const float* __restrict__ src, int s_ctot, int s_coff,
                                                            float* __restrict__ dst, int d_ctot, int d_coff, int HW,
@@ -427,6 +485,24 @@ int cd_upsample2x_add_fwd(const float* lo, int lo_ctot, int lo_coff, const float
     hipLaunchKernelGGL(cd::upsample2x_add_fwd_kernel, cd::plane_grid(4 * h * w, C, N, 4), dim3(cd::kBlock), 0,
                        (hipStream_t)stream, lo, lo_ctot, lo_coff, lo_scale, lo_shift, lo_relu, hi, hi_ctot, hi_coff, hi_scale,
                        hi_shift, hi_relu, out, o_ctot, o_coff, h, w);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_upsample2x_halfpixel_fwd(const float* lo, int lo_ctot, int lo_coff, float* out, int o_ctot, int o_coff, int C, int N, int h, int w,
+                                void* stream) {
+    CD_ARGCHK(lo && out && C > 0 && N > 0 && h > 0 && w > 0 && lo_coff >= 0 && o_coff >= 0 && lo_coff + C <= lo_ctot && o_coff + C <= o_ctot);
+    hipLaunchKernelGGL(cd::upsample2x_halfpixel_fwd_kernel, cd::plane_grid(4 * h * w, C, N, 4), dim3(cd::kBlock), 0, (hipStream_t)stream,
+                       lo, lo_ctot, lo_coff, out, o_ctot, o_coff, h, w);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_upsample2x_halfpixel_bwd(const float* dout, int d_ctot, int d_coff, float* dlo, int l_ctot, int l_coff, int C, int N, int h, int w,
+                                int accumulate, void* stream) {
+    CD_ARGCHK(dout && dlo && C > 0 && N > 0 && h > 0 && w > 0 && d_coff >= 0 && l_coff >= 0 && d_coff + C <= d_ctot && l_coff + C <= l_ctot);
+    hipLaunchKernelGGL(cd::upsample2x_halfpixel_bwd_kernel, cd::plane_grid(h * w, C, N, 1), dim3(cd::kBlock), 0, (hipStream_t)stream,
+                       dout, d_ctot, d_coff, dlo, l_ctot, l_coff, h, w, accumulate);
     CD_CHECK_LAUNCH();
     return CD_OK;
 }

@@ -11,10 +11,12 @@ Output: inverse depth (N, H, W).  State-dict keys follow upstream (`pretrained.l
 `scratch.refinenet4.resConfUnit1.conv1.weight`, `scratch.output_conv.0.weight`): a real checkpoint loads by
 key.  "Parity unpinned" (no source, no weights, no golden vectors in /root/reference); ~105 M parameters.
 
-Convolutions: `backend="hip"` (default) builds the network from ops.conv_layer.HipConv2d -- every convolution (grouped
-32 x 8d 3x3, strided stem / down-samples, decoder) forward, input gradient and weight gradient on the hand-written gfx950
-MFMA kernels; `backend="torch"` keeps nn.Conv2d (PyTorch-ROCm / MIOpen).  BatchNorm, ReLU, max-pool and the bilinear
-up-sampling are ATen ops in both; loss, optimiser and data parallelism are the HIP/RCCL path.
+Convolutions: `backend="hip"` (default) builds the network from ops.conv_layer.HipConv2d -- EVERY convolution (the dense 1x1
+bottleneck entries / exits, the grouped 32 x 8d 3x3, strided stem / down-samples, decoder) forward, input gradient and weight
+gradient on the hand-written gfx950 MFMA kernels (end of round 5: the dense 1x1 too; `CD_AMD_MIDAS_1X1=gemm` sends them to the GEMM
+library as before, for A/B) -- and the five bilinear x2 up-samplings on ops.layers.bilinear_up2 (gather kernels, no atomics in the
+backward); `backend="torch"` keeps nn.Conv2d (PyTorch-ROCm / MIOpen) and F.interpolate.  BatchNorm, ReLU, the residual adds and the one
+max-pool are ATen / MIOpen ops in both; loss, optimiser and data parallelism are the HIP/RCCL path.
 """
 from __future__ import annotations
 
@@ -73,6 +75,14 @@ class _Encoder(nn.Module):
         self.layer4 = _stage(1024, 512, 3, 2)
 
 
+def _up2(x, align_corners, hip):
+    """Bilinear x2.  hip: the hand-written gather kernels (CUDA tensors only -- the fp64 CPU twins of the tests take the ATen op)."""
+    if hip and x.is_cuda and x.dtype == torch.float32:
+        from ..ops.layers import bilinear_up2
+        return bilinear_up2(x, align_corners)
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=align_corners)
+
+
 class ResidualConvUnit(nn.Module):
     def __init__(self, features):
         super().__init__()
@@ -96,12 +106,12 @@ class FeatureFusionBlock(nn.Module):
         if len(xs) == 2:
             out = out + self.resConfUnit1(xs[1])
         out = self.resConfUnit2(out)
-        return F.interpolate(out, scale_factor=2, mode="bilinear", align_corners=True)
+        return _up2(out, True, getattr(self, "hip_up", False))
 
 
 class _Interpolate(nn.Module):
     def forward(self, x):
-        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        return _up2(x, False, getattr(self, "hip_up", False))
 
 
 class MidasNet(nn.Module):
@@ -124,6 +134,8 @@ class MidasNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, HipConv2d):
                     self._pack_pool.register(m)
+                if isinstance(m, (FeatureFusionBlock, _Interpolate)):
+                    m.hip_up = True
         if path:
             self.load_state_dict(torch.load(path, map_location="cpu"))
 

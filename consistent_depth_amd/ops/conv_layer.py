@@ -11,12 +11,13 @@ Same parameters and state_dict keys as nn.Conv2d (a checkpoint loads unchanged).
     16-wide MFMA column tile is half empty;
   * stride 2: the stride-1 "same" output sampled at even positions (identical values; 4x the MACs of a strided kernel --
     only the stem, 3 bottlenecks and 3 down-sample 1x1 of ResNeXt-101 are strided).
-  * 1x1, dense (the bottleneck entry / exit convolutions: 2/3 of ResNeXt-101's multiply-adds, at 24x24 .. 96x96 images with
-    256 .. 2048 channels): a plain GEMM  Y[n] = W [Cout x Cin] . X[n] [Cin x HW]  -- not a stencil.  The staged fp32-MFMA 1x1
-    kernel of the hourglass (built for 128 -> 208 channels at 384x224) ran them at ~15 TFLOP/s; they go to the GEMM library
-    (rocBLAS / hipBLASLt through torch.matmul / torch.bmm: forward, input gradient, per-image weight-gradient products), which is what
-    a plain GEMM is for.  Stride-2 1x1 (the down-sample paths) sub-sample FIRST (exact, 4x fewer multiply-adds).
-    `CD_AMD_MIDAS_1X1=hip` keeps the hand-written 1x1 kernels (A/B).
+  * 1x1, dense (the bottleneck entry / exit convolutions: 2/3 of ResNeXt-101's multiply-adds, at 12x12 .. 96x96 images with
+    256 .. 2048 channels): a plain GEMM  Y[n] = W [Cout x Cin] . X[n] [Cin x HW]  -- not a stencil.  Rounds 3-4 sent them to the GEMM
+    library (rocBLAS / hipBLASLt through torch.matmul / torch.bmm); measured at the end of round 5 the hand-written 1x1 kernels (the
+    staged fp32-MFMA kernel `conv_fwd_kernel<1, ...>` / `conv_wgrad_kernel<1, ...>` at these small images -- ~118 TFLOP/s = 75 % of the
+    fp32 matrix instruction's peak --, the split-bf16 1x1 kernels at 96x96) run the configs[4] step 6 % slower than the library
+    (54.0 vs 57.6 pairs/s) and are the DEFAULT now: no library GEMM on the path.  `CD_AMD_MIDAS_1X1=gemm` restores the library route
+    (A/B; stride-2 1x1 sub-sample first there).
 Filters are re-packed once per forward (weights move under the optimiser): a `PackPool` shared by the layers of a network
 packs EVERY filter of the network, forward and transposed layouts, in ONE table launch (round 2: two launches of 16 workgroups
 per layer and pass -- 53 ms of a 211 ms MiDaS step); a layer outside a pool packs its own filters.
@@ -74,10 +75,14 @@ class PackPool:
 class _HipConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, layer):
-        x = x.contiguous()
-        N, Cin, H, W = x.shape
         Cout, cin_g, ks, _ = weight.shape
         G, s = layer.groups, layer.stride[0]
+        ctx.full_hw = None
+        if ks == 1 and s > 1:      # a strided 1x1 reads only the sampled pixels: sub-sample FIRST (exact, s^2 fewer multiply-adds)
+            ctx.full_hw = tuple(x.shape[2:])
+            x, s = x[:, :, ::s, ::s], 1
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
         cout_g = Cout // G
         lib, stream = _native.lib(), _native.stream_ptr(x.device)
         pk, _ = layer._packed(weight)
@@ -86,7 +91,7 @@ class _HipConvFn(torch.autograd.Function):
         rc = lib.cd_conv2d_fwd_grouped(_native.dev_ptr(x, "x"), Cin, 0, cin_g, pk[0].data_ptr(), layer._pack_stride, bptr, y.data_ptr(), Cout, 0,
                                        cout_g, G, 0, N, H, W, ks, stream)
         _native.check(rc, "cd_conv2d_fwd_grouped")
-        ctx.layer, ctx.hw = layer, (H, W)
+        ctx.layer, ctx.hw, ctx.s = layer, (H, W), s
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y[:, :, ::s, ::s].contiguous() if s > 1 else y
@@ -97,7 +102,7 @@ class _HipConvFn(torch.autograd.Function):
         layer, (H, W) = ctx.layer, ctx.hw
         N, Cin = x.shape[:2]
         Cout, cin_g, ks, _ = weight.shape
-        G, s = layer.groups, layer.stride[0]
+        G, s = layer.groups, ctx.s
         cout_g = Cout // G
         lib, stream = _native.lib(), _native.stream_ptr(x.device)
         if s > 1:   # adjoint of the sub-sampling: zeros between the samples
@@ -112,6 +117,11 @@ class _HipConvFn(torch.autograd.Function):
             rc = lib.cd_conv2d_fwd_grouped(dyf.data_ptr(), Cout, 0, cout_g, pkT[0].data_ptr(), layer._pack_strideT, None, dx.data_ptr(), Cin, 0,
                                            cin_g, G, 0, N, H, W, ks, stream)
             _native.check(rc, "cd_conv2d_fwd_grouped (dgrad)")
+            if ctx.full_hw is not None:      # (strided 1x1: the input was sub-sampled first)
+                st = layer.stride[0]
+                full = torch.zeros((N, Cin) + ctx.full_hw, dtype=dx.dtype, device=dx.device)
+                full[:, :, ::st, ::st] = dx
+                dx = full
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws, ws_stride = layer._wgrad_workspace(cout_g, cin_g, ks, x.device)
@@ -132,7 +142,7 @@ class HipConv2d(torch.nn.Conv2d):
             raise ValueError(f"HipConv2d: unsupported geometry kernel {k} stride {s} padding {p}")
         self._pk = self._pkT = self._table = self._tableT = self._wptr = self._ws = self._pool = None
         # dense 1x1: a GEMM (see the module docstring)
-        self._gemm = k[0] == 1 and self.groups == 1 and os.environ.get("CD_AMD_MIDAS_1X1", "gemm") != "hip"
+        self._gemm = k[0] == 1 and self.groups == 1 and os.environ.get("CD_AMD_MIDAS_1X1", "hip") == "gemm"
 
     def _uses_packed(self):
         return not self._gemm

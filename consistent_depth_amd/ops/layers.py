@@ -84,6 +84,54 @@ def upsample2x_bwd(dout, d_coff, dlo, l_coff, C, accumulate):
     _native.check(rc, "cd_upsample2x_bwd")
 
 
+def upsample2x_halfpixel_fwd(lo, lo_coff, C, out, out_coff=0):
+    N, lo_ctot, h, w = lo.shape
+    rc = _native.lib().cd_upsample2x_halfpixel_fwd(_p(lo), lo_ctot, lo_coff, _p(out), out.shape[1], out_coff, C, N, h, w, _s(lo))
+    _native.check(rc, "cd_upsample2x_halfpixel_fwd")
+
+
+def upsample2x_halfpixel_bwd(dout, d_coff, dlo, l_coff, C, accumulate):
+    N, l_ctot, h, w = dlo.shape
+    rc = _native.lib().cd_upsample2x_halfpixel_bwd(_p(dout), dout.shape[1], d_coff, _p(dlo), l_ctot, l_coff, C, N, h, w,
+                                                   int(accumulate), _s(dlo))
+    _native.check(rc, "cd_upsample2x_halfpixel_bwd")
+
+
+class _BilinearUp2(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=...) on the hand-written kernels: forward one gather per output
+    pixel, backward the adjoint as a gather per INPUT pixel (no atomics: ATen's backward scatters with atomics, ~1.3 ms per call at the
+    MiDaS decoder's sizes).  align_corners=True: cd_upsample2x_add_fwd / cd_upsample2x_bwd (the hourglass' up-sampling);
+    False: cd_upsample2x_halfpixel_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, align_corners):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            raise RuntimeError("bilinear_up2: fp32 (N, C, H, W) tensors on the HIP device (no CPU path)")
+        x = x.contiguous()
+        N, C, h, w = x.shape
+        out = torch.empty((N, C, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+        if align_corners:
+            upsample2x_add_fwd(x, 0, C, out)
+        else:
+            upsample2x_halfpixel_fwd(x, 0, C, out)
+        ctx.align_corners, ctx.in_shape = bool(align_corners), (N, C, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dx = torch.empty(ctx.in_shape, dtype=dout.dtype, device=dout.device)
+        if ctx.align_corners:
+            upsample2x_bwd(dout, 0, dx, 0, ctx.in_shape[1], False)
+        else:
+            upsample2x_halfpixel_bwd(dout, 0, dx, 0, ctx.in_shape[1], False)
+        return dx, None
+
+
+def bilinear_up2(x, align_corners):
+    return _BilinearUp2.apply(x, align_corners)
+
+
 def add_slice(src, s_coff, dst, d_coff, C, accumulate):
     N, d_ctot, H, W = dst.shape
     rc = _native.lib().cd_add_slice(_p(src), src.shape[1], s_coff, _p(dst), d_ctot, d_coff, C, N, H, W, int(accumulate),

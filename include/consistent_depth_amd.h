@@ -49,7 +49,7 @@ typedef enum cd_depth_mode {
  * cd_conv2d_fwd_multi added, cd_bn_relu_bwd's last
  * argument became a flags bitfield, cd_debug_set_loss_variant(2) is refused).
  * The loader (consistent_depth_amd/_native.py) refuses a library whose cd_abi_version() differs from this constant. */
-#define CD_ABI_VERSION 7
+#define CD_ABI_VERSION 8
 int cd_abi_version(void);
 
 /* Batch-statistics buffers (the `stats` arguments below) hold CD_BN_STAT_SLOTS partial copies:
@@ -463,6 +463,13 @@ int cd_upsample2x_add_fwd(const float* lo, int lo_ctot, int lo_coff, const float
                           int o_coff, int C, int N, int h, int w, void* stream);
 int cd_upsample2x_bwd(const float* dout, int d_ctot, int d_coff, float* dlo, int l_ctot, int l_coff, int C,
                       int N, int h, int w, int accumulate, void* stream);
+/* out = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=False) (half-pixel centres, borders clamped) and its adjoint as
+ * a gather -- the last up-sampling of the MiDaS output head (reference call site: monodepth/midas_v2_model.py:61-67 -> MidasNet.forward;
+ * the un-vendored `midas_net.py::Interpolate`).  (ABI v8) */
+int cd_upsample2x_halfpixel_fwd(const float* lo, int lo_ctot, int lo_coff, float* out, int o_ctot, int o_coff, int C,
+                                int N, int h, int w, void* stream);
+int cd_upsample2x_halfpixel_bwd(const float* dout, int d_ctot, int d_coff, float* dlo, int l_ctot, int l_coff, int C,
+                                int N, int h, int w, int accumulate, void* stream);
 
 /* dst[:, d_coff:+C] (+)= src[:, s_coff:+C]  -- gradient fan-in of a tensor with several consumers. */
 int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_ctot, int d_coff, int C, int N,

@@ -247,3 +247,29 @@ def test_midas_blocks_match_fp64(name):
     worst = max(dw, key=dw.get)
     report(f"midas_block[{name}]", y=dy, dx=dx, dW_worst=dw[worst], worst=worst)
     assert dy < 2e-5 and dx < 2e-4 and dw[worst] < 2e-4, (dy, dx, worst, dw[worst])
+
+
+@pytest.mark.parametrize("align_corners", [True, False], ids=["align_corners", "half_pixel"])
+@pytest.mark.parametrize("shape", [(2, 5, 12, 12), (1, 3, 7, 9), (2, 4, 1, 6)], ids=lambda s: "x".join(map(str, s)))
+def test_bilinear_up2_matches_interpolate(shape, align_corners):
+    """ops.layers.bilinear_up2 -- the five x2 up-samplings of the MiDaS decoder on the hand-written gather kernels (align_corners=True in
+    the fusion blocks, half-pixel centres in the output head) -- against F.interpolate in fp64: the output, and the input gradient
+    (the adjoint written as a gather per input pixel: no atomics) for a random output gradient.  Odd and one-row extents included."""
+    import torch
+    import torch.nn.functional as F
+    from consistent_depth_amd.ops.layers import bilinear_up2
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g, dtype=torch.float64)
+    xh = x.float().cuda().requires_grad_(True)
+    y = bilinear_up2(xh, align_corners)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy.float().cuda())
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=align_corners)
+    yr.backward(dy)
+    assert y.shape == yr.shape
+    ey = float((y.detach().double().cpu() - yr.detach()).abs().max())
+    ex = float((xh.grad.double().cpu() - xr.grad).abs().max())
+    report("bilinear_up2", shape="x".join(map(str, shape)), align_corners=align_corners, y=f"{ey:.2e}", dx=f"{ex:.2e}")
+    # fp32 weights and products on values of a few units (the source index of align_corners=True is a rounded fp32 product): a few 1e-6
+    assert ey < 6e-6 and ex < 1e-5, (ey, ex)
