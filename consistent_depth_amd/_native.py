@@ -88,6 +88,11 @@ SIGNATURES = {
     "cd_upsample2x_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_upsample2x_halfpixel_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_upsample2x_halfpixel_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_bn_block_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cd_bn_block_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cd_eltwise": (c_i, [c_p, c_p, c_p, ctypes.c_size_t, c_i, c_p]),
+    "cd_maxpool3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "cd_maxpool3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_add_slice": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "cd_channel_sum": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "cd_adam_step_flat": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),

@@ -15,10 +15,15 @@ Convolutions: `backend="hip"` (default) builds the network from ops.conv_layer.H
 bottleneck entries / exits, the grouped 32 x 8d 3x3, strided stem / down-samples, decoder) forward, input gradient and weight
 gradient on the hand-written gfx950 MFMA kernels (end of round 5: the dense 1x1 too; `CD_AMD_MIDAS_1X1=gemm` sends them to the GEMM
 library as before, for A/B) -- and the five bilinear x2 up-samplings on ops.layers.bilinear_up2 (gather kernels, no atomics in the
-backward); `backend="torch"` keeps nn.Conv2d (PyTorch-ROCm / MIOpen) and F.interpolate.  BatchNorm, ReLU, the residual adds and the one
-max-pool are ATen / MIOpen ops in both; loss, optimiser and data parallelism are the HIP/RCCL path.
+backward), every BatchNorm (+ identity) (+ ReLU) as ONE hand-written block (ops.blocks.bn_act: batch statistics, apply, and the
+backward's reduce / apply -- csrc/bn_block.hip), the decoder's ReLUs and adds and the stem's max-pool on the same file's kernels
+(`CD_AMD_MIDAS_BLOCKS=aten` keeps the ATen / MIOpen ops, for A/B); `backend="torch"` keeps nn.Conv2d (PyTorch-ROCm / MIOpen),
+F.interpolate and the ATen modules.  What is left to the framework in the hip back end: autograd's own gradient accumulation where a
+tensor has two consumers, the bias gradients' sums, tensor allocation.  Loss, optimiser and data parallelism are the HIP/RCCL path.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn as nn
@@ -47,6 +52,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if getattr(self, "hip_blocks", False) and x.is_cuda:     # BatchNorm (+ identity) (+ ReLU) as one hand-written block each
+            from ..ops import blocks as B
+            idt = x if self.downsample is None else B.bn_act(self.downsample[0](x), self.downsample[1], False)
+            out = B.bn_act(self.conv1(x), self.bn1, True)
+            out = B.bn_act(self.conv2(out), self.bn2, True)
+            return B.bn_act(self.conv3(out), self.bn3, True, res=idt)
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
@@ -63,13 +74,31 @@ def _stage(inplanes, planes, blocks, stride):
     return nn.Sequential(*layers)
 
 
+class _Layer1(nn.Sequential):
+    """stem (conv 7x7 / 2, BatchNorm, ReLU, max-pool 3x3 / 2) + resnet.layer1, with upstream's indices (`layer1.0`, `.1`, `.4`)."""
+
+    def forward(self, x):
+        if getattr(self, "hip_blocks", False) and x.is_cuda:
+            from ..ops import blocks as B
+            return self[4](B.maxpool3s2(B.bn_act(self[0](x), self[1], True)))
+        return super().forward(x)
+
+
+class _Relu(nn.Module):
+    def forward(self, x):
+        if getattr(self, "hip_blocks", False) and x.is_cuda:
+            from ..ops import blocks as B
+            return B.relu(x)
+        return F.relu(x)
+
+
 class _Encoder(nn.Module):
     """`pretrained` of upstream: layer1 = stem + resnet.layer1, layer2..4 = resnet.layer2..4."""
 
     def __init__(self):
         super().__init__()
         stem = [Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)]
-        self.layer1 = nn.Sequential(*stem, _stage(64, 64, 3, 1))
+        self.layer1 = _Layer1(*stem, _stage(64, 64, 3, 1))
         self.layer2 = _stage(256, 128, 4, 2)
         self.layer3 = _stage(512, 256, 23, 2)
         self.layer4 = _stage(1024, 512, 3, 2)
@@ -90,6 +119,9 @@ class ResidualConvUnit(nn.Module):
         self.conv2 = Conv2d(features, features, 3, 1, 1, bias=True)
 
     def forward(self, x):
+        if getattr(self, "hip_blocks", False) and x.is_cuda:
+            from ..ops import blocks as B
+            return B.add(self.conv2(B.relu(self.conv1(B.relu(x)))), x)
         out = self.conv1(F.relu(x))
         out = self.conv2(F.relu(out))
         return out + x
@@ -104,7 +136,11 @@ class FeatureFusionBlock(nn.Module):
     def forward(self, *xs):
         out = xs[0]
         if len(xs) == 2:
-            out = out + self.resConfUnit1(xs[1])
+            if getattr(self, "hip_blocks", False) and out.is_cuda:
+                from ..ops import blocks as B
+                out = B.add(out, self.resConfUnit1(xs[1]))
+            else:
+                out = out + self.resConfUnit1(xs[1])
         out = self.resConfUnit2(out)
         return _up2(out, True, getattr(self, "hip_up", False))
 
@@ -136,6 +172,9 @@ class MidasNet(nn.Module):
                     self._pack_pool.register(m)
                 if isinstance(m, (FeatureFusionBlock, _Interpolate)):
                     m.hip_up = True
+                if os.environ.get("CD_AMD_MIDAS_BLOCKS", "hip") != "aten" and isinstance(
+                        m, (Bottleneck, _Layer1, _Relu, ResidualConvUnit, FeatureFusionBlock)):
+                    m.hip_blocks = True      # BatchNorm / ReLU / adds / max-pool on ops.blocks (A/B: CD_AMD_MIDAS_BLOCKS=aten)
         if path:
             self.load_state_dict(torch.load(path, map_location="cpu"))
 
@@ -147,8 +186,8 @@ class MidasNet(nn.Module):
         for i in (4, 3, 2, 1):
             setattr(self.scratch, f"refinenet{i}", FeatureFusionBlock(features))
         self.scratch.output_conv = nn.Sequential(
-            Conv2d(features, 128, 3, 1, 1), _Interpolate(), Conv2d(128, 32, 3, 1, 1), nn.ReLU(True),
-            Conv2d(32, 1, 1, 1, 0), nn.ReLU(True) if non_negative else nn.Identity())
+            Conv2d(features, 128, 3, 1, 1), _Interpolate(), Conv2d(128, 32, 3, 1, 1), _Relu(),
+            Conv2d(32, 1, 1, 1, 0), _Relu() if non_negative else nn.Identity())
 
     def forward(self, x):
         if self._pack_pool is not None:

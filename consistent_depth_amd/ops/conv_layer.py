@@ -129,7 +129,10 @@ class _HipConvFn(torch.autograd.Function):
                                              ws.data_ptr(), ws_stride, N, H, W, ks, stream)
             _native.check(rc, "cd_conv2d_wgrad_grouped")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3))
+            from .layers import channel_sum      # (hand-written reduction: cd_channel_sum)
+            dyc = dy.contiguous()
+            db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+            channel_sum(dyc, 0, Cout, db)
         return dx, dw, db, None
 
 

@@ -471,6 +471,26 @@ int cd_upsample2x_halfpixel_fwd(const float* lo, int lo_ctot, int lo_coff, float
 int cd_upsample2x_halfpixel_bwd(const float* dout, int d_ctot, int d_coff, float* dlo, int l_ctot, int l_coff, int C,
                                 int N, int h, int w, int accumulate, void* stream);
 
+/* ---- blocks of an autograd-driven backbone (MiDaS v2 / ResNeXt-101, BASELINE configs[4]; reference call site
+ * monodepth/midas_v2_model.py:58-67 -> the un-vendored MidasNet; torchvision Bottleneck: conv-bn-relu x2, conv-bn, + identity, relu).  (ABI v8)
+ * cd_bn_block_fwd: y = act(BatchNorm2d_train(x) [+ res]), act = ReLU (relu != 0) or identity; batch statistics in fp64 across blocks,
+ *   running statistics updated like nn.BatchNorm2d (momentum, unbiased variance); gamma / beta NULL = not affine; res NULL = no residual.
+ *   Saves mean_invstd [C][2] for the backward; scale / shift [C] and stats [CD_BN_STAT_SLOTS][C][2] doubles are scratch (zeroed by the call).
+ * cd_bn_block_bwd: from dy = d loss / d y:  dv = relu ? (y > 0 ? dy : 0) : dy;  dres = dv (NULL: none);
+ *   dx = gamma invstd (dv - mean(dv) - xhat mean(dv xhat));  dgamma = sum dv xhat, dbeta = sum dv (assigned; NULL: none).  sums [C][2]
+ *   doubles scratch.  x, y: the forward's input and output. */
+int cd_bn_block_fwd(const float* x, const float* gamma, const float* beta, const float* res, int relu, float* running_mean,
+                    float* running_var, float momentum, float eps, float* y, float* mean_invstd, float* scale, float* shift,
+                    double* stats, int C, int N, int H, int W, void* stream);
+int cd_bn_block_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* mean_invstd, int relu,
+                    float* dx, float* dres, float* dgamma, float* dbeta, double* sums, int C, int N, int H, int W, void* stream);
+/* y = max(a, 0) (op 0) | a + b (op 1) | b > 0 ? a : 0 (op 2: ReLU backward, a = dy, b = the ReLU's input or output); 16-byte aligned. */
+int cd_eltwise(const float* a, const float* b, float* y, size_t n, int op, void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1): y (N, C, (H-1)/2+1, (W-1)/2+1), argmax = position inside the window (0..8; ATen's first-maximum
+ * rule); the backward is a gather over the <= 4 windows that contain an input pixel. */
+int cd_maxpool3s2_fwd(const float* x, float* y, unsigned char* argmax, int C, int N, int H, int W, void* stream);
+int cd_maxpool3s2_bwd(const float* dy, const unsigned char* argmax, float* dx, int C, int N, int H, int W, void* stream);
+
 /* dst[:, d_coff:+C] (+)= src[:, s_coff:+C]  -- gradient fan-in of a tensor with several consumers. */
 int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_ctot, int d_coff, int C, int N,
                  int H, int W, int accumulate, void* stream);

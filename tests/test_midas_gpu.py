@@ -273,3 +273,80 @@ def test_bilinear_up2_matches_interpolate(shape, align_corners):
     report("bilinear_up2", shape="x".join(map(str, shape)), align_corners=align_corners, y=f"{ey:.2e}", dx=f"{ex:.2e}")
     # fp32 weights and products on values of a few units (the source index of align_corners=True is a rounded fp32 product): a few 1e-6
     assert ey < 6e-6 and ex < 1e-5, (ey, ex)
+
+
+@pytest.mark.parametrize("relu,with_res,affine", [(True, False, True), (False, False, True), (True, True, True), (True, False, False)],
+                         ids=["bn_relu", "bn", "bn_add_relu", "bn_relu_not_affine"])
+@pytest.mark.parametrize("shape", [(4, 6, 12, 12), (2, 5, 7, 9)], ids=lambda s: "x".join(map(str, s)))
+def test_bn_block_matches_batchnorm_fp64(shape, relu, with_res, affine):
+    """ops.blocks.bn_act -- act(BatchNorm2d_train(x) [+ res]) as ONE hand-written block (csrc/bn_block.hip) -- against nn.BatchNorm2d (+ add)
+    (+ ReLU) in fp64: output, input gradient, the residual's gradient, d gamma / d beta, and the running statistics + batch counter after
+    the step.  H*W a multiple of 4 (16-byte path) and not."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from consistent_depth_amd.ops import blocks as B
+    g = torch.Generator().manual_seed(sum(shape) + 7 * relu + 3 * with_res)
+    N, C, H, W = shape
+    x = torch.randn(shape, generator=g, dtype=torch.float64) * 1.7 + 0.4
+    res = torch.randn(shape, generator=g, dtype=torch.float64) if with_res else None
+    bn64 = nn.BatchNorm2d(C, affine=affine).double().train()
+    if affine:
+        with torch.no_grad():
+            bn64.weight.copy_(torch.rand(C, generator=g, dtype=torch.float64) + 0.5)
+            bn64.bias.copy_(torch.randn(C, generator=g, dtype=torch.float64) * 0.3)
+    bn32 = nn.BatchNorm2d(C, affine=affine).train()
+    bn32.load_state_dict(bn64.state_dict())
+    bn32 = bn32.cuda()
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    yr = bn64(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    dy = torch.randn(shape, generator=g, dtype=torch.float64)
+    yr.backward(dy)
+    xh = x.float().cuda().requires_grad_(True)
+    rh = res.float().cuda().requires_grad_(True) if with_res else None
+    y = B.bn_act(xh, bn32, relu, rh)
+    y.backward(dy.float().cuda())
+    rel = lambda a, b: float((a.detach().double().cpu() - b.detach()).abs().max() / max(float(b.detach().abs().max()), 1e-30))  # noqa: E731
+    got = {"y": rel(y, yr), "dx": rel(xh.grad, xr.grad)}
+    if with_res:
+        got["dres"] = rel(rh.grad, rr.grad)
+    if affine:
+        got["dgamma"], got["dbeta"] = rel(bn32.weight.grad, bn64.weight.grad), rel(bn32.bias.grad, bn64.bias.grad)
+    got["running_mean"], got["running_var"] = rel(bn32.running_mean, bn64.running_mean), rel(bn32.running_var, bn64.running_var)
+    report("bn_block", shape="x".join(map(str, shape)), relu=relu, res=with_res, affine=affine, **{k: f"{v:.2e}" for k, v in got.items()})
+    assert int(bn32.num_batches_tracked) == int(bn64.num_batches_tracked) == 1
+    for k, v in got.items():
+        assert v < 2e-5, (k, v)      # (a ReLU mask flips where |pre-activation| < 1e-7: none in these cases)
+
+
+def test_eltwise_and_maxpool_match_aten():
+    """ops.blocks.relu / add / maxpool3s2 (the decoder's element-wise pieces and the stem's nn.MaxPool2d(3, 2, 1)) against the ATen ops,
+    forward and backward -- BIT-identical: they move or select values, nothing is rounded.  Odd extents, -inf and ties for the pool."""
+    import torch
+    import torch.nn.functional as F
+    from consistent_depth_amd.ops import blocks as B
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(2, 3, 9, 7, device="cuda", generator=g)
+    b = torch.randn(2, 3, 9, 7, device="cuda", generator=g)
+    dy = torch.randn(2, 3, 9, 7, device="cuda", generator=g)
+    for fn, ref in ((lambda u, v: B.add(B.relu(u), v), lambda u, v: F.relu(u) + v),):
+        u1, v1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        u2, v2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y1, y2 = fn(u1, v1), ref(u2, v2)
+        y1.backward(dy); y2.backward(dy)
+        assert torch.equal(y1, y2) and torch.equal(u1.grad, u2.grad) and torch.equal(v1.grad, v2.grad)
+    for shape in ((2, 3, 12, 12), (1, 2, 7, 9), (1, 1, 1, 5)):
+        x = torch.randn(shape, device="cuda", generator=g)
+        x[..., 0, 0] = float("-inf")
+        x[..., -1, :] = torch.round(x[..., -1, :])        # ties in the last row
+        x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        y1, y2 = B.maxpool3s2(x1), F.max_pool2d(x2, 3, 2, 1)
+        assert y1.shape == y2.shape and torch.equal(y1, y2)
+        d = torch.randn(y2.shape, device="cuda", generator=g)
+        y1.backward(d); y2.backward(d)
+        assert torch.equal(x1.grad, x2.grad), shape
