@@ -202,6 +202,19 @@ def profile_collect(lib, cap):
 LOSS_WARM_CALLS = 100
 
 
+def midas_path_note():
+    """What the configs[4] line ran on (the two A/B switches of the midas2 plugin)."""
+    gemm = os.environ.get("CD_AMD_MIDAS_1X1", "hip") == "gemm"
+    aten = os.environ.get("CD_AMD_MIDAS_BLOCKS", "hip") == "aten"
+    return ("k >= 3 convolutions incl. the grouped 32x8d 3x3 (1/3 of the multiply-adds): hand-written split-bf16 HIP kernels, forward / input "
+            "gradient / weight gradient; dense 1x1 convolutions (2/3 of the multiply-adds): "
+            + ("fp32 GEMMs of the library (rocBLAS / hipBLASLt through torch.matmul / bmm; CD_AMD_MIDAS_1X1=gemm)" if gemm else
+               "hand-written too (the staged fp32-MFMA 1x1 kernels at 12x12 .. 48x48, the split-bf16 1x1 kernels at 96x96; no library GEMM)")
+            + "; BatchNorm (+ identity) (+ ReLU), ReLU, adds, max-pool: "
+            + ("ATen / MIOpen (CD_AMD_MIDAS_BLOCKS=aten)" if aten else "hand-written blocks (csrc/bn_block.hip)")
+            + "; bilinear x2: hand-written gather kernels; stride 2 (k >= 3) = stride 1 + sub-sampling; loss + Adam: hand-written HIP)")
+
+
 def loss_microbench(lib, B, H, W, iters, device, warm=LOSS_WARM_CALLS):
     """Fused loss kernel at an HBM-saturating batch: per-launch ms from HIP events on the stream."""
     from consistent_depth_amd import synthetic
@@ -427,10 +440,7 @@ def main():
                                (f"midas2 plugin: MiDaS-v2-shaped backbone (ResNeXt-101 32x8d + feature-fusion decoder restated, random init, "
                                 f"seed 0), fine-tuning steps over a synthetic {args.frames}-frame {H}x{W} clip ({len(store)} pairs), BS{B} pairs/GPU, "
                                 f"lambda_r 1.0 lambda_b 1e-4, Adam lr 1e-4 (BASELINE configs[4] shape on {world} GPU(s); "
-                                + ("k >= 3 convolutions incl. the grouped 32x8d 3x3 (1/3 of the multiply-adds): hand-written split-bf16 HIP kernels, "
-                                   "forward / input gradient / weight gradient; dense 1x1 convolutions (2/3 of the multiply-adds): fp32 GEMMs of the "
-                                   "library (rocBLAS / hipBLASLt through torch.matmul / bmm); BatchNorm, ReLU, max-pool, bilinear: ATen; stride 2 = "
-                                   "stride 1 + sub-sampling; loss + Adam: hand-written HIP)" if args.backend == "hip" else "convolutions: PyTorch-ROCm/MIOpen)")),
+                                + (midas_path_note() if args.backend == "hip" else "convolutions: PyTorch-ROCm/MIOpen)")),
                    "model": args.model,
                    "conv_backend": args.backend,
                    "conv_arith": ("fp32 results from split operands: every fp32 input = 3 exact bf16 terms, 6 cross products on the BF16 matrix "
@@ -466,7 +476,8 @@ def main():
                                                      "of what the convolution kernels reach while they run)",
             "peak_note": ("fp32-equivalent roof of the split-operand kernels = dense BF16 peak 2500 / 6 products" if split else
                           ("a MIXTURE for midas2, priced against the LOWER of its two roofs (which flatters the fraction): 2/3 of the flops are "
-                           "fp32 library GEMMs (roof 157.3), 1/3 run on the split-operand kernels (roof 416.7); against the flop-weighted roof "
+                           "dense 1x1 convolutions on the fp32 matrix instruction (hand-written staged kernel, or the library's fp32 GEMMs under "
+                           "CD_AMD_MIDAS_1X1=gemm: roof 157.3), 1/3 run on the split-operand kernels (roof 416.7); against the flop-weighted roof "
                            "1 / (2/3 / 157.3 + 1/3 / 416.7) = 198.4 TFLOP/s the fraction is frac x 0.793"
                            if args.model == "midas2" and args.backend == "hip" else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)")),
             "frac_of_fp32_mfma_peak": round(ach_tf / MFMA_FP32_PEAK_TFLOPS, 4),
