@@ -438,8 +438,11 @@ static inline void pick_conv_tile(int ks, int pack_cot, int Cout, int N, int H, 
     int ty, cot;
     if (ks == 1) {   // measured: 4-row tiles with the full packed group win nearly everywhere; the wide (8/16-tile) slices do not
         cot = px > L3 ? pack_cot : (pack_cot < 2 ? pack_cot : 2);
+        // many output channels on few pixels (the MiDaS / ResNeXt bottlenecks at 24x24 and 12x12: 512 .. 2048 channels; the hourglass has
+        // at most 256): with two channel tiles per workgroup the input is re-read once per 32 output channels -- the full packed group
+        // again (measured on the configs[4] step: 58.0 -> 60.1 pairs/s; 8 tiles 59.5, 16 tiles 55.4).  Same bits for every launch shape.
+        if (Cout >= 512) cot = pack_cot;
         ty = 4;
-        (void)Cout;
     } else {
         cot = px > L2 ? (pack_cot < 2 ? pack_cot : 2) : 1;
         ty = px > L2 ? ((ks == 7) ? 8 : 16) : (px > L3 ? 8 : 4);
