@@ -15,8 +15,9 @@ Same parameters and state_dict keys as nn.Conv2d (a checkpoint loads unchanged).
     256 .. 2048 channels): a plain GEMM  Y[n] = W [Cout x Cin] . X[n] [Cin x HW]  -- not a stencil.  Rounds 3-4 sent them to the GEMM
     library (rocBLAS / hipBLASLt through torch.matmul / torch.bmm); measured at the end of round 5 the hand-written 1x1 kernels (the
     staged fp32-MFMA kernel `conv_fwd_kernel<1, ...>` / `conv_wgrad_kernel<1, ...>` at these small images -- ~118 TFLOP/s = 75 % of the
-    fp32 matrix instruction's peak --, the split-bf16 1x1 kernels at 96x96) run the configs[4] step 6 % slower than the library
-    (54.0 vs 57.6 pairs/s) and are the DEFAULT now: no library GEMM on the path.  `CD_AMD_MIDAS_1X1=gemm` restores the library route
+    fp32 matrix instruction's peak --, the split-bf16 1x1 kernels at 96x96) ran the configs[4] step 6 % slower than the library
+    (54.0 vs 57.6 pairs/s) and are the DEFAULT now: no library GEMM on the path (with the launch shape for >= 512 output channels and the
+    hand-written layer blocks the step is at 60.8 pairs/s).  `CD_AMD_MIDAS_1X1=gemm` restores the library route
     (A/B; stride-2 1x1 sub-sample first there).
 Filters are re-packed once per forward (weights move under the optimiser): a `PackPool` shared by the layers of a network
 packs EVERY filter of the network, forward and transposed layouts, in ONE table launch (round 2: two launches of 16 workgroups
