@@ -79,7 +79,9 @@ int cd_mask_sums(const float* mask_fwd, const float* mask_bwd, int B, int H, int
  * pairs).  Like the mask sums they depend only on flows and masks, i.e. on the dataset: compute them
  * once per pair (rows of B pairs can be gathered: the layout is [B][2][tiles] x 8 bytes) and pass
  * them to cd_consistency_loss_fwd_bwd; NULL there = recomputed on every call (one extra read of the
- * flows and masks). */
+ * flows and masks).  They must belong to EXACTLY the flows and masks of the call (like mask_sum): the
+ * row-sweep kernel trusts the plan's statement that a row group's valid sources sample resident rows
+ * (no clamp, no vote for such groups) -- windows of other flows or masks give undefined gradients. */
 size_t cd_tile_windows_bytes(int B, int H, int W);
 int cd_tile_windows(const float* flow_fwd, const float* flow_bwd, const float* mask_fwd,
                     const float* mask_bwd, int B, int H, int W, void* tile_windows, void* stream);
