@@ -13,7 +13,7 @@ import torch  # imported first on purpose: libcd_amd.so then binds to torch's li
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # CD_AMD_LIB: load another build of the SAME library (A/B measurements of kernel variants, tools/exp/build_variants.sh); not a fallback
 SO_PATH = os.environ.get("CD_AMD_LIB") or os.path.join(_PKG, "libcd_amd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 BN_STAT_SLOTS = 16   # CD_BN_STAT_SLOTS of include/consistent_depth_amd.h (checked by tests/test_abi.py)
 
 _lib = None
@@ -25,6 +25,7 @@ SIGNATURES = {
     "cd_abi_version": (c_i, []),
     "cd_build_info": (ctypes.c_char_p, []),
     "cd_consistency_loss_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "cd_consistency_loss_workspace_init": (c_i, [c_p, c_sz, c_p]),
     "cd_mask_sums": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "cd_tile_windows_bytes": (c_sz, [c_i, c_i, c_i]),
     "cd_tile_windows": (c_i, [c_p] * 4 + [c_i, c_i, c_i, c_p, c_p]),
@@ -156,14 +157,17 @@ _workspaces: dict = {}
 _retired: list = []   # outgrown workspaces stay alive: a captured HIP graph may have their addresses baked in
 
 
-def workspace(key, nbytes: int, device) -> torch.Tensor:
+def workspace(key, nbytes: int, device, on_new=None) -> torch.Tensor:
     """Persistent per-(key, device) scratch buffer, grown on demand (never shrunk, never freed: a step graph captured
-    with the smaller buffer keeps replaying into it while later, larger calls use the new one)."""
+    with the smaller buffer keeps replaying into it while later, larger calls use the new one).  on_new(buf): called once
+    for every buffer this function allocates (cd_consistency_loss_workspace_init for the loss workspace)."""
     k = (key, str(device))
     buf = _workspaces.get(k)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
             _retired.append(buf)
         buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        if on_new is not None:
+            on_new(buf)
         _workspaces[k] = buf
     return buf

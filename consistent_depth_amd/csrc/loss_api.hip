@@ -121,6 +121,7 @@ static void prof_after(hipStream_t s) {
 
 // ---------------------------------------------------------------- workspace
 struct Workspace {
+    WorkspaceHeader* hdr;   // 256 B at offset 0 (a FIXED place whatever B: state that outlives a call, cd_consistency_loss_workspace_init)
     PairCam* cams;     // [B*2]
     float* mask_sum;   // [B*2]            (when the caller passes none)
     float* partial;    // [B*2][ntiles][2] (v2) or [B*2][nblk][2] (v1 forward-only)
@@ -143,6 +144,7 @@ static inline size_t ws_layout(int B, int H, int W, void* base, Workspace* w) {
     const int np = v1_blocks_per_plane(HW, 1) > owner_ntiles(H, W) ? v1_blocks_per_plane(HW, 1) : owner_ntiles(H, W);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t o_hdr = take(sizeof(WorkspaceHeader));
     const size_t o_cams = take(sizeof(PairCam) * (size_t)B * 2);
     const size_t o_msum = take(sizeof(float) * (size_t)B * 2);
     const size_t o_part = take(sizeof(float) * (size_t)B * 2 * np * 2);
@@ -153,6 +155,7 @@ static inline size_t ws_layout(int B, int H, int W, void* base, Workspace* w) {
     const size_t o_slab = take(sizeof(float) * slab_floats(B, H, W));
     if (w) {
         char* p = (char*)base;
+        w->hdr = (WorkspaceHeader*)(p + o_hdr);
         w->cams = (PairCam*)(p + o_cams); w->mask_sum = (float*)(p + o_msum); w->partial = (float*)(p + o_part);
         w->partial_fb = (float*)(p + o_pfb); w->wins = p + o_wins; w->ovf = p + o_ovf; w->ovf_cap = cap;
         w->slabs = (float*)(p + o_slab);
@@ -214,7 +217,7 @@ static int run_loss(const float* depth, const float* ff, const float* fb, const 
         const int cap = (g_force_overflow_cap >= 0 && g_force_overflow_cap < w.ovf_cap) ? g_force_overflow_cap : w.ovf_cap;
         if (use_sweep)      // ONE kernel: gradient, per-pair losses and their mean are complete when it is (loss_sweep.hip)
             return launch_sweep(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, grad, w.ovf, cap, s, prof_before,
-                                prof_after, intr, extr, mask_sum, lambda_r, lambda_b, reproj, disp, total);
+                                prof_after, intr, extr, mask_sum, lambda_r, lambda_b, reproj, disp, total, w.hdr);
         rc = launch_slab(depth, ff, fb, mf, mb, w.cams, tile_windows, depth_mode, r_on, B, H, W, w.partial, grad, w.slabs,
                          w.ovf, cap, s, prof_before, prof_after);
         if (rc != CD_OK) return rc;
@@ -299,6 +302,14 @@ int cd_debug_set_overflow_capacity(int cap) {
 size_t cd_consistency_loss_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     return cd::ws_layout(B, H, W, nullptr, nullptr);
+}
+
+int cd_consistency_loss_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < sizeof(cd::WorkspaceHeader)) return CD_ERR_INVALID_ARG;
+        // (the 8 bytes travel inside the command: no host buffer to keep alive, capturable)
+    if (hipMemsetD32Async((hipDeviceptr_t)((char*)workspace + 4), 0, 1, (hipStream_t)stream) != hipSuccess) return CD_ERR_LAUNCH;
+    if (hipMemsetD32Async((hipDeviceptr_t)workspace, (int)cd::kWorkspaceMagic, 1, (hipStream_t)stream) != hipSuccess) return CD_ERR_LAUNCH;
+    return CD_OK;
 }
 
 int cd_mask_sums(const float* mask_fwd, const float* mask_bwd, int B, int H, int W, float* mask_sum, void* stream) {

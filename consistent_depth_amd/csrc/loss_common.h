@@ -28,6 +28,13 @@ int launch_tile_windows(const float* ff, const float* fb, const float* mf, const
 const int* owner_fallback_flag(void* ovf_mem);
 int launch_overflow_apply(void* ovf_mem, int ovf_cap, float* grad, hipStream_t s);
 
+// The first 256 bytes of the loss workspace: state that OUTLIVES a call (cd_consistency_loss_workspace_init writes it once after the
+// workspace is allocated).  `finished` counts the workgroups of the running row-sweep launch that are done; the last one averages the
+// per-pair losses and puts the counter back to zero, so no per-call reset dispatch is needed.
+constexpr unsigned kWorkspaceMagic = 0xC0D1A6D5u;
+struct WorkspaceHeader { unsigned magic; unsigned finished; unsigned reserved[62]; };
+static_assert(sizeof(WorkspaceHeader) == 256, "header = one 256-byte workspace slot");
+
 // ---- v4 (loss_sweep.hip): one workgroup per pair, row rings in LDS; plans live in the tile-windows blob
 size_t pair_record_bytes(int H, int W);   // bytes of one pair's record of the blob: tile windows [+ sweep plan]
 int launch_sweep_plan(const float* ff, const float* fb, const float* mf, const float* mb, int B, int H, int W, void* blob,
@@ -41,7 +48,7 @@ void set_sweep_pxt(int pxt);
 int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, void* cams,
                  const void* blob, int mode, bool reproj, int B, int H, int W, float* grad, void* ovf_mem, int ovf_cap, hipStream_t s,
                  void (*before)(hipStream_t), void (*after)(hipStream_t), const float* intr, const float* extr, const float* mask_sum,
-                 float lambda_r, float lambda_b, float* reproj_out, float* disp_out, float* total_out);
+                 float lambda_r, float lambda_b, float* reproj_out, float* disp_out, float* total_out, WorkspaceHeader* hdr);
 
 // ---- v3 (loss_slab.hip): source pass + gather pass; slabs = slab_floats(B,H,W) floats of scratch
 size_t slab_floats(int B, int H, int W);

@@ -180,7 +180,8 @@ __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlan
 
 // SG: 0 = the geometry arrives at run time (kernel argument); 1 = the BASELINE shape 384 x 224 at 2 pixels per thread as
 // COMPILE-TIME constants: ring strides, rows per pass, image size fold into immediates (the kernel is short of scalar registers:
-// ~30 wave-uniform camera constants, 10 pointers and the plan records live next to them) -- same code, same results.
+// ~30 wave-uniform camera constants, 10 pointers and the plan records live next to them) -- same code, same results;
+// 2 = 1 with non-temporal loads of the depth rows (round 6: launches of more than ~290 pairs, launch_sweep_inst).
 constexpr int kStaticH = 384, kStaticW = 224, kStaticPXT = 2;
 static_assert(kStagePasses == 2, "the service wave's quad count assumes SMAX = 2 passes of RP = 4 rows at the static geometry");
 constexpr int kStaticSvcQuads = (2 * 4 * (kStaticW / 4) + kSvcLanes - 1) / kSvcLanes;
@@ -192,7 +193,7 @@ static bool static_geometry_holds(const Geo& c) {
            kStaticH % 4 == 0;
 }
 
-struct SweepOut { float* reproj; float* disp; float* total; int* done; };     // per-pair losses [B], batch mean [1], the launch's finished-pairs counter
+struct SweepOut { float* reproj; float* disp; float* total; WorkspaceHeader* hdr; };     // per-pair losses [B], batch mean [1], the workspace header (finished-pairs counter)
 
 // fbar (batch mean of (fx + fy) / 2 of the ref frames, consistency_loss.py:178), the pair's PairCam[2] (prep_pair) and the accumulator
 // units (units_from_samples) -> st.cam; scratch: 24 floats of LDS.  All kThreads threads call both parts.
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     // 255 words: {0, 1} and {RW, RW + 1} fit), its accumulator adds ds_add_u32 with 16-bit byte offsets -- so ONE address register,
     // the tap's depth address, serves all eight (accumulators first cost a v_add per read pair)
     extern __shared__ __align__(16) unsigned smem[];
-    const Geo g = SG == 1 ? make_geo(kStaticH, kStaticW, kStaticPXT) : sh.g;
+    const Geo g = SG >= 1 ? make_geo(kStaticH, kStaticW, kStaticPXT) : sh.g;
+    constexpr bool NTD = SG == 2;        // non-temporal depth rows (launches whose depth planes cannot stay in the Infinity Cache)
     const int b = blockIdx.x, HW = g.H * g.W, ring = ring_rows(g) * g.RW;
     const int f = uni((int)(threadIdx.x / kFrameThreads)), k = 1 - f;   // whole waves serve one frame: everything derived from f is scalar
     View v;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
 #pragma unroll
     for (int j = 0; j < kInitBatches; ++j) {
         const int lo = j * kStagePasses * g.RP;
-        load_stage_nosel<PXT>(v, l0, lo < init_hi ? lo : 0, init_batched ? min(lo + kStagePasses * g.RP, init_hi) : 0, sv0[j]);
+        load_stage_nosel<PXT, NTD>(v, l0, lo < init_hi ? lo : 0, init_batched ? min(lo + kStagePasses * g.RP, init_hi) : 0, sv0[j]);
     }
     // ... and the flow / mask of the first item's source rows (fast pass; consumed at the top of the loop, ~15 us from here)
     const PlanHeader* ph = reinterpret_cast<const PlanHeader*>(blob + (size_t)b * sh.stride + sh.plan_off);
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     // ahead: loading it at the top of its own item exposed the scalar-load latency (0.344 -> 0.374 ms at 256 pairs).
     // The frame's SERVICE wave (loss_sweep_core.h: the eighth wave of each frame has no source pixels at W = 224 and takes over the
     // rows that enter and leave the ring; compile-time geometry only -- the run-time-geometry build keeps every thread on its columns).
-    constexpr bool SVC = SG == 1 && PXT == kStaticPXT;
+    constexpr bool SVC = SG >= 1 && PXT == kStaticPXT;
 #ifndef CD_SWEEP_SRC_STAGES
 #define CD_SWEEP_SRC_STAGES 1
 #endif
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
             else load_inputs<PXT>(v, l, more ? nx.p : -1, 0, nxt);
             if (SRC_STAGES) {      // the depth rows entering now were requested during the previous item; request the next ones
                 r.bad = !stage_rows<MODE, PXT, false>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;     // (pad columns: written by the prologue, constant)
-                load_stage_nosel<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
+                load_stage_nosel<PXT, NTD>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
             } else if (!SVC) {
                 r.bad = !stage_rows<MODE, PXT>(v, l, me.s_lo, me.s_hi, r.sv) || r.bad;
                 load_stage<PXT>(v, l, nx.s_lo, more ? nx.s_hi : nx.s_lo, r.sv);
@@ -551,7 +553,13 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
         __hip_atomic_store(out.disp + b, pp.lambda_b > 0.f ? (float)((double)pp.lambda_b * (qq[0] + qq[1]) * 0.5) : 0.f, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st.is_last = __hip_atomic_fetch_add(out.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == B - 1 ? 1 : 0;
+        // The finished-pairs counter lives in the workspace header and is zero BETWEEN calls: cd_consistency_loss_workspace_init zeroes it
+        // once, the workgroup that finishes last puts it back to zero (round 6: the per-call 4-byte fill was a dispatch of its own,
+        // 5-10 us in front of a 200 us kernel).  A workspace that was never initialised carries no magic word: every workgroup then
+        // reports a NaN mean loss instead of leaving a stale one behind.
+        const unsigned magic = __hip_atomic_load(&out.hdr->magic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st.is_last = __hip_atomic_fetch_add(&out.hdr->finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(B - 1) ? 1 : 0;
+        if (magic != kWorkspaceMagic) { out.total[0] = __builtin_nanf(""); st.is_last = 0; }
     }
     __syncthreads();
     if (st.is_last != 0) {
@@ -568,7 +576,10 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
             if ((int)threadIdx.x < s2) ld[threadIdx.x] += ld[threadIdx.x + s2];
             __syncthreads();
         }
-        if (threadIdx.x == 0) out.total[0] = (float)(ld[0] / (double)B);
+        if (threadIdx.x == 0) {
+            out.total[0] = (float)(ld[0] / (double)B);
+            __hip_atomic_store(&out.hdr->finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every workgroup of this launch has counted: ready for the next call
+        }
     }
 }
 
@@ -598,7 +609,13 @@ template <int MODE, bool REPROJ, int PXT>
 static int launch_sweep_inst(const SweepArgs& a, int B, size_t lds, hipStream_t s) {
     if (PXT == kStaticPXT && a.sh.g.H == kStaticH && a.sh.g.W == kStaticW && g_sweep_static_geo) {
         const Geo c = make_geo(kStaticH, kStaticW, kStaticPXT);
-        if (memcmp(&c, &a.sh.g, sizeof(Geo)) == 0 && static_geometry_holds(c)) return launch_sweep_sg<MODE, REPROJ, PXT, PXT == kStaticPXT ? 1 : 0>(a, B, lds, s);
+        if (memcmp(&c, &a.sh.g, sizeof(Geo)) == 0 && static_geometry_holds(c)) {
+            // depth rows: default cache policy while the launch's depth planes (2 per pair) fit the 256 MB Infinity Cache with room to
+            // spare (a 256-pair call: 176 MB), non-temporal beyond (loss_sweep_core.h, CD_SWEEP_NT)
+            if ((size_t)B * 2 * kStaticH * kStaticW * sizeof(float) > (size_t)200 << 20)
+                return launch_sweep_sg<MODE, REPROJ, PXT, PXT == kStaticPXT ? 2 : 0>(a, B, lds, s);
+            return launch_sweep_sg<MODE, REPROJ, PXT, PXT == kStaticPXT ? 1 : 0>(a, B, lds, s);
+        }
     }
     return launch_sweep_sg<MODE, REPROJ, PXT, 0>(a, B, lds, s);
 }
@@ -641,17 +658,15 @@ static const bool g_sweep_env_read = [] {
 int launch_sweep(const float* depth, const float* ff, const float* fb, const float* mf, const float* mb, void* cams,
                  const void* blob, int mode, bool reproj, int B, int H, int W, float* grad, void* ovf_mem, int ovf_cap, hipStream_t s,
                  void (*before)(hipStream_t), void (*after)(hipStream_t), const float* intr, const float* extr, const float* mask_sum,
-                 float lambda_r, float lambda_b, float* reproj_out, float* disp_out, float* total_out) {
+                 float lambda_r, float lambda_b, float* reproj_out, float* disp_out, float* total_out, WorkspaceHeader* hdr) {
     const Geo g = sweep_geo(H, W);
     if (!sweep_supported(H, W) || !intr || !extr || !mask_sum) return CD_ERR_UNSUPPORTED;
-    Overflow* ovf = (Overflow*)ovf_mem;
     unsigned* oidx = (unsigned*)((char*)ovf_mem + 256);
     float* oval = (float*)(oidx + ovf_cap);
     if (before) before(s);
-    if (hipMemsetAsync(&ovf->count, 0, sizeof(int), s) != hipSuccess) return CD_ERR_LAUNCH;     // the finished-pairs counter
     SweepArgs prm{depth, ff, fb, mf, mb, (PairCam*)cams, (const char*)blob, grad, oidx, oval, ovf_cap / B,
                   SweepShape{g, pair_record_bytes(H, W), plan_offset(H, W)}, PairPrep{intr, extr, mask_sum, lambda_r, lambda_b}, B,
-                  SweepOut{reproj_out, disp_out, total_out, &ovf->count}};
+                  SweepOut{reproj_out, disp_out, total_out, hdr}};
     const size_t lds = ring_lds_bytes(g);
     int rc;
     if (mode == CD_DEPTH_EXP) rc = launch_sweep_mode<CD_DEPTH_EXP>(reproj, prm, B, lds, s);

@@ -426,6 +426,41 @@ template <int N> CD_HD VecF<N> ldgv(const float* base, unsigned byte_off) {
 template <int N> CD_HD void stgv(float* base, unsigned byte_off, const VecF<N>& v) {
     *reinterpret_cast<VecF<N>*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+// ... the same for planes that are touched ONCE per call (flow, mask: read; gradient: written): non-temporal accesses keep them from
+// displacing the depth rows / plan records in L2 and the Infinity Cache.  (The host emulation has no cache policy.)
+// Measured (round 6, profiles/loss_sweep_variants_r06.txt; whole call, 256 / 1024 pairs, fraction of 8 TB/s): default policy 0.546 / 0.552,
+// flow + mask loads nt 0.553 / 0.554, gradient stores nt 0.560 / 0.569, both 0.616 / 0.578, depth rows too 0.588 / 0.602 -- the depth
+// planes of a 256-pair call (176 MB) survive in the 256 MB Infinity Cache when nothing else allocates there, those of 1024 pairs do
+// not: the depth policy is a template argument of the kernel (NTD), chosen by the launch size.
+#ifndef CD_SWEEP_NT
+#define CD_SWEEP_NT 3      // bit 0: flow / mask loads, bit 1: gradient stores, bit 2: depth rows of every instantiation (A/B builds)
+#endif
+template <int N> CD_HD VecF<N> ldgv_nt(const float* base, unsigned byte_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float vt __attribute__((ext_vector_type(N)));
+    const vt t = __builtin_nontemporal_load(reinterpret_cast<const vt*>(reinterpret_cast<const char*>(base) + byte_off));
+    VecF<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = t[i];
+    return r;
+#else
+    return ldgv<N>(base, byte_off);
+#endif
+}
+template <int N> CD_HD void stgv_nt(float* base, unsigned byte_off, const VecF<N>& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float vt __attribute__((ext_vector_type(N)));
+    vt t;
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = v.v[i];
+    __builtin_nontemporal_store(t, reinterpret_cast<vt*>(reinterpret_cast<char*>(base) + byte_off));
+#else
+    stgv<N>(base, byte_off, v);
+#endif
+}
+template <int N> CD_HD VecF<N> ldg_in(const float* base, unsigned byte_off) { return (CD_SWEEP_NT & 1) ? ldgv_nt<N>(base, byte_off) : ldgv<N>(base, byte_off); }
+template <int N, bool NTD = false> CD_HD VecF<N> ldg_depth(const float* base, unsigned byte_off) { return ((CD_SWEEP_NT & 4) || NTD) ? ldgv_nt<N>(base, byte_off) : ldgv<N>(base, byte_off); }
+template <int N> CD_HD void stg_grad(float* base, unsigned byte_off, const VecF<N>& v) { if (CD_SWEEP_NT & 2) stgv_nt<N>(base, byte_off, v); else stgv<N>(base, byte_off, v); }
 
 template <int PXT> struct Inputs { float fx[PXT], fy[PXT], m[PXT]; };   // flow and mask of the PXT source pixels of one pass
 
@@ -458,7 +493,7 @@ template <int PXT> CD_HD bool pass_row_ok(const View& v, const Lane<PXT>& l, int
 template <int PXT> CD_HD void load_inputs(const View& v, const Lane<PXT>& l, int p, int q, Inputs<PXT>& in) {
     const bool ok = pass_row_ok<PXT>(v, l, p, q);
     const unsigned off = ok ? ((unsigned)(p + q * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2 : 0u;
-    const VecF<PXT> a = ldgv<PXT>(v.flj, off), b = ldgv<PXT>(v.flj + v.HW, off), mm = ldgv<PXT>(v.mkj, off);
+    const VecF<PXT> a = ldg_in<PXT>(v.flj, off), b = ldg_in<PXT>(v.flj + v.HW, off), mm = ldg_in<PXT>(v.mkj, off);
 #pragma unroll
     for (int i = 0; i < PXT; ++i) { in.fx[i] = ok ? a.v[i] : 0.f; in.fy[i] = ok ? b.v[i] : 0.f; in.m[i] = ok ? mm.v[i] : 0.f; }
 }
@@ -470,7 +505,7 @@ template <int PXT> CD_HD void load_stage(const View& v, const Lane<PXT>& l, int 
         const int row = s_lo + s * v.RP + l.rr;
         const bool ok = l.on && row < s_hi && row < v.H;
         const unsigned off = ok ? ((unsigned)(s_lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2 : 0u;
-        const VecF<PXT> a = ldgv<PXT>(v.vj, off);
+        const VecF<PXT> a = ldg_depth<PXT>(v.vj, off);
 #pragma unroll
         for (int i = 0; i < PXT; ++i) sv[s][i] = ok ? a.v[i] : 0.f;
     }
@@ -478,7 +513,7 @@ template <int PXT> CD_HD void load_stage(const View& v, const Lane<PXT>& l, int 
 
 // ... the same without anything to select after the loads (clamped addresses; stage_rows only reads the values of rows it stages): the
 // compiler has no reason to wait for them before the stage of the NEXT item
-template <int PXT> CD_HD void load_stage_nosel(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, float (*sv)[PXT]) {
+template <int PXT, bool NTD = false> CD_HD void load_stage_nosel(const View& v, const Lane<PXT>& l, int s_lo, int s_hi, float (*sv)[PXT]) {
 #pragma unroll
     for (int s = 0; s < kStagePasses; ++s) {
         // an ordinary item moves its window by RP rows: the passes beyond the first are skipped by a WAVE-UNIFORM branch (the rows of
@@ -487,7 +522,7 @@ template <int PXT> CD_HD void load_stage_nosel(const View& v, const Lane<PXT>& l
         const int row = s_lo + s * v.RP + l.rr;
         const int rc = row < v.H ? row : v.H - 1;       // (a lane beyond s_hi reads a row it does not stage: in bounds, never used)
         const unsigned off = mad24((unsigned)rc, (unsigned)v.W << 2, l.x0 << 2);
-        const VecF<PXT> a = ldgv<PXT>(v.vj, off);
+        const VecF<PXT> a = ldg_depth<PXT, NTD>(v.vj, off);
 #pragma unroll
         for (int i = 0; i < PXT; ++i) sv[s][i] = a.v[i];
     }
@@ -558,7 +593,7 @@ CD_HD void flush_rows(const View& v, const Lane<PXT>& l, int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < PXT; ++i) g.v[i] = (float)(int)n.v[i] * unit;
             *ap = z;
-            stgv<PXT>(v.gradj, ((unsigned)(lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2, g);
+            stg_grad<PXT>(v.gradj, ((unsigned)(lo + s * v.RP) * (unsigned)v.W + l.rrW + l.x0) << 2, g);
             if (l.x0 == 0u)
                 for (int c = v.W; c < v.RW; ++c) {
                     v.Aj[base + (unsigned)c] = 0u;
@@ -606,7 +641,7 @@ template <int NQ> CD_HD void svc_load(const View& v, const SvcLane<NQ>& sl, int 
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         if (i * kSvcLanes >= nq) break;                          // wave-uniform
-        const VecF<4> a = ldgv<4>(srow, umin(sl.go[i], 16u * (unsigned)(nq - 1)));
+        const VecF<4> a = ldg_depth<4>(srow, umin(sl.go[i], 16u * (unsigned)(nq - 1)));
 #pragma unroll
         for (int e = 0; e < 4; ++e) q.v[i][e] = a.v[e];
     }
@@ -700,7 +735,7 @@ template <int NQ> CD_HD void svc_flush(const View& v, const SvcLane<NQ>& sl, int
             VecF<4> g;
             g.v[0] = (float)(int)n0[i].v[0] * unit; g.v[1] = (float)(int)n0[i].v[1] * unit;
             g.v[2] = (float)(int)n1[i].v[0] * unit; g.v[3] = (float)(int)n1[i].v[1] * unit;
-            stgv<4>(grow, sl.go[i], g);
+            stg_grad<4>(grow, sl.go[i], g);
         }
     }
 }
@@ -926,13 +961,13 @@ CD_HD bool fast_geometry_ok(const Geo& g) { return g.ok && g.PXT == 2 && g.G == 
 // compiler has no reason to wait for them before their first use one item later
 template <int PXT> CD_HD void load_inputs_goff(const View& v, unsigned goff, int p, Inputs<PXT>& in) {      // (goff = LaneF::goff)
     const unsigned off = (unsigned)p * ((unsigned)v.W << 2) + goff;
-    const VecF<PXT> a = ldgv<PXT>(v.flj, off), b = ldgv<PXT>(v.flj + v.HW, off), mm = ldgv<PXT>(v.mkj, off);
+    const VecF<PXT> a = ldg_in<PXT>(v.flj, off), b = ldg_in<PXT>(v.flj + v.HW, off), mm = ldg_in<PXT>(v.mkj, off);
 #pragma unroll
     for (int i = 0; i < PXT; ++i) { in.fx[i] = a.v[i]; in.fy[i] = b.v[i]; in.m[i] = mm.v[i]; }
 }
 template <int PXT> CD_HD void load_inputs_all(const View& v, const LaneF<PXT>& lf, int p, Inputs<PXT>& in) {
     const unsigned off = (unsigned)p * ((unsigned)v.W << 2) + lf.goff;
-    const VecF<PXT> a = ldgv<PXT>(v.flj, off), b = ldgv<PXT>(v.flj + v.HW, off), mm = ldgv<PXT>(v.mkj, off);
+    const VecF<PXT> a = ldg_in<PXT>(v.flj, off), b = ldg_in<PXT>(v.flj + v.HW, off), mm = ldg_in<PXT>(v.mkj, off);
 #pragma unroll
     for (int i = 0; i < PXT; ++i) { in.fx[i] = a.v[i]; in.fy[i] = b.v[i]; in.m[i] = mm.v[i]; }
 }

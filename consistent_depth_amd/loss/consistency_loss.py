@@ -61,15 +61,17 @@ def _launch(depth, flow_fwd, flow_bwd, mask_fwd, mask_bwd, msum, twin, intr, ext
                            ("intrinsics", intr, (B, 2, 4)), ("extrinsics", extr, (B, 2, 3, 4))):
         if tuple(t.shape) != shape:
             raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
-    ws_bytes = lib.cd_consistency_loss_workspace_bytes(B, H, W)
-    ws = _native.workspace("consistency_loss", ws_bytes, dev)
-    out = torch.empty(2 * B + 1, dtype=torch.float32, device=dev)
-    reproj, disp, total = out[:B], out[B:2 * B], out[2 * B:]
     args = [_native.dev_ptr(depth, "depths"), _native.dev_ptr(flow_fwd, "flows[0]"),
             _native.dev_ptr(flow_bwd, "flows[1]"), _native.dev_ptr(mask_fwd, "masks[0]"),
             _native.dev_ptr(mask_bwd, "masks[1]"), _native.dev_ptr(msum, "mask_sums") if msum is not None else None]
-    tail = [_native.dev_ptr(intr, "intrinsics"), _native.dev_ptr(extr, "extrinsics"),
-            float(lambda_r), float(lambda_b), int(mode), B, H, W,
+    intr_p, extr_p = _native.dev_ptr(intr, "intrinsics"), _native.dev_ptr(extr, "extrinsics")     # (every operand is checked before anything is allocated)
+    ws_bytes = lib.cd_consistency_loss_workspace_bytes(B, H, W)
+    # (ABI 9: a loss workspace is initialised ONCE after allocation -- its header holds the row sweep's finished-workgroup counter)
+    ws = _native.workspace("consistency_loss", ws_bytes, dev, on_new=lambda buf: _native.check(
+        lib.cd_consistency_loss_workspace_init(buf.data_ptr(), buf.numel(), _native.stream_ptr(dev)), "cd_consistency_loss_workspace_init"))
+    out = torch.empty(2 * B + 1, dtype=torch.float32, device=dev)
+    reproj, disp, total = out[:B], out[B:2 * B], out[2 * B:]
+    tail = [intr_p, extr_p, float(lambda_r), float(lambda_b), int(mode), B, H, W,
             reproj.data_ptr(), disp.data_ptr(), total.data_ptr()]
     if want_grad:
         grad = torch.empty_like(depth)

@@ -47,9 +47,10 @@ typedef enum cd_depth_mode {
 /* ABI version, bumped on any change of an exported signature, of the meaning of an argument, or of the export list
  * (6: cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped / cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table /
  * cd_conv2d_fwd_multi added, cd_bn_relu_bwd's last
- * argument became a flags bitfield, cd_debug_set_loss_variant(2) is refused).
+ * argument became a flags bitfield, cd_debug_set_loss_variant(2) is refused;
+ * 9: cd_consistency_loss_workspace_init added -- a loss workspace must be initialised once before its first use).
  * The loader (consistent_depth_amd/_native.py) refuses a library whose cd_abi_version() differs from this constant. */
-#define CD_ABI_VERSION 8
+#define CD_ABI_VERSION 9
 int cd_abi_version(void);
 
 /* Batch-statistics buffers (the `stats` arguments below) hold CD_BN_STAT_SLOTS partial copies:
@@ -68,6 +69,14 @@ const char* cd_build_info(void);
 
 /* Bytes of scratch the loss entry points need for a batch of B pairs of HxW frames. */
 size_t cd_consistency_loss_workspace_bytes(int B, int H, int W);
+/* ABI 9.  A loss workspace carries a 256-byte header at its start whose contents OUTLIVE a call (the finished-workgroup counter of the
+ * row-sweep gradient kernel: the workgroup that finishes last puts it back to zero, so a call needs no reset dispatch of its own).
+ * Call this ONCE after allocating (or re-allocating) a workspace, on the stream of the loss calls that follow or synchronised with it,
+ * before the first cd_consistency_loss_fwd_bwd / _fwd on it; the same workspace may then serve any (B, H, W) that fits it, one call at a
+ * time.  A gradient call on a workspace that was never initialised reports total = NaN (never a stale number).  Re-initialise after a
+ * call that was aborted (device reset).  Enqueues two 4-byte fills; capturable.  (Replaces nothing in the reference: torch's
+ * allocator zero-fills nothing either -- this is the price of keeping per-call state out of the entry point.) */
+int cd_consistency_loss_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
 /* Per-pair, per-direction mask sums S[b,k] = sum(mask_k[b])  (weighted_mean_loss,
  * loss/consistency_loss.py:85).  They depend only on the dataset, so a caller may

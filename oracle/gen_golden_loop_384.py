@@ -266,18 +266,19 @@ def _rel(a, b):
     return float(np.abs(a - b).sum() / max(np.abs(b).sum(), 1e-300))
 
 
-def distances(got, z, epochs):
+def distances(got, z, epochs, prefix=""):
     """Relative-L1 distance of every artefact of `got` to the golden `z`, per epoch: the rows of profiles/parity_20ep_r05.txt and the
-    quantities tests/test_loop_gpu.py bounds."""
+    quantities tests/test_loop_gpu.py bounds.  prefix = "ref32_": against the artefacts of the reference's OWN arithmetic (the fp32 CPU
+    continuation stored next to the fp64 ones since round 6) -- the comparison BASELINE.json literally names."""
     rows = {}
     for e in epochs:
         rows[int(e)] = {
-            "mean": _rel(got[f"val_e{e}_mean"], z[f"val_e{e}_mean"]),
-            "perpair": max(_rel(got[f"val_e{e}_{p}"], z[f"val_e{e}_{p}"]) for p in ("reprojection", "disparity")),
-            "perpair_max": float(max(np.abs(np.asarray(got[f"val_e{e}_{p}"], np.float64) - z[f"val_e{e}_{p}"]).max()
-                                     / np.abs(z[f"val_e{e}_{p}"]).mean() for p in ("reprojection", "disparity"))),
-            "evaldepth": _rel(got[f"evaldepth_e{e}"], z[f"evaldepth_e{e}"]),
-            "ckpt": _rel(got[f"ckpt_e{e}"], z[f"ckpt_e{e}"]),
+            "mean": _rel(got[f"val_e{e}_mean"], z[f"{prefix}val_e{e}_mean"]),
+            "perpair": max(_rel(got[f"val_e{e}_{p}"], z[f"{prefix}val_e{e}_{p}"]) for p in ("reprojection", "disparity")),
+            "perpair_max": float(max(np.abs(np.asarray(got[f"val_e{e}_{p}"], np.float64) - z[f"{prefix}val_e{e}_{p}"]).max()
+                                     / np.abs(z[f"{prefix}val_e{e}_{p}"]).mean() for p in ("reprojection", "disparity"))),
+            "evaldepth": _rel(got[f"evaldepth_e{e}"], z[f"{prefix}evaldepth_e{e}"]),
+            "ckpt": _rel(got[f"ckpt_e{e}"], z[f"{prefix}ckpt_e{e}"]),
         }
     return rows
 
@@ -331,17 +332,20 @@ def stage_crosscheck(spec, src):
 
 
 def stage_ref32(spec, src):
-    """The YARDSTICK: the same continuation in the reference's own arithmetic (fp32 on the CPU) -- how far the reference is from its
-    fp64 self on every artefact.  Stored next to the fp64 golden as `ref32dist_<artefact>` (distances only: the fp32 artefacts
-    themselves are one realisation of round-off and nothing is compared with them)."""
+    """The reference's OWN arithmetic: the same continuation in fp32 on the CPU (torch's CPU kernels, the path BASELINE.json names).
+    Stored next to the fp64 golden: `ref32dist_<artefact>` = its distance to the fp64 run (the yardstick of rounds 4-5) and, since round
+    6, the ARTEFACTS themselves as `ref32_<artefact>` (sampled like the fp64 ones), so that the product can be compared with the
+    reference path DIRECTLY (tests/test_loop_gpu.py, third column; tools/parity_decompose.py)."""
     res, cs, _ = _cpu_run(spec, src, torch.float32)
     out = golden_path(spec)
     z = dict(np.load(out))
     for name, v in cs.items():
         assert np.array_equal(v, z["checksum_" + name]), name
+    assert [int(e) for e in res["epochs"]] == [int(e) for e in z["epochs"]], (res["epochs"], z["epochs"])
     for k, v in res.items():
         if v.dtype.kind == "f" and k in z and z[k].shape == v.shape:
             z["ref32dist_" + k] = np.array(_rel(v, z[k]))
+            z["ref32_" + k] = v.astype(np.float32) if v.size > 4096 else v
             print(f"[{spec}] reference fp32 vs fp64  {k:24s} {float(z['ref32dist_' + k]):.3e}")
     for e in z["epochs"]:      # the per-pair maximum, like distances()
         if f"val_e{e}_reprojection" in res:

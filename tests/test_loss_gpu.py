@@ -436,3 +436,52 @@ def test_chunked_launches_are_bit_identical(torch_cuda):
     np.testing.assert_array_equal(one[1], three[1])
     np.testing.assert_array_equal(one[2], three[2])
     np.testing.assert_array_equal(one[3], three[3])
+
+
+def _raw_fwd_bwd(torch, d, ws, lr=1.0, lb=0.1):
+    """cd_consistency_loss_fwd_bwd on a caller-owned workspace (row sweep forced), straight through ctypes."""
+    from consistent_depth_amd import _native
+    lib = _native.lib()
+    depth = d["depth"].contiguous()
+    B, _, H, W = depth.shape
+    out = torch.zeros(2 * B + 1, device=depth.device)
+    grad = torch.empty_like(depth)
+    rc = lib.cd_consistency_loss_fwd_bwd(depth.data_ptr(), d["flows"][0].data_ptr(), d["flows"][1].data_ptr(), d["masks"][0].data_ptr(),
+                                         d["masks"][1].data_ptr(), None, None, d["intrinsics"].data_ptr(), d["extrinsics"].data_ptr(),
+                                         lr, lb, 0, B, H, W, out[:B].data_ptr(), out[B:2 * B].data_ptr(), out[2 * B:].data_ptr(),
+                                         grad.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(depth.device))
+    assert rc == 0
+    return out, grad
+
+
+def test_sweep_workspace_header(torch_cuda, variant):
+    """ABI 9: the row sweep keeps its finished-workgroup counter in the workspace header BETWEEN calls (the workgroup that finishes last
+    puts it back to zero; no per-call reset dispatch).  (1) A workspace that was never initialised gives total = NaN, not a stale
+    number; (2) after cd_consistency_loss_workspace_init the same buffer serves calls of DIFFERENT batch sizes back to back, `total` is
+    the mean of the per-pair losses every time and the counter is zero after every call.  (The advisor's stress test of the fence-free
+    hand-off of the per-pair losses: 60 launches.)"""
+    torch = torch_cuda
+    from consistent_depth_amd import _native, synthetic
+    if variant != 4:
+        pytest.skip("the header is the row sweep's")
+    lib = _native.lib()
+    H, W = 64, 96
+    batches = {B: to_dev(synthetic.make_scene_batch(B, H, W, seed=20 + B), torch) for B in (7, 3, 12)}
+    ws = torch.full((lib.cd_consistency_loss_workspace_bytes(12, H, W),), 0x5a, dtype=torch.uint8, device="cuda")
+    out, _ = _raw_fwd_bwd(torch, batches[7], ws)
+    torch.cuda.synchronize()
+    assert torch.isnan(out[-1]), "an uninitialised workspace must not report a mean loss"
+    assert lib.cd_consistency_loss_workspace_init(ws.data_ptr(), ws.numel(), _native.stream_ptr(ws.device)) == 0
+    hdr = ws[:8].view(torch.int32)
+    ref = {}
+    for it in range(60):
+        B = (7, 3, 12)[it % 3]
+        out, grad = _raw_fwd_bwd(torch, batches[B], ws)
+        torch.cuda.synchronize()
+        assert int(hdr[1]) == 0, (it, B, int(hdr[1]))
+        per_pair = (out[:B].double() + out[B:2 * B].double()).mean().item()
+        assert abs(out[-1].item() - per_pair) <= 2e-7 * abs(per_pair), (it, B, out[-1].item(), per_pair)
+        if B in ref:        # integer accumulation: every repeat is bitwise the first call
+            assert torch.equal(ref[B][0], out) and torch.equal(ref[B][1], grad), (it, B)
+        else:
+            ref[B] = (out.clone(), grad.clone())
