@@ -217,6 +217,9 @@ extern "C" int cd_bn_block_fwd(const float* x, const float* gamma, const float* 
                                double* stats, int C, int N, int H, int W, void* stream) {
     CD_ARGCHK(x && y && mean_invstd && scale && shift && stats && C > 0 && N > 0 && H > 0 && W > 0 && C <= 65535 && N <= 65535);
     CD_ARGCHK((gamma == nullptr) == (beta == nullptr) && (running_mean == nullptr) == (running_var == nullptr));
+    // the kernels move 16 bytes per lane when H*W % 4 == 0: planes then start on 16-byte boundaries only if the tensors do (a contiguous
+    // VIEW with an odd storage offset does not; the Python face re-homes such tensors, a C caller gets an error instead of a fault)
+    CD_ARGCHK(((H * W) & 3) != 0 || ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0));
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
     if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)C * CD_BN_STAT_SLOTS, s) != hipSuccess) return CD_ERR_LAUNCH;
@@ -233,6 +236,7 @@ extern "C" int cd_bn_block_bwd(const float* dy, const float* x, const float* y, 
                                float* dx, float* dres, float* dgamma, float* dbeta, double* sums, int C, int N, int H, int W, void* stream) {
     CD_ARGCHK(dy && x && mean_invstd && dx && sums && (y || !relu) && C > 0 && N > 0 && H > 0 && W > 0 && C <= 65535 && N <= 65535);
     CD_ARGCHK((dgamma == nullptr) == (dbeta == nullptr));
+    CD_ARGCHK(((H * W) & 3) != 0 || ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0));     // (as cd_bn_block_fwd)
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) return CD_ERR_LAUNCH;

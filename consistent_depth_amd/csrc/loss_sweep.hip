@@ -99,6 +99,22 @@ __global__ __launch_bounds__(kBlock) void sweep_plan_kernel(const float* __restr
         }
     }
     lo_i[threadIdx.x] = fmax;          // (lo_i is free now: block-wide max through it)
+    // the fingerprint of the flows / masks this plan belongs to (loss_sweep_core.h, plan_fingerprint_term)
+    if (threadIdx.x == 0) hi_i[0] = 0;
+    __syncthreads();
+    {
+        unsigned h = 0u;
+        for (int i = threadIdx.x; i < 2 * kUnitGrid * kUnitGrid; i += kBlock) {
+            const int j = i / (kUnitGrid * kUnitGrid);
+            int sx, sy;
+            unit_sample_xy(g.H, g.W, i - j * kUnitGrid * kUnitGrid, &sx, &sy);
+            const float* fl = (j == 0 ? flow_fwd : flow_bwd) + (size_t)b * 2 * HW;
+            const float* mk = (j == 0 ? mask_fwd : mask_bwd) + (size_t)b * HW;
+            const int p = sy * g.W + sx;
+            h += plan_fingerprint_term(i, mk[p], fl[p], fl[HW + p]);
+        }
+        atomicAdd(reinterpret_cast<unsigned*>(&hi_i[0]), h);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int fan_in = 0;
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void sweep_plan_kernel(const float* __restr
         if (n > 0 && fan_in > SWEEP_MAX_FAN_IN) n = -3;     // a 32-bit accumulator could wrap: no plan, the exact fallback path
         if (n > 0) expand_plan(g, items, n, reinterpret_cast<PlanItem*>(ph + 1), lo_s, hi_s);
         ph->n_items = n; ph->G = g.G; ph->R = g.R; ph->PXT = g.PXT;
-        ph->fan_in = fan_in; ph->limit = sweep_limit_scaled(fan_in); ph->pad[0] = ph->pad[1] = 0;
+        ph->fan_in = fan_in; ph->limit = sweep_limit_scaled(fan_in); ph->fingerprint = (unsigned)hi_i[0]; ph->pad = 0;
     }
 }
 
@@ -146,6 +162,7 @@ struct WgState {           // in LDS (the `red` scratch behind the rings)
     float fbar[2];
     float red4[8];
     float prep_in[34];     // the pair's intrinsics [2][4], extrinsics [2][3][4], mask sums [2] (pair_constants)
+    unsigned fingerprint;  // of the flows / masks of THIS call at the unit-sample positions (cf. PlanHeader::fingerprint)
 };
 static_assert(sizeof(WgState) <= kLdsReserve, "WgState must fit the LDS reserve behind the rings");
 
@@ -256,9 +273,19 @@ __device__ __forceinline__ void pair_constants(WgState& st, float* scratch, cons
     u.direct = u.scatter = 0.f; u.valid = 0;
     if (t < 2 * NS) u = unit_sample_eval<MODE>(st.cam[t / NS], ul, sx, sy);
     const float wd = wave_sum(u.direct), ws = wave_sum(u.scatter), wn = wave_sum((float)u.valid);
-    if (t < 2 * NS && lane == 0) { scratch[wid * 3] = wd; scratch[wid * 3 + 1] = ws; scratch[wid * 3 + 2] = wn; }
+    // the call's fingerprint (plan_fingerprint_term over the same 2 x 256 samples; waves 0..7 hold them): an integer sum, any order
+    unsigned fpw = t < 2 * NS ? plan_fingerprint_term(t, ul.m, ul.fx, ul.fy) : 0u;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) fpw += (unsigned)__shfl_xor((int)fpw, o, kWave);
+    if (t < 2 * NS && lane == 0) {
+        scratch[wid * 3] = wd; scratch[wid * 3 + 1] = ws; scratch[wid * 3 + 2] = wn;
+        reinterpret_cast<unsigned*>(scratch)[3 * (2 * NS / kWave) + wid] = fpw;
+    }
     __syncthreads();
     if (t == 0) {
+        unsigned fp = 0u;
+        for (int w = 0; w < 2 * NS / kWave; ++w) fp += reinterpret_cast<const unsigned*>(scratch)[3 * (2 * NS / kWave) + w];
+        st.fingerprint = fp;
         float D[2] = {0.f, 0.f}, S[2] = {0.f, 0.f};
         int n[2] = {0, 0};
         for (int j = 0; j < 2; ++j)
@@ -374,6 +401,10 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
     // no plan (the planner's item backstop, a fan-in beyond the accumulators' range), or one made for another geometry
     // (cd_debug_set_loss_sweep changed after the blob was cached): this pair cannot be swept -> the exact mode below.  Workgroup-uniform.
     const bool has_plan = !(n_items <= 0 || ph->G != g.G || ph->R != g.R || ph->PXT != g.PXT);
+    // ... or one made from OTHER flows / masks (a stale or foreign tile_windows blob): its items still describe a valid order of the
+    // rows, but their `inw` promises are not believed -- the general source pass clamps and votes (round 5's build computed silently
+    // wrong gradients there).  Wave-uniform.
+    const bool trust_inw = uni((int)(ph->fingerprint == st.fingerprint)) != 0;
     unsigned* oidx = oidx_all + (size_t)b * seg_cap;
     float* oval = oval_all + (size_t)b * seg_cap;
     __syncthreads();       // (pair_constants' scratch is free: the rings can be cleared)
@@ -481,7 +512,7 @@ __global__ __launch_bounds__(kThreads) void loss_sweep_kernel(
                 flush_rows<PXT>(v, l, me.fl_lo, me.fl_hi);
             }
             if constexpr (FAST) {
-                if (me.p >= 0) process_rows_fast<MODE, REPROJ, PXT>(v, cf, env, r, l, lf, cur, me.p, wk, nvk, me.inw != 0);     // wave-uniform branch
+                if (me.p >= 0) process_rows_fast<MODE, REPROJ, PXT>(v, cf, env, r, l, lf, cur, me.p, wk, nvk, me.inw != 0 && trust_inw);     // wave-uniform branch
             } else process_rows<MODE, REPROJ, PXT>(v, env, r, l, cur, me.p, 0, wk, nvk);
             __syncthreads();
             me = nx; wk = nwk; nvk = nnvk;

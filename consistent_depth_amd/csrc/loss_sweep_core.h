@@ -204,7 +204,9 @@ struct Rec {
 };
 static_assert(sizeof(Rec) == 48, "Rec layout");
 struct PlanItem { Rec f[2]; };
-struct PlanHeader { int n_items, G, R, PXT; int fan_in; float limit; int pad[2]; };   // fan_in: max sources per target pixel; limit: sweep_limit_scaled(fan_in)
+// fan_in: max sources per target pixel; limit: sweep_limit_scaled(fan_in); fingerprint: plan_fingerprint_term summed over the 2 x 256
+// unit-sample positions of the flows / masks the plan was made from (0 in plans no device kernel made: the host emulation's)
+struct PlanHeader { int n_items, G, R, PXT; int fan_in; float limit; unsigned fingerprint; int pad; };
 static_assert(sizeof(PlanHeader) == 32, "PlanHeader layout");
 CD_HD size_t plan_bytes(const Geo& g) { return sizeof(PlanHeader) + sizeof(PlanItem) * (size_t)g.max_items; }
 
@@ -352,6 +354,19 @@ CD_HD UnitSample unit_sample_at(const PairCam* cams, const float* depth_p, const
     return unit_sample_eval<MODE>(cams[j], unit_sample_load(depth_p + (j ? HW : 0), depth_p + (j ? 0 : HW), j ? fb : ff, j ? mb : mf, H, W, x, y), x, y);
 }
 // (the kernel's two steps of unit_sample_at)
+// A plan's statements (Rec::inw: "every tap of this row group's valid sources lies in resident rows") hold for the flows and masks it
+// was made from.  Round 5's fast source pass TRUSTS inw (no clamp, no vote): a blob that belongs to other flows / masks would give
+// silently wrong gradients.  The plan therefore carries a fingerprint -- the sum (mod 2^32: order-free) of this term over the 2 x 256
+// positions the sweep kernel samples anyway for its accumulator units -- which the sweep recomputes from the flows / masks it is
+// given; on a mismatch no item's inw is believed (the general pass: slower, exact).  i = direction * 256 + sample index.
+CD_HD unsigned plan_fingerprint_term(int i, float m, float fx, float fy) {
+    union { float f; unsigned u; } a, b, c;
+    a.f = m; b.f = fx; c.f = fy;
+    unsigned h = (a.u * 0x9E3779B1u) ^ (b.u * 0x85EBCA77u) ^ ((c.u << 13) | (c.u >> 19));
+    h = (h ^ (unsigned)i) * 0xC2B2AE3Du;
+    return h ^ (h >> 15);
+}
+
 CD_HD void unit_sample_xy(int H, int W, int t, int* x, int* y) {
     const int iy = t / kUnitGrid, ix = t - iy * kUnitGrid;
     *x = (2 * ix + 1) * W / (2 * kUnitGrid); *y = (2 * iy + 1) * H / (2 * kUnitGrid);

@@ -105,6 +105,25 @@ class DepthFineTuner:
         net = self.model.netG if hasattr(self.model, "netG") else self.model.model
         load_state_dict_any_prefix(net, state_dict)
         names = [n for n, _ in net.named_parameters()]
+        for what, d in (("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+            missing, extra = [n for n in names if n not in d], [n for n in d if n not in set(names)]
+            if missing or extra:
+                raise ValueError(f"resume_from: {what} must hold exactly the model's named parameters "
+                                 f"(missing {missing[:3]}{'...' if len(missing) > 3 else ''}, unknown {extra[:3]}{'...' if len(extra) > 3 else ''})")
+            shapes = {n: tuple(p.shape) for n, p in net.named_parameters()}
+            bad = [n for n in names if tuple(d[n].shape) != shapes[n]]
+            if bad:
+                raise ValueError(f"resume_from: {what}[{bad[0]!r}] has shape {tuple(d[bad[0]].shape)}, the parameter {shapes[bad[0]]}")
+        if min(int(adam_steps), int(epoch), int(total_iters)) < 0:
+            raise ValueError("resume_from: adam_steps, epoch and total_iters are counts (>= 0)")
+        # the three counters of one run are tied together when no step was skipped (NaN guard): epoch * steps-per-epoch optimiser steps and
+        # epoch * len(dataset) pairs.  A mismatch is legal (skipped steps lower both) but never an EXCESS -- that renames the validation files.
+        n_pairs = len(self.store) if self.store is not None else None
+        if n_pairs is not None and self.world == 1:
+            per_epoch = -(-n_pairs // self.params.batch_size)
+            if int(total_iters) > int(epoch) * n_pairs or int(adam_steps) > int(epoch) * per_epoch:
+                raise ValueError(f"resume_from: epoch {epoch} of {n_pairs} pairs (batch {self.params.batch_size}) allows at most "
+                                 f"total_iters {int(epoch) * n_pairs} and adam_steps {int(epoch) * per_epoch}, got {total_iters} / {adam_steps}")
         self._resume = dict(m1=[exp_avg[n] for n in names], m2=[exp_avg_sq[n] for n in names], steps=int(adam_steps),
                             epoch=int(epoch), total_iters=int(total_iters))
 

@@ -143,6 +143,14 @@ def _clone_tree(metadata):
     return metadata
 
 
+def _store_key(store, pair_ids):
+    """What a captured graph's static buffers depend on, for BOTH graph caches: the store's resident buffers (the caching allocator hands a
+    freed block's address to the next allocation, and a collected store's id() can be reused: neither alone identifies a store), its
+    geometry and size stated explicitly, the record width (PairStore.rebuild_masks changes it) and the batch size."""
+    return (id(store), int(store.color.data_ptr()), int(store.flows.data_ptr()), tuple(store.color.shape), len(store),
+            int(store.tile_windows.shape[1]), int(pair_ids.numel()))
+
+
 class GraphedFineTuneStep:
     """A FineTuneStep replayed from a HIP graph.
 
@@ -223,7 +231,7 @@ class GraphedFineTuneStep:
         """Like FineTuneStep.step_from_store; once the graph of this batch shape exists the pairs are gathered STRAIGHT into
         its static input buffers (no intermediate batch, no copies) and the graph is replayed."""
         # (the record width is part of the key: PairStore.rebuild_masks changes it, and a stale graph's static buffers with it)
-        skey = (id(store), int(pair_ids.numel()), int(store.tile_windows.shape[1]))
+        skey = _store_key(store, pair_ids)
         key = self._store_sig.get(skey)
         g = self._graphs.get(key) if key is not None else None
         if g is None:
@@ -269,7 +277,7 @@ class GraphedEvaluate:
         output buffers: consume them (copy, reduce, hand to the writer) before the next call overwrites them."""
         # keyed by the store's resident colour buffer (an address that lives as long as the store's data), not by id(store): a
         # collected store's id can be reused by a new one, whose geometry only coincidentally matches a stale graph
-        key = (int(store.color.data_ptr()), int(store.flows.data_ptr()), int(pair_ids.numel()), int(store.tile_windows.shape[1]))
+        key = _store_key(store, pair_ids)
         g = self._graphs.get(key)
         if g is None:
             n = self._seen.get(key, 0)

@@ -26,7 +26,10 @@ def _o(t):
 def _chk(x, name):
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         raise RuntimeError(f"{name}: fp32 (N, C, H, W) tensors on the HIP device (no CPU path)")
-    return x.contiguous()
+    x = x.contiguous()
+    if x.data_ptr() % 16:      # a contiguous view at an odd storage offset: the kernels move 16 bytes per lane (cd_bn_block_* / cd_eltwise refuse it)
+        x = x.clone()
+    return x
 
 
 class _BnAct(torch.autograd.Function):
@@ -40,10 +43,17 @@ class _BnAct(torch.autograd.Function):
         mi = torch.empty(C, 2, dtype=torch.float32, device=dev)
         scratch = torch.empty(2 * C, dtype=torch.float32, device=dev)
         stats = torch.empty(_native.BN_STAT_SLOTS * C * 2, dtype=torch.float64, device=dev)
-        momentum = bn.momentum if bn.momentum is not None else 0.1
         track = bn.track_running_stats and bn.running_mean is not None
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
+        if bn.momentum is not None:
+            momentum = bn.momentum
+        elif track and bn.num_batches_tracked is not None:
+            # nn.BatchNorm2d(momentum=None): the CUMULATIVE moving average, factor 1 / num_batches_tracked after the increment
+            # (torch/nn/modules/batchnorm.py).  One host read per forward: only this unusual configuration pays it.
+            momentum = 1.0 / float(bn.num_batches_tracked.item())
+        else:
+            momentum = 0.0
         rc = _native.lib().cd_bn_block_fwd(_p(x), _o(gamma), _o(beta), _o(res), int(relu), _o(bn.running_mean) if track else None,
                                            _o(bn.running_var) if track else None, float(momentum), float(bn.eps), _p(y), _p(mi),
                                            _p(scratch[:C]), _p(scratch[C:]), stats.data_ptr(), C, N, H, W, _native.stream_ptr(dev))
@@ -55,7 +65,7 @@ class _BnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, mi = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = _chk(dy, "bn_act backward")
         N, C, H, W = x.shape
         dev = x.device
         dx = torch.empty_like(x)

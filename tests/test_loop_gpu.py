@@ -320,6 +320,8 @@ def test_config1_torch_convs_hip_loss_from_the_same_snapshot(tmp_path, monkeypat
     ft = DepthFineTuner(range_dir, list(range(S["clip"]["n_frames"])), params)
     assert ft.model.backend == "torch" and ft.model._engine is None
     n_pairs = len(z["pair_order"])
+    with pytest.raises(ValueError, match="exp_avg_sq must hold exactly"):       # (a moment dict that does not cover the parameters: a clear error)
+        ft.resume_from(snap["state"], snap["m1"], {k: v for i, (k, v) in enumerate(snap["m2"].items()) if i}, snap["k"], epoch=K, total_iters=K * n_pairs)
     ft.resume_from(snap["state"], snap["m1"], snap["m2"], snap["k"], epoch=K, total_iters=K * n_pairs)
     want_plans = json.loads(str(z["plans"]))
     pair_id = {tuple(p): i for i, p in enumerate(z["pair_order"].tolist())}

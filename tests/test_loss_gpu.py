@@ -218,6 +218,41 @@ def test_stale_plan_falls_back_to_the_exact_path(torch_cuda, oracle):
         lib.cd_debug_set_loss_variant(0)
 
 
+def test_foreign_tile_windows_degrade_to_the_general_pass(torch_cuda, oracle):
+    """A tile_windows blob that belongs to OTHER flows / masks of the same shape (a caller's cache gone stale): the row-sweep plan's
+    promise "the taps of this row group's valid sources are resident" (Rec::inw, trusted by round 5's fast source pass without clamp or
+    vote) does not hold for the flows of the call.  Round 6: the plan carries a fingerprint of the flows / masks it was made from, the
+    sweep kernel recomputes it from the samples it reads anyway and, on a mismatch, believes no inw -- the general pass routes taps
+    outside the rings through the overflow list: the gradient is the oracle's, as it was before the fast pass existed."""
+    from consistent_depth_amd import _native, synthetic
+    from consistent_depth_amd.loss import consistency_loss as CL
+    torch = torch_cuda
+    lib = _native.lib()
+    H, W = 384, 224
+    a = to_dev(synthetic.make_scene_batch(2, H, W, seed=3), torch)
+    batch = synthetic.make_pair_batch(2, H, W, seed=8)          # unrelated depth per frame: flows with a wide vertical spread
+    d = to_dev(batch, torch)
+    foreign = CL.tile_windows(a["flows"], a["masks"])
+    own = CL.tile_windows(d["flows"], d["masks"])
+    ref = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], 1.0, 0.1, dtype=np.float64)
+    r32 = oracle.consistency_loss(batch["depth"], batch["flows"], batch["masks"], batch["intrinsics"], batch["extrinsics"], 1.0, 0.1, dtype=np.float32)
+    assert lib.cd_debug_set_loss_variant(4) == 0
+    try:
+        res = {}
+        for name, blob in (("own", own), ("foreign", foreign)):
+            depth = d["depth"].clone().requires_grad_(True)
+            total, _, _ = CL.consistency_loss(depth, d["flows"], d["masks"], d["intrinsics"], d["extrinsics"], 1.0, 0.1, tile_windows=blob)
+            total.backward()
+            res[name] = (total.item(), oracle.rel_l1(depth.grad.cpu().numpy(), ref["grad_depth"]))
+    finally:
+        lib.cd_debug_set_loss_variant(0)
+    report("foreign_tile_windows", own_grad_rel_l1=res["own"][1], foreign_grad_rel_l1=res["foreign"][1],
+           ref_fp32_grad_rel_l1=oracle.rel_l1(r32["grad_depth"], ref["grad_depth"]))
+    for name, (total, dist) in res.items():
+        np.testing.assert_allclose(total, ref["total"][0], rtol=LOSS_RTOL)
+        assert dist < grad_tol(oracle.rel_l1(r32["grad_depth"], ref["grad_depth"])), (name, dist)
+
+
 @pytest.mark.parametrize("force", [0, 3], ids=["default_dispatch", "slab_chunked"])
 def test_roofline_launch_vs_oracle(torch_cuda, oracle, force):
     """The launch bench.py's roofline number is taken on -- B = 256 pairs of 384x224 in ONE call (0.88 GB, beyond the
