@@ -32,7 +32,7 @@
 #include "cd_common.h"
 #include "conv_split.h"
 
-#ifndef CD_SP_DBG        // measurement builds (tools/exp/build_variants.sh): 1 = no MFMA phase, 2 = no staging (profiles/conv_phases_r03.txt)
+#ifndef CD_SP_DBG        // measurement builds (tools/exp/build_variants.sh): 1 = no MFMA phase, 2 = no staging (profiles/conv_phases_r03.txt), 4 = staging without its global loads
 #define CD_SP_DBG 0
 #endif
 
@@ -240,6 +240,12 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
         const int gy = Y0 - P + r, gx = X0 - PADL + q4;
         const bool row_in = (unsigned)gy < (unsigned)H;
         const int gyc = row_in ? gy : 0;
+        if (CD_SP_DBG & 4) {       // what-if: the staging's arithmetic and LDS writes without its memory round trip (wrong results)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { sc[c] = 1.f; sh[c] = 0.f; v[c][0] = v[c][1] = v[c][2] = v[c][3] = __int_as_float(0x3f800000 + u + c + gy); }
+            keep[0] = keep[1] = keep[2] = keep[3] = 0xffffffffu;
+            return;
+        }
         if (vec_in) {       // W % 4 == 0: an aligned quad is inside or outside the image as a whole
             const bool in = row_in && (unsigned)gx < (unsigned)W;
             const float* src = xin + (size_t)gyc * W + (in ? gx : 0);

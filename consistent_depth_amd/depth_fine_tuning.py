@@ -110,10 +110,10 @@ class DepthFineTuner:
             if missing or extra:
                 raise ValueError(f"resume_from: {what} must hold exactly the model's named parameters "
                                  f"(missing {missing[:3]}{'...' if len(missing) > 3 else ''}, unknown {extra[:3]}{'...' if len(extra) > 3 else ''})")
-            shapes = {n: tuple(p.shape) for n, p in net.named_parameters()}
-            bad = [n for n in names if tuple(d[n].shape) != shapes[n]]
+            sizes = {n: p.numel() for n, p in net.named_parameters()}      # (flat or parameter-shaped moments alike)
+            bad = [n for n in names if d[n].numel() != sizes[n]]
             if bad:
-                raise ValueError(f"resume_from: {what}[{bad[0]!r}] has shape {tuple(d[bad[0]].shape)}, the parameter {shapes[bad[0]]}")
+                raise ValueError(f"resume_from: {what}[{bad[0]!r}] has {d[bad[0]].numel()} elements, the parameter {sizes[bad[0]]}")
         if min(int(adam_steps), int(epoch), int(total_iters)) < 0:
             raise ValueError("resume_from: adam_steps, epoch and total_iters are counts (>= 0)")
         # the three counters of one run are tied together when no step was skipped (NaN guard): epoch * steps-per-epoch optimiser steps and

@@ -165,9 +165,10 @@ class GraphedFineTuneStep:
     CD_AMD_DP_GRAPH_COLLECTIVE=1 captures them too -- RCCL's all-reduce is an ordinary kernel launch on the capturing
     stream (torch's ProcessGroupNCCL supports capture), the step is then ONE replay per rank.  Exercised with a one-rank
     RCCL group on one GPU (tests/test_dp_gpu.py::test_rccl_collective_inside_the_step_graph); opt-in until it has run on
-    a multi-GPU node: a collective inside a graph cannot time out rank by rank, so a rank that falls back to eager steps
-    (capture failure) while the others replay would desynchronise the call sequence -- the opt-in therefore makes a
-    capture failure fatal instead of falling back.
+    a multi-GPU node.  A rank that fell back to eager steps (capture failure) while the others replay would desynchronise the
+    call sequence: the ranks therefore AGREE after the capture attempt (parallel.all_agree: one eager all-reduce of a flag) and,
+    unless every rank holds a graph, all of them drop to the eager exchange together (tests/test_parallel_cpu.py, two gloo ranks,
+    one forced to fail).
 
     If capture fails (a torch / HIP runtime without stream capture) the step stays eager and `self.graphed` is False.
     """
@@ -207,13 +208,29 @@ class GraphedFineTuneStep:
             return self.step(images, metadata)
         g = self._graphs.get(key)
         if g is None:
+            err = None
             try:
                 g = self._capture(images, metadata)
             except Exception as e:   # noqa: BLE001 -- stay on the (equally native) eager path
-                if self.graph_collective:
-                    raise RuntimeError("CD_AMD_DP_GRAPH_COLLECTIVE=1: capturing the step with its all-reduce failed; not falling back "
-                                       "(the other ranks would replay a graph with the collective inside)") from e
-                self.graphed, self.capture_error = False, f"{type(e).__name__}: {e}"
+                err = e
+            if self.graph_collective:
+                # CAPTURE CONSENSUS (round 6): with the all-reduce inside the graph a rank that replays while another one runs eager
+                # steps would desynchronise the collectives.  Capturing executes nothing, so no collective has been issued yet: all
+                # ranks agree here (one eager all-reduce(MIN) of a flag, same position in every rank's call sequence -- the first
+                # call of this signature beyond the eager ones) whether EVERYBODY has a graph; if not, everybody drops to the eager
+                # exchange (graphs without the collective), the path the two-rank tests cover.
+                if not parallel.all_agree(err is None, images.device):
+                    self.graph_collective = False
+                    self.capture_error = (f"{type(err).__name__}: {err}" if err is not None else
+                                          "another rank could not capture the step with its all-reduce") + " -> eager exchange on every rank"
+                    self._graphs.clear()
+                    err, g = None, None
+                    try:
+                        g = self._capture(images, metadata)        # (now without the collective: it ends before the exchange)
+                    except Exception as e:   # noqa: BLE001
+                        err = e
+            if err is not None:
+                self.graphed, self.capture_error = False, f"{type(err).__name__}: {err}"
                 torch.cuda.synchronize()
                 return self.step(images, metadata)
             self._graphs[key], self.graphed = g, True

@@ -184,6 +184,19 @@ class GradBuckets:
         self._handles = []
 
 
+def all_agree(ok: bool, device=None) -> bool:
+    """True iff `ok` holds on EVERY rank (one tiny all-reduce(MIN); every rank must call it at the same point of its call sequence).
+    Used as the capture-consensus handshake of GraphedFineTuneStep: a step graph that contains the gradient all-reduce may only be
+    replayed if every rank captured one -- a rank that fell back to eager steps would issue its collectives in another order."""
+    if not collective_active():
+        return bool(ok)
+    backend = dist.get_backend()
+    dev = device if (backend == "nccl" and device is not None) else torch.device("cpu")
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
+
+
 def broadcast_(tensors, src: int = 0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         for t in tensors:

@@ -266,3 +266,80 @@ def test_bench_epoch_plans_deal_disjoint_full_batches_to_the_ranks():
         if plans[0].epoch == 0:
             seen_epoch0 += flat
     assert len(set(seen_epoch0)) == len(seen_epoch0) == (n_pairs // (world * bs)) * world * bs    # no pair twice within an epoch
+
+
+class _FakeGraph:
+    def __init__(self, with_collective):
+        self.with_collective, self.replays = with_collective, 0
+
+    def replay(self):
+        self.replays += 1
+        if self.with_collective:          # a graph captured WITH the exchange issues the collective when replayed
+            parallel.allreduce_sum_(torch.ones(4))
+
+
+class _FakeStep:
+    """The surface GraphedFineTuneStep uses of a FineTuneStep, with the data-parallel exchange as its only real action."""
+    world = 2
+
+    def __init__(self):
+        self.eager, self.updates = 0, 0
+
+    def __call__(self, images, metadata):
+        self.eager += 1
+        parallel.allreduce_sum_(torch.ones(4))
+        return torch.zeros(1), {}
+
+    def _update(self, guard):
+        self.updates += 1
+        parallel.allreduce_sum_(torch.ones(4))
+
+    def _weights_updated(self):
+        pass
+
+
+def _consensus_worker(rank, world, port, fail_rank, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      CD_AMD_DP_GRAPH_COLLECTIVE="1")
+    parallel.init(backend="gloo")
+    from consistent_depth_amd.engine import GraphedFineTuneStep
+    step = _FakeStep()
+    g = GraphedFineTuneStep(step, eager_steps=1)
+    assert g.graph_collective
+    captures = []
+
+    def fake_capture(images, metadata):
+        captures.append(g.graph_collective)
+        if g.graph_collective and rank == fail_rank:
+            raise RuntimeError("forced capture failure")
+        return {"graph": _FakeGraph(g.graph_collective), "images": images.clone(), "meta": {}, "flat": [], "guard": torch.zeros(1), "parts": {}}
+    g._capture = fake_capture
+    x = torch.zeros(2, 2, 3, 4, 4)
+    for _ in range(4):          # 1 eager call, the capture call, 2 replays: every rank issues the same collectives in the same order
+        g(x, {})
+    graph = next(iter(g._graphs.values()))["graph"]
+    out[rank] = dict(collective=g.graph_collective, graphed=g.graphed, eager=step.eager, updates=step.updates, captures=captures,
+                     replays=graph.replays, with_collective=graph.with_collective, error=g.capture_error)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [1, -1], ids=["one_rank_fails", "all_capture"])
+def test_capture_consensus_of_the_graphed_exchange(fail_rank):
+    """CD_AMD_DP_GRAPH_COLLECTIVE=1 (the gradient all-reduce inside the step graph): after the capture attempt the ranks agree whether
+    EVERYBODY holds a graph (parallel.all_agree).  One rank forced to fail -> all ranks drop to the eager exchange together (graphs
+    without the collective + an eager all-reduce per step) and keep issuing their collectives in the same order: the run finishes
+    instead of hanging; nobody fails -> the collective stays inside the replayed graph on every rank."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_consensus_worker, args=(world, port, fail_rank, out), nprocs=world, join=True)
+    res = dict(out)
+    assert set(res) == {0, 1}
+    for r, o in res.items():
+        assert o["graphed"] is True and o["eager"] == 1 and o["replays"] == 3
+        if fail_rank < 0:
+            assert o["collective"] is True and o["with_collective"] is True and o["updates"] == 0 and o["captures"] == [True]
+        else:
+            assert o["collective"] is False and o["with_collective"] is False and o["updates"] == 3 and o["captures"] == [True, False]
+            assert "eager exchange on every rank" in o["error"]
