@@ -95,6 +95,9 @@ SIGNATURES = {
     "cd_maxpool3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_maxpool3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_add_slice": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_copy_segments": (c_i, [c_p, c_i, c_p]),
+    "cd_counters_add": (c_i, [c_p, c_i, ctypes.c_longlong, c_p]),
+    "cd_zero_bytes": (c_i, [c_p, c_sz, c_p]),
     "cd_channel_sum": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "cd_adam_step_flat": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
     "cd_adam_step_flat_guarded": (c_i, [c_p] * 4 + [c_sz, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_p]),
@@ -151,6 +154,15 @@ def dev_ptr(t: torch.Tensor, name: str = "tensor") -> int:
 
 def stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """t.zero_() as hipMemsetAsync on the current stream (contiguous device tensors; no framework kernel inside a captured step)."""
+    if not (t.is_cuda and t.is_contiguous()):
+        raise RuntimeError("zero_: a contiguous tensor on the HIP device")
+    if t.numel():
+        check(lib().cd_zero_bytes(t.data_ptr(), t.numel() * t.element_size(), stream_ptr(t.device)), "cd_zero_bytes")
+    return t
 
 
 _workspaces: dict = {}

@@ -147,6 +147,18 @@ __global__ __launch_bounds__(kBlock) void bnb_bwd_apply_kernel(const float* __re
 // op 0: y = max(a, 0)      op 1: y = a + b      op 2: y = b > 0 ? a : 0   (ReLU backward: a = dy, b = the ReLU's input or output)
 __global__ __launch_bounds__(kBlock) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                                                          size_t n, int op) {
+    if (op == 3) {      // y = a * b[0]: one device scalar for the whole array (block-uniform branch)
+        const float sc = b[0];
+        const size_t n4 = n / 4, stride = (size_t)gridDim.x * kBlock;
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+            const float4 av = a4[i];
+            y4[i] = make_float4(av.x * sc, av.y * sc, av.z * sc, av.w * sc);
+        }
+        for (size_t i = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = a[i] * sc;
+        return;
+    }
     auto f = [&](float av, float bv) -> float { return op == 0 ? fmaxf(av, 0.f) : (op == 1 ? av + bv : (bv > 0.f ? av : 0.f)); };
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * kBlock;
     const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -249,8 +261,8 @@ extern "C" int cd_bn_block_bwd(const float* dy, const float* x, const float* y, 
 }
 
 extern "C" int cd_eltwise(const float* a, const float* b, float* y, size_t n, int op, void* stream) {
-    CD_ARGCHK(a && y && n > 0 && op >= 0 && op <= 2 && (b || op == 0));
-    CD_ARGCHK(((uintptr_t)a & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!b || ((uintptr_t)b & 15) == 0));
+    CD_ARGCHK(a && y && n > 0 && op >= 0 && op <= 3 && (b || op == 0));
+    CD_ARGCHK(((uintptr_t)a & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!b || op == 3 || ((uintptr_t)b & 15) == 0));
     size_t blocks = (n / 4 + cd::kBlock * 4 - 1) / (cd::kBlock * 4);
     if (blocks < 1) blocks = 1;
     if (blocks > 8192) blocks = 8192;

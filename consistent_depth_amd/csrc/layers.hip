@@ -409,6 +409,19 @@ static inline dim3 plane_grid(int HW, int C, int N, int per_thread) {
     return dim3(bx, C, N);
 }
 
+// ---------------------------------------------------------------- small host-side chores as ONE launch each (round 6: they were ATen
+// launches inside the step -- 22 torch.cat of the fused entry convolutions' biases, a foreach-add over the 155 BatchNorm batch counters)
+// table[i]: n floats from src to dst (block i)
+__global__ __launch_bounds__(kBlock) void copy_segments_kernel(const cd_copy_seg* __restrict__ table) {
+    const cd_copy_seg seg = table[blockIdx.x];
+    for (long long i = threadIdx.x; i < seg.n; i += kBlock) seg.dst[i] = seg.src[i];
+}
+// *table[i] += delta (nn.BatchNorm2d.num_batches_tracked of every layer, int64 scalars)
+__global__ __launch_bounds__(kBlock) void counters_add_kernel(long long* const* __restrict__ table, int n, long long delta) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) *table[i] += delta;
+}
+
 }  // namespace cd
 
 extern "C" {
@@ -523,6 +536,26 @@ int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_cto
                        s_ctot, s_coff, dst, d_ctot, d_coff, H * W, accumulate);
     CD_CHECK_LAUNCH();
     return CD_OK;
+}
+
+int cd_copy_segments(const cd_copy_seg* table_dev, int n, void* stream) {
+    CD_ARGCHK(table_dev && n > 0);
+    hipLaunchKernelGGL(cd::copy_segments_kernel, dim3((unsigned)n), dim3(cd::kBlock), 0, (hipStream_t)stream, table_dev);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_counters_add(long long* const* table_dev, int n, long long delta, void* stream) {
+    CD_ARGCHK(table_dev && n > 0);
+    hipLaunchKernelGGL(cd::counters_add_kernel, dim3((unsigned)((n + cd::kBlock - 1) / cd::kBlock)), dim3(cd::kBlock), 0, (hipStream_t)stream,
+                       table_dev, n, delta);
+    CD_CHECK_LAUNCH();
+    return CD_OK;
+}
+
+int cd_zero_bytes(void* p, size_t bytes, void* stream) {
+    CD_ARGCHK(p && bytes > 0);
+    return hipMemsetAsync(p, 0, bytes, (hipStream_t)stream) == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
 int cd_channel_sum(const float* src, int ctot, int coff, int C, int N, int H, int W, float* out, int accumulate,

@@ -33,6 +33,7 @@ class FineTuneStep:
         self.opt = cd_optimizer.create(getattr(params, "optimizer", "Adam"), plist, params.learning_rate,
                                        betas=(0.9, 0.999))
         self._plist = plist
+        self._root_grad = None       # d loss / d loss = 1, kept (loss.backward() would fill a fresh ones_like every step)
         # Autograd-driven models with a large gradient (MiDaS: 420 MB): bucketed all-reduce overlapped with the backward pass.
         # The hourglass engine writes its 21 MB of gradients without autograd hooks: one collective after the backward.
         self.buckets = None
@@ -47,19 +48,24 @@ class FineTuneStep:
             self.buckets.close()
             self.buckets = None
 
+    def _backward(self, loss):
+        if self._root_grad is None or self._root_grad.shape != loss.shape or self._root_grad.device != loss.device:
+            self._root_grad = torch.ones_like(loss)
+        torch.autograd.backward(loss, grad_tensors=self._root_grad)
+
     def _backward_and_reduce(self, loss):
         """backward + the data-parallel exchange; returns the guard scalar (the summed loss with world > 1)."""
         guard = loss.detach()
         if self.world == 1:
-            loss.backward()
+            self._backward(loss)
             return guard
         if self.buckets is not None:
             self.opt.loss_slot.copy_(guard.reshape(1))     # before backward: nothing writes the slot afterwards
             self.buckets.arm()
-            loss.backward()
+            self._backward(loss)
             self.buckets.finish()
             return self.opt.loss_slot
-        loss.backward()
+        self._backward(loss)
         self.opt.loss_slot.copy_(guard.reshape(1))
         parallel.allreduce_sum_(self.opt.reduce_buffer)
         return self.opt.loss_slot
@@ -97,7 +103,7 @@ class FineTuneStep:
         raw = self.model.estimate_raw(images)
         self.opt.zero_grad()
         loss, parts = self.criterion(raw, metadata, parameters=self._plist)
-        loss.backward()
+        self._backward(loss)
         guard = loss.detach()
         if self.world > 1:
             self.opt.loss_slot.copy_(guard.reshape(1))

@@ -103,7 +103,12 @@ class _FusedConsistency(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_reproj, _g_disp):
         (grad,) = ctx.saved_tensors
-        return (grad * g_total,) + (None,) * 11
+        # d loss / d depth = (the kernel's gradient of `total`) x (upstream scalar, on the device): one hand-written launch (cd_eltwise op 3)
+        out = torch.empty_like(grad)
+        g = g_total.detach().to(torch.float32).reshape(1).contiguous()
+        rc = _native.lib().cd_eltwise(grad.data_ptr(), g.data_ptr(), out.data_ptr(), grad.numel(), 3, _native.stream_ptr(grad.device))
+        _native.check(rc, "cd_eltwise")
+        return (out,) + (None,) * 11
 
 
 def consistency_loss(depths, flows, masks, intrinsics, extrinsics, lambda_reprojection, lambda_view_baseline,

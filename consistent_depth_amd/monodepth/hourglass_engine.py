@@ -182,11 +182,10 @@ class PointwiseGroup:
                                     y_ctot=src.buf.shape[1])
 
     def _fused_bias(self):
-        # Rebuilt on EVERY forward (one tiny concatenation, captured into the step graph): FlatAdam updates the member biases
-        # through raw pointers, which tensor version counters never see, so a cached copy would go stale -- harmless under a
-        # train-mode BatchNorm (which cancels the bias) but wrong in eval mode and as soon as the biases get a gradient
-        # (lambda_parameter > 0).
-        torch.cat([m.conv.bias.detach() for m in self.members], out=self._bias)
+        # Refreshed on EVERY forward: FlatAdam updates the member biases through raw pointers, which tensor version counters never
+        # see, so a cached copy would go stale -- harmless under a train-mode BatchNorm (which cancels the bias) but wrong in eval
+        # mode and as soon as the biases get a gradient (lambda_parameter > 0).  Round 6: the copies of ALL groups of a plan are one
+        # cd_copy_segments launch at the top of the forward (_BiasTable; 22 torch.cat launches per forward before).
         return self._bias
 
     def forward(self, training):
@@ -206,6 +205,39 @@ class PointwiseGroup:
         if s.gbuf is not None:
             C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
+
+
+class _BiasTable:
+    """member bias -> fused bias vector of every PointwiseGroup of a plan, as ONE launch (cd_copy_segments)."""
+
+    def __init__(self, groups, device):
+        self.groups, self.device, self._key, self._table = groups, device, None, None
+
+    def run(self):
+        if not self.groups:
+            return
+        key = tuple(m.conv.bias.data_ptr() for g in self.groups for m in g.members)
+        if key != self._key:        # (first use, or the parameters were re-homed -- FlatAdam moves them into its flat buffer)
+            rows = []
+            for g in self.groups:
+                off = 0
+                for m in g.members:
+                    rows.append((m.conv.bias.data_ptr(), g._bias.data_ptr() + 4 * off, m.cout))
+                    off += m.cout
+                assert off == g.ctot
+            self._table, self._key = torch.tensor(rows, dtype=torch.int64, device=self.device), key
+        _native.check(_native.lib().cd_copy_segments(self._table.data_ptr(), self._table.shape[0], _native.stream_ptr(self.device)),
+                      "cd_copy_segments")
+
+
+def _groups_of(steps):
+    out = []
+    for st in steps:
+        if st.kind == "inception":
+            out.append(st.group)
+        elif st.kind == "channels":
+            out += _groups_of(st.flat) + _groups_of(st.up)
+    return out
 
 
 def _grad_of(p: torch.nn.Parameter) -> torch.Tensor:
@@ -280,6 +312,22 @@ class HourglassEngine:
         # momentum is fixed so nothing reads the counters, but they are part of the checkpoint the reference writes
         self._batch_counters = [m.num_batches_tracked for m in net.modules()
                                 if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
+
+    def _bias_table(self, plan):
+        if "bias_table" not in plan:
+            plan["bias_table"] = _BiasTable(_groups_of(plan["steps"]), self.device)
+        return plan["bias_table"]
+
+    def _advance_batch_counters(self):
+        """num_batches_tracked += 1 of every BatchNorm2d: one launch over a device table of the counters' addresses (torch._foreach_add_
+        was two multi-tensor launches inside the captured step).  The table follows the counters if a state-dict load re-binds them."""
+        ptrs = tuple(t.data_ptr() for t in self._batch_counters)
+        if ptrs != getattr(self, "_counter_key", None):
+            if not all(t.is_cuda and t.dtype == torch.int64 for t in self._batch_counters):
+                raise RuntimeError("BatchNorm batch counters must be int64 tensors on the HIP device")
+            self._counter_table, self._counter_key = torch.tensor(ptrs, dtype=torch.int64, device=self.device), ptrs
+        _native.check(_native.lib().cd_counters_add(self._counter_table.data_ptr(), len(ptrs), 1, _native.stream_ptr(self.device)),
+                      "cd_counters_add")
 
     def _rehome_running_stats(self, bns):
         n = sum(b.num_features for b in bns)
@@ -613,11 +661,12 @@ class HourglassEngine:
         N, _, H, W = x.shape
         plan = self.plan(N, H, W)
         plan["x"].copy_(x)
-        plan["stats_arena"].zero_()
+        _native.zero_(plan["stats_arena"])
         self._pack.run()
+        self._bias_table(plan).run()
         self._run_forward(plan["steps"], self.net.training)
         if self.net.training and self._batch_counters:
-            torch._foreach_add_(self._batch_counters, 1)
+            self._advance_batch_counters()
         self._last = plan
         return plan["pred"]
 
@@ -625,7 +674,7 @@ class HourglassEngine:
     def _backward(self, dpred: torch.Tensor):
         plan = self._last
         plan["dpred"].copy_(dpred.reshape(plan["dpred"].shape))
-        plan["sums_arena"].zero_()
+        _native.zero_(plan["sums_arena"])
         for a in plan["acts"]:  # first gradient contribution overwrites, later ones accumulate
             a.grad_written = False
         self._run_backward(plan["steps"])
@@ -675,8 +724,9 @@ class BlockRunner:
     @torch.no_grad()
     def forward(self, x_raw: torch.Tensor, training: bool = True) -> torch.Tensor:
         self.x.buf.copy_(x_raw)
-        self.plan["stats_arena"].zero_()
+        _native.zero_(self.plan["stats_arena"])
         self.eng._pack.run()
+        self.eng._bias_table(self.plan).run()
         self.eng._run_forward(self.plan["steps"], training)
         o = self.out      # the buffer holds the raw convolution output: apply the BatchNorm like every consumer does
         v = o.buf[:, o.coff:o.coff + o.C]
@@ -686,7 +736,7 @@ class BlockRunner:
     def backward(self, dy: torch.Tensor) -> torch.Tensor:
         o = self.out
         self.step.Pg[:, o.coff:o.coff + o.C].copy_(dy)
-        self.plan["sums_arena"].zero_()
+        _native.zero_(self.plan["sums_arena"])
         for a in self.plan["acts"]:
             a.grad_written = False
         self.eng._run_backward(self.plan["steps"])

@@ -71,7 +71,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):
         # grads are views into the flat buffer: keep them bound, clear with one memset
-        self._grad_store.zero_()
+        _native.zero_(self._grad_store)
         for p, o in zip(self._params, self._offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)

@@ -495,7 +495,8 @@ int cd_bn_block_fwd(const float* x, const float* gamma, const float* beta, const
                     double* stats, int C, int N, int H, int W, void* stream);
 int cd_bn_block_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* mean_invstd, int relu,
                     float* dx, float* dres, float* dgamma, float* dbeta, double* sums, int C, int N, int H, int W, void* stream);
-/* y = max(a, 0) (op 0) | a + b (op 1) | b > 0 ? a : 0 (op 2: ReLU backward, a = dy, b = the ReLU's input or output); 16-byte aligned. */
+/* y = max(a, 0) (op 0) | a + b (op 1) | b > 0 ? a : 0 (op 2: ReLU backward, a = dy, b = the ReLU's input or output) |
+ * a * b[0] (op 3, ABI 9: scale by a DEVICE scalar -- the upstream gradient of the loss's autograd node); 16-byte aligned. */
 int cd_eltwise(const float* a, const float* b, float* y, size_t n, int op, void* stream);
 /* nn.MaxPool2d(3, stride 2, padding 1): y (N, C, (H-1)/2+1, (W-1)/2+1), argmax = position inside the window (0..8; ATen's first-maximum
  * rule); the backward is a gather over the <= 4 windows that contain an input pixel. */
@@ -505,6 +506,20 @@ int cd_maxpool3s2_bwd(const float* dy, const unsigned char* argmax, float* dx, i
 /* dst[:, d_coff:+C] (+)= src[:, s_coff:+C]  -- gradient fan-in of a tensor with several consumers. */
 int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_ctot, int d_coff, int C, int N,
                  int H, int W, int accumulate, void* stream);
+/* ABI 9.  Host-side chores of a step as ONE launch each (they were framework launches inside the captured step):
+ * cd_copy_segments: table[i] = {src, dst, n}: n floats copied per entry (the biases of the four branch-entry 1x1 convolutions of every
+ * inception into the fused convolution's bias vector: 22 torch.cat per forward before); the table lives in device memory.
+ * cd_counters_add: *table[i] += delta for n device pointers to int64 scalars (nn.BatchNorm2d.num_batches_tracked of every layer,
+ * advanced by every train-mode forward: /root/reference/depth_fine_tuning.py:241,327-328 keeps train mode during validation too).
+ * cd_zero_bytes: hipMemsetAsync(p, 0, bytes) on the caller's stream (gradient / statistics arenas). */
+typedef struct cd_copy_seg {
+    const float* src;
+    float* dst;
+    long long n;
+} cd_copy_seg;
+int cd_copy_segments(const cd_copy_seg* table_dev, int n, void* stream);
+int cd_counters_add(long long* const* table_dev, int n, long long delta, void* stream);
+int cd_zero_bytes(void* p, size_t bytes, void* stream);
 /* out[c] (+)= sum over n,y,x of src[n][coff+c]  -- bias gradient of a conv not followed by BatchNorm. */
 int cd_channel_sum(const float* src, int ctot, int coff, int C, int N, int H, int W, float* out,
                    int accumulate, void* stream);

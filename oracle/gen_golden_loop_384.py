@@ -26,7 +26,7 @@ Two clips (SPECS):
            (<dir>/cpu_<spec>_<dtype>): `golden` on a directory whose run was interrupted collects the epochs that are complete.
   stage 3  `ref32 <spec> <dir>`     the same continuation in the reference's OWN arithmetic (fp32 on the CPU): its distances to the
            fp64 run are the yardstick stored next to each artefact (`ref32dist_*`).
-  test     tests/test_loop_gpu.py::test_full_length_run_within_1e_3[...] re-runs the product from the seeds (the step is
+  test     tests/test_loop_gpu.py::test_full_length_run_vs_fp64_and_vs_the_reference_fp32_run[...] re-runs the product from the seeds (the step is
            bit-reproducible: the regenerated snapshot is compared with the golden's checksums) and asserts the bounds at EVERY epoch.
 
     gpurun -- 'python -m oracle.gen_golden_loop_384 snapshot a gpurun_out/snap384'
