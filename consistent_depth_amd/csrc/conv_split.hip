@@ -36,6 +36,13 @@
 #define CD_SP_DBG 0
 #endif
 
+#ifndef CD_SP_PF         // 1: the first staging unit of every thread is PREFETCHED across the MFMA phase (see conv_fwd_split_block)
+#define CD_SP_PF 1
+#endif
+#ifndef CD_SP_MG8        // M-tiles whose fragments are in registers at a time in the classes with 8 accumulator tiles per wave (prefetch builds)
+#define CD_SP_MG8 2
+#endif
+
 namespace cd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -138,6 +145,7 @@ int launch_pack_split_table(const void* table_dev, int n, hipStream_t s) {
 // bottleneck).  At the end the four partial sums of an M-tile are added in a fixed order through LDS by the wave that
 // stores it.  The order of accumulation depends on nothing but (Cin, KS, DY): every launch shape gives the same bits.
 constexpr size_t SPLIT_REDUCE_LDS = 4 * 3 * 4096;   // one round of the cross-wave reduction: 4 owners x 3 foreign partials x 4 KB
+static inline size_t split_aff_bytes(int Cin) { return (size_t)((Cin + 7) / 8) * 8 * 2 * sizeof(float); }   // scale / shift of every (padded) input channel
 
 // One convolution as the kernels see it (the arguments of a stand-alone launch).
 struct SplitArgs {
@@ -167,7 +175,13 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
     constexpr int TY = Cfg::TY, ROWS = Cfg::ROWS, RSP = Cfg::RSP, COFF = Cfg::COFF, PADL = Cfg::PADL, PLANE = Cfg::PLANE;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, KSTEPS = Cfg::KSTEPS;
     constexpr int MB = TY / DY;                       // M-tiles (tile rows, DY output rows each) per block
-    constexpr int MG = 4;                             // M-tiles whose fragments are in registers at a time
+    // PF by launch class (static census, profiles/kernel_resources_r06.txt): the two classes that would spill with 32 more live registers
+    // (two column tiles x two chunks per round; 16 rows x 2 output rows per tile) and the two whose 150 registers give THREE resident
+    // workgroups per CU (a third workgroup's MFMAs already cover a staging round trip) stay without it.
+    constexpr bool PF = CD_SP_PF != 0 && !(NT == 2 && CGS == 2) && !(DY == 2 && TYP == 16) && !(MB * NT == 4 && CGS == 1);
+    // M-tiles whose fragments are in registers at a time (the prefetch needs 32 registers across the MFMA phase: the classes with 128
+    // accumulator registers pay for them with a smaller fragment group)
+    constexpr int MG = (PF && MB * NT >= 8) ? CD_SP_MG8 : 4;
     constexpr int CPT = DY == 2 ? 16 : 32;            // output channels per column tile
     constexpr int COB = NT * CPT;
     constexpr int UNITS = ROWS * (RSP / 4);           // staging units: (row, 4-pixel quad) x 8 channels
@@ -225,25 +239,28 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
 
     const int abase = li + COFF;   // LDS slot of this lane's pixel in tile row 0 at tap (0, 0)
 
-    // staging of one unit = (tile row r, 4-pixel quad) x the 8 channels of a chunk, in two halves: raw loads, then transform + split
-    // (the producer's BatchNorm scale / shift of the chunk's 8 channels are loaded HERE, with the data: fetched in stage_finish they
-    // started a second memory round trip per unit once every activation of the network is applied on load -- forward convolutions
-    // +20 % in round 3's first apply-on-load build)
-    auto stage_load = [&](int chunk, int u, float (&v)[8][4], unsigned (&keep)[4], float (&sc)[8], float (&sh)[8]) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int ci = chunk * 8 + c;
-            sc[c] = in_scale ? in_scale[ci < Cin ? ci : Cin - 1] : 1.f;
-            sh[c] = in_scale ? in_shift[ci < Cin ? ci : Cin - 1] : 0.f;
-        }
+    // The producer's BatchNorm scale / shift of ALL input channels sit in LDS behind the images (round 6; padded channels: 0): every
+    // staging unit used to fetch its chunk's 16 values from global memory with its data (round 3: fetched in the second half of the
+    // staging they were a second memory round trip per unit).
+    const int nc8 = n_chunks * 8;
+    float* s_aff = reinterpret_cast<float*>(smem_raw + (size_t)CGS * Cfg::LDS);     // [2][nc8]
+    if (in_scale != nullptr)
+        for (int i = threadIdx.x; i < nc8; i += kBlock) {
+            s_aff[i] = i < Cin ? in_scale[i] : 0.f;
+            s_aff[nc8 + i] = i < Cin ? in_shift[i] : 0.f;
+        }       // (visible after the first barrier of the round loop)
+
+    // staging of one unit = (tile row r, 4-pixel quad) x the 8 channels of a chunk, in two halves: the raw loads (32 registers), then
+    // transform + split + LDS writes.  Everything else a unit needs (its position, the padding masks, the affine) is recomputed / read
+    // from LDS in the second half, so that a unit's raw loads can be issued a whole MFMA phase ahead (PF, below).
+    auto stage_load = [&](int chunk, int u, float (&v)[8][4]) {
         const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
         const int gy = Y0 - P + r, gx = X0 - PADL + q4;
         const bool row_in = (unsigned)gy < (unsigned)H;
         const int gyc = row_in ? gy : 0;
         if (CD_SP_DBG & 4) {       // what-if: the staging's arithmetic and LDS writes without its memory round trip (wrong results)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { sc[c] = 1.f; sh[c] = 0.f; v[c][0] = v[c][1] = v[c][2] = v[c][3] = __int_as_float(0x3f800000 + u + c + gy); }
-            keep[0] = keep[1] = keep[2] = keep[3] = 0xffffffffu;
+            for (int c = 0; c < 8; ++c) v[c][0] = v[c][1] = v[c][2] = v[c][3] = __int_as_float(0x3f800000 + u + c + gy);
             return;
         }
         if (vec_in) {       // W % 4 == 0: an aligned quad is inside or outside the image as a whole
@@ -255,12 +272,10 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
                 const float4 f = *reinterpret_cast<const float4*>(src + (size_t)(ci < Cin ? ci : Cin - 1) * HW);
                 v[c][0] = f.x; v[c][1] = f.y; v[c][2] = f.z; v[c][3] = f.w;
             }
-            keep[0] = keep[1] = keep[2] = keep[3] = in ? 0xffffffffu : 0u;
         } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const bool in = row_in && (unsigned)(gx + p) < (unsigned)W;
-                keep[p] = in ? 0xffffffffu : 0u;
                 const float* src = xin + (size_t)gyc * W + (in ? gx + p : 0);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -270,9 +285,22 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
             }
         }
     };
-    auto stage_finish = [&](int chunk, int u, float (&v)[8][4], const unsigned (&keep)[4], const float (&sc)[8], const float (&sh)[8],
-                            int gbase) {
+    auto stage_finish = [&](int chunk, int u, float (&v)[8][4], int gbase) {
         const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
+        const int gy = Y0 - P + r, gx = X0 - PADL + q4;
+        const bool row_in = (unsigned)gy < (unsigned)H;
+        unsigned keep[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            keep[p] = ((CD_SP_DBG & 4) || (row_in && (unsigned)(gx + (vec_in ? 0 : p)) < (unsigned)W)) ? 0xffffffffu : 0u;
+        float sc[8], sh[8];
+        if (in_scale) {
+            const f32x4* a4 = reinterpret_cast<const f32x4*>(s_aff + chunk * 8);
+            const f32x4* b4 = reinterpret_cast<const f32x4*>(s_aff + nc8 + chunk * 8);
+            const f32x4 s0 = a4[0], s1 = a4[1], h0 = b4[0], h1 = b4[1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { sc[c] = s0[c]; sc[4 + c] = s1[c]; sh[c] = h0[c]; sh[4 + c] = h1[c]; }
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int ci = chunk * 8 + c;
@@ -298,9 +326,23 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
             s_in[slot] = hh; s_in[PLANE + slot] = mm; s_in[2 * PLANE + slot] = ll;
         }
     };
+    // PF: this thread's FIRST unit of the next round is requested at the top of the current round's MFMA phase and consumed after
+    // it (32 registers).  Measured in round 6 (profiles/conv_phases_r06.txt): of the 1.7 ms per step the staging costs the forward /
+    // input-gradient family, 0.86 ms is the memory round trip at the top of every round -- the two resident workgroups of a CU run
+    // in lockstep, so nothing else covers it -- and 0.83 ms its arithmetic and LDS writes.  Round 3's fetch-ahead issued the loads
+    // BEFORE the phase and kept the affine with them (48 registers): the first weight-fragment wait then waited for the whole
+    // prefetch (vmcnt retires in order) and the 128-accumulator shapes spilled.  Here the weight fragments of the phase's first
+    // step are already in registers when the prefetch is issued, and a unit is 32 registers.
+    float pv[8][4];
+    const int n_rounds = (n_chunks + CGS - 1) / CGS;
+    // (the loads are UNCONDITIONAL -- a thread without a unit re-reads the last one and drops it: a load under a divergent branch is
+    // waited for at once)
+    const bool pf_mine = PF && (int)threadIdx.x < CGS * UNITS;
+    const int pf_uu = (int)threadIdx.x < CGS * UNITS ? (int)threadIdx.x : CGS * UNITS - 1;
+    const int pf_g2 = pf_uu / UNITS, pf_u = pf_uu - pf_g2 * UNITS;
+    if (PF) stage_load(pf_g2, pf_u, pv);
     // CGS channel chunks (8 channels each) are staged per barrier round, each into its own LDS image: the deep levels of the
     // hourglass have few tiles per launch and are a latency chain of rounds -- two chunks per round halve it
-    const int n_rounds = (n_chunks + CGS - 1) / CGS;
     for (int round = 0; round < n_rounds; ++round) {
         __syncthreads();   // the previous round's fragments are consumed
         // ---- stage: global fp32 -> (affine, relu) -> three bf16 planes, channels-last.  The 8 loads of a unit are UNCONDITIONAL
@@ -309,14 +351,15 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
         // (Fetching a thread's unit for round r + 1 BEFORE the MFMA phase of round r was tried in round 3 and is slower: the weight
         // fragments below are global loads too, vmcnt retires in order, so the first fragment wait of the phase also waits for the
         // whole prefetch -- nothing overlaps; profiles/conv_phases_r03.txt.)
-        for (int uu = threadIdx.x; uu < ((CD_SP_DBG & 2) ? 0 : CGS * UNITS); uu += kBlock) {
+        if (pf_mine && !(CD_SP_DBG & 2)) stage_finish(round * CGS + pf_g2, pf_u, pv, pf_g2 * 3 * PLANE);      // (requested one round ago)
+        for (int uu = threadIdx.x + (PF ? kBlock : 0); uu < ((CD_SP_DBG & 2) ? 0 : CGS * UNITS); uu += kBlock) {
             const int g2 = uu / UNITS, u = uu - g2 * UNITS;
-            float v[8][4], sc[8], sh[8];
-            unsigned keep[4];
-            stage_load(round * CGS + g2, u, v, keep, sc, sh);     // (a chunk beyond the last one: channels >= Cin, zeroed)
-            stage_finish(round * CGS + g2, u, v, keep, sc, sh, g2 * 3 * PLANE);
+            float v[8][4];
+            stage_load(round * CGS + g2, u, v);     // (a chunk beyond the last one: channels >= Cin, zeroed)
+            stage_finish(round * CGS + g2, u, v, g2 * 3 * PLANE);
         }
         __syncthreads();
+        if (PF && round + 1 < n_rounds) stage_load((round + 1) * CGS + pf_g2, pf_u, pv);     // (block-uniform) in flight during the MFMAs below
 
         // ---- MFMA over this wave's tap steps of the chunk
         const int lin_end = ((round + 1) * CGS < n_chunks ? (round + 1) * CGS : n_chunks) * KSTEPS;
@@ -509,7 +552,8 @@ static int launch_split_t(const float* x, int x_ctot, int x_coff, int Cin, const
                           int N, int H, int W, const ConvGroups& grp, hipStream_t s) {
     using Cfg = SplitCfg<KS, TYP, DY>;
     const int tiles_x = (W + SP_TX - 1) / SP_TX, tiles_y = (H + Cfg::TY - 1) / Cfg::TY;
-    const size_t lds = CGS * Cfg::LDS > SPLIT_REDUCE_LDS ? CGS * Cfg::LDS : SPLIT_REDUCE_LDS;
+    const size_t img = CGS * Cfg::LDS + split_aff_bytes(Cin);      // the LDS images + the producer's scale / shift table behind them
+    const size_t lds = img > SPLIT_REDUCE_LDS ? img : SPLIT_REDUCE_LDS;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_fwd_split_kernel<KS, NT, TYP, DY, CGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -543,7 +587,7 @@ static int launch_split_multi_t(const SplitConv* c, int n, int N, int H, int W, 
         a.tiles_total = tiles_total; a.chunk_tiles = chunk_tiles; a.slices = slices; a.grp = ConvGroups();
         m.ks[i] = c[i].ks;
         const int ks = c[i].ks;
-        const size_t need = (size_t)CGS * 3 * (TYP + ks - 1) * (SP_TX + 2 * ((((ks - 1) / 2) + 3) & ~3)) * 16;   // = CGS * SplitCfg<ks, TYP, DY>::LDS
+        const size_t need = (size_t)CGS * 3 * (TYP + ks - 1) * (SP_TX + 2 * ((((ks - 1) / 2) + 3) & ~3)) * 16 + split_aff_bytes(c[i].Cin);   // = CGS * SplitCfg<ks, TYP, DY>::LDS + the affine table
         if (need > lds) lds = need;
     }
     for (int i = n; i < kSplitMultiMax; ++i) { m.b[i] = m.b[0]; m.ks[i] = m.ks[0]; }

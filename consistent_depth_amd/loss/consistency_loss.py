@@ -98,11 +98,14 @@ class _FusedConsistency(torch.autograd.Function):
                                             lambda_r, lambda_b, mode, True)
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(reproj, disp)
+        ctx.set_materialize_grads(False)       # (autograd would fill two (B,) zero tensors per step for the non-differentiable outputs)
         return total, reproj, disp
 
     @staticmethod
     def backward(ctx, g_total, _g_reproj, _g_disp):
         (grad,) = ctx.saved_tensors
+        if g_total is None:       # `total` did not take part in what was differentiated
+            return (None,) * 12
         # d loss / d depth = (the kernel's gradient of `total`) x (upstream scalar, on the device): one hand-written launch (cd_eltwise op 3)
         out = torch.empty_like(grad)
         g = g_total.detach().to(torch.float32).reshape(1).contiguous()
