@@ -36,13 +36,6 @@
 #define CD_SP_DBG 0
 #endif
 
-#ifndef CD_SP_PF         // 1: the first staging unit of every thread is PREFETCHED across the MFMA phase (see conv_fwd_split_block)
-#define CD_SP_PF 1
-#endif
-#ifndef CD_SP_MG8        // M-tiles whose fragments are in registers at a time in the classes with 8 accumulator tiles per wave (prefetch builds)
-#define CD_SP_MG8 2
-#endif
-
 namespace cd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -175,13 +168,7 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
     constexpr int TY = Cfg::TY, ROWS = Cfg::ROWS, RSP = Cfg::RSP, COFF = Cfg::COFF, PADL = Cfg::PADL, PLANE = Cfg::PLANE;
     constexpr int P = (KS - 1) / 2, TAPS = Cfg::TAPS, KSTEPS = Cfg::KSTEPS;
     constexpr int MB = TY / DY;                       // M-tiles (tile rows, DY output rows each) per block
-    // PF by launch class (static census, profiles/kernel_resources_r06.txt): the two classes that would spill with 32 more live registers
-    // (two column tiles x two chunks per round; 16 rows x 2 output rows per tile) and the two whose 150 registers give THREE resident
-    // workgroups per CU (a third workgroup's MFMAs already cover a staging round trip) stay without it.
-    constexpr bool PF = CD_SP_PF != 0 && !(NT == 2 && CGS == 2) && !(DY == 2 && TYP == 16) && !(MB * NT == 4 && CGS == 1);
-    // M-tiles whose fragments are in registers at a time (the prefetch needs 32 registers across the MFMA phase: the classes with 128
-    // accumulator registers pay for them with a smaller fragment group)
-    constexpr int MG = (PF && MB * NT >= 8) ? CD_SP_MG8 : 4;
+    constexpr int MG = 4;                             // M-tiles whose fragments are in registers at a time
     constexpr int CPT = DY == 2 ? 16 : 32;            // output channels per column tile
     constexpr int COB = NT * CPT;
     constexpr int UNITS = ROWS * (RSP / 4);           // staging units: (row, 4-pixel quad) x 8 channels
@@ -252,7 +239,7 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
 
     // staging of one unit = (tile row r, 4-pixel quad) x the 8 channels of a chunk, in two halves: the raw loads (32 registers), then
     // transform + split + LDS writes.  Everything else a unit needs (its position, the padding masks, the affine) is recomputed / read
-    // from LDS in the second half, so that a unit's raw loads can be issued a whole MFMA phase ahead (PF, below).
+    // from LDS in the second half: a unit's raw loads are 32 registers and nothing else.
     auto stage_load = [&](int chunk, int u, float (&v)[8][4]) {
         const int r = u / (RSP / 4), q4 = (u - r * (RSP / 4)) * 4;
         const int gy = Y0 - P + r, gx = X0 - PADL + q4;
@@ -326,21 +313,13 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
             s_in[slot] = hh; s_in[PLANE + slot] = mm; s_in[2 * PLANE + slot] = ll;
         }
     };
-    // PF: this thread's FIRST unit of the next round is requested at the top of the current round's MFMA phase and consumed after
-    // it (32 registers).  Measured in round 6 (profiles/conv_phases_r06.txt): of the 1.7 ms per step the staging costs the forward /
-    // input-gradient family, 0.86 ms is the memory round trip at the top of every round -- the two resident workgroups of a CU run
-    // in lockstep, so nothing else covers it -- and 0.83 ms its arithmetic and LDS writes.  Round 3's fetch-ahead issued the loads
-    // BEFORE the phase and kept the affine with them (48 registers): the first weight-fragment wait then waited for the whole
-    // prefetch (vmcnt retires in order) and the 128-accumulator shapes spilled.  Here the weight fragments of the phase's first
-    // step are already in registers when the prefetch is issued, and a unit is 32 registers.
-    float pv[8][4];
+    // (Round 6 also built a PREFETCH of every thread's first unit across the MFMA phase -- 32 registers, requested after the
+    // barrier, consumed one round later -- and took it out again: hipcc's wait in front of a weight fragment is one immediate for
+    // every path that reaches it, the smallest one, so the first fragment wait of every phase waited for the whole prefetch (no
+    // gain: 179.7-181.0 pairs/s against 180.2-180.3 without it); with the first steps of a phase peeled out of the loop and the
+    // scalar / vector staging paths as two copies of the round loop the 128-accumulator class spilled 728 bytes per lane.  Of the
+    // 1.7 ms per step the staging costs this family, 0.86 ms is that memory round trip: profiles/conv_phases_r06.txt.)
     const int n_rounds = (n_chunks + CGS - 1) / CGS;
-    // (the loads are UNCONDITIONAL -- a thread without a unit re-reads the last one and drops it: a load under a divergent branch is
-    // waited for at once)
-    const bool pf_mine = PF && (int)threadIdx.x < CGS * UNITS;
-    const int pf_uu = (int)threadIdx.x < CGS * UNITS ? (int)threadIdx.x : CGS * UNITS - 1;
-    const int pf_g2 = pf_uu / UNITS, pf_u = pf_uu - pf_g2 * UNITS;
-    if (PF) stage_load(pf_g2, pf_u, pv);
     // CGS channel chunks (8 channels each) are staged per barrier round, each into its own LDS image: the deep levels of the
     // hourglass have few tiles per launch and are a latency chain of rounds -- two chunks per round halve it
     for (int round = 0; round < n_rounds; ++round) {
@@ -351,15 +330,13 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
         // (Fetching a thread's unit for round r + 1 BEFORE the MFMA phase of round r was tried in round 3 and is slower: the weight
         // fragments below are global loads too, vmcnt retires in order, so the first fragment wait of the phase also waits for the
         // whole prefetch -- nothing overlaps; profiles/conv_phases_r03.txt.)
-        if (pf_mine && !(CD_SP_DBG & 2)) stage_finish(round * CGS + pf_g2, pf_u, pv, pf_g2 * 3 * PLANE);      // (requested one round ago)
-        for (int uu = threadIdx.x + (PF ? kBlock : 0); uu < ((CD_SP_DBG & 2) ? 0 : CGS * UNITS); uu += kBlock) {
+        for (int uu = threadIdx.x; uu < ((CD_SP_DBG & 2) ? 0 : CGS * UNITS); uu += kBlock) {
             const int g2 = uu / UNITS, u = uu - g2 * UNITS;
             float v[8][4];
             stage_load(round * CGS + g2, u, v);     // (a chunk beyond the last one: channels >= Cin, zeroed)
             stage_finish(round * CGS + g2, u, v, g2 * 3 * PLANE);
         }
         __syncthreads();
-        if (PF && round + 1 < n_rounds) stage_load((round + 1) * CGS + pf_g2, pf_u, pv);     // (block-uniform) in flight during the MFMAs below
 
         // ---- MFMA over this wave's tap steps of the chunk
         const int lin_end = ((round + 1) * CGS < n_chunks ? (round + 1) * CGS : n_chunks) * KSTEPS;
@@ -520,6 +497,8 @@ __device__ __forceinline__ void conv_fwd_split_block(const SplitArgs& a, const i
     }
 }
 
+// (__launch_bounds__(.., 3) for the classes with 4 accumulator tiles per wave -- 168 registers, 16 bytes of scratch in the two-chunk
+// classes, three resident workgroups -- measured in round 6: 176.6-177.7 against 176.9-177.1 pairs/s, no gain)
 template <int KS, int NT, int TYP, int DY, int CGS>
 __global__ __launch_bounds__(kBlock, 2) void conv_fwd_split_kernel(const SplitArgs a) {
     conv_fwd_split_block<KS, NT, TYP, DY, CGS>(a, (int)blockIdx.x, (int)blockIdx.y);
