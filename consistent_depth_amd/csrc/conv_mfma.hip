@@ -558,7 +558,9 @@ int cd_conv2d_pack_weights(const float* w, int Cout, int Cin, int ks, int transp
 
 int cd_conv2d_pack_weights_table(const void* table_dev, int n, void* stream) {
     if (!table_dev || n <= 0 || n > 65535) return CD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(cd::pack_weights_table_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const cd::PackDesc*)table_dev);
+    // (64 workgroups per descriptor since round 6 -- 16 left the largest filters to 4096 threads each, a latency chain at the top of every
+    // forward: 180.5 -> 182.1 pairs/s, four alternations on one box, profiles/conv_phases_r06.txt)
+    hipLaunchKernelGGL(cd::pack_weights_table_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const cd::PackDesc*)table_dev);
     CD_CHECK_LAUNCH();
     const int rc = cd::launch_pack_split_table(table_dev, n, (hipStream_t)stream);
     return rc != CD_OK ? rc : cd::launch_pack_1x1_table(table_dev, n, (hipStream_t)stream);
@@ -572,7 +574,7 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     if ((in_scale == nullptr) != (in_shift == nullptr)) return CD_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int pack_cot = cd::pick_co_tiles(ks, Cout);
-    if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16)) return CD_ERR_INVALID_ARG;
+    if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16 || tile_rows == 32)) return CD_ERR_INVALID_ARG;
     if (!(co_tiles == 0 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4 || co_tiles == 8 || co_tiles == 16)) return CD_ERR_INVALID_ARG;
     // (small images -- fewer 32-pixel tiles than the chip has waves -- stay on the staged fp32 kernel: measured equal or faster there)
     if (cd::g_conv_arith == 2 && cd::split_1x1_supported(ks, Cout, Cin) && (size_t)N * x_ctot * H * W < ((size_t)1 << 30) &&
@@ -591,6 +593,7 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
         return cd::launch_conv_split(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift,
                                      in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, ks, sty, scot, s);
     }
+    if (tile_rows == 32) return CD_ERR_UNSUPPORTED;       // (a launch shape of the split-bf16 k x k kernels only)
     int ty, cot;
     cd::pick_conv_tile(ks, pack_cot, Cout, N, H, W, &ty, &cot);
     const int max_cot = cd::max_co_tiles(ks, Cout);
@@ -638,7 +641,7 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
 
 int cd_conv2d_fwd_multi(const cd_conv_desc* d, int n, int tile_rows, int co_tiles, void* stream) {
     if (!d || n < 1 || n > 4) return CD_ERR_INVALID_ARG;
-    if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16) || !(co_tiles == 0 || co_tiles == 1 || co_tiles == 2)) return CD_ERR_INVALID_ARG;
+    if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16 || tile_rows == 32) || !(co_tiles == 0 || co_tiles == 1 || co_tiles == 2)) return CD_ERR_INVALID_ARG;
     if (cd::g_conv_arith < 1) return CD_ERR_UNSUPPORTED;      // the fp32-instruction kernels have no multi-convolution dispatch
     cd::SplitConv c[4];
     for (int i = 0; i < n; ++i) {

@@ -126,7 +126,7 @@ __global__ void pack_split_table_kernel(const PackDesc* __restrict__ table) {
 }
 
 int launch_pack_split_table(const void* table_dev, int n, hipStream_t s) {
-    hipLaunchKernelGGL(pack_split_table_kernel, dim3(16, n), dim3(256), 0, s, (const PackDesc*)table_dev);
+    hipLaunchKernelGGL(pack_split_table_kernel, dim3(64, n), dim3(256), 0, s, (const PackDesc*)table_dev);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
@@ -586,6 +586,10 @@ int launch_conv_split_multi(const SplitConv* c, int n, int N, int H, int W, int 
     for (int i = 0; i < n; ++i)
         if (!split_supported(c[i].ks)) return CD_ERR_UNSUPPORTED;
     const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
+    if (ty >= 32) {     // hint 32 (round 6): 8 M-tiles AND two channel chunks per barrier round -- 32 output channels per column tile only
+        if (split_dy(Cout) == 2 || nt == 2) return CD_ERR_UNSUPPORTED;
+        return launch_split_multi_t<1, 8, 1, 2>(c, n, N, H, W, Cout, s);
+    }
     const bool two = ty >= 16;
     const int mb = (nt == 2 || ty <= 4 || two) ? 4 : 8;
     if (split_dy(Cout) == 2) {     // <= 16 output channels: 16 channels x 2 output rows per column tile (the shapes of launch_conv_split)
@@ -623,6 +627,8 @@ int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const flo
                       int H, int W, int ks, int ty, int cot, hipStream_t s, const ConvGroups& grp) {
     const int dy = split_dy(Cout);
     const int nt = (cot >= 2 && split_ntiles(Cout) >= 2) ? 2 : 1;
+    const bool wide2 = ty >= 32;                      // hint 32: 8 M-tiles, two channel chunks per barrier round (half the rounds of the 8-tile class)
+    if (wide2 && (dy == 2 || nt == 2)) return CD_ERR_UNSUPPORTED;
     const bool two = ty >= 16;                        // hint 16: 4 M-tiles, two channel chunks per barrier round (latency-bound small images)
     const int mb = (nt == 2 || ty <= 4 || two) ? 4 : 8;
 #define CD_SP(K, T, Y, D, G) return launch_split_t<K, T, Y, D, G>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, grp, s)
@@ -630,6 +636,7 @@ int launch_conv_split(const float* x, int x_ctot, int x_coff, int Cin, const flo
     if (ks == K) {                                                   \
         if (dy == 2) { if (mb == 8) CD_SP(K, 1, 16, 2, 1); if (two) CD_SP(K, 1, 8, 2, 2); CD_SP(K, 1, 8, 2, 1); } \
         if (nt == 2) { if (two) CD_SP(K, 2, 4, 1, 2); CD_SP(K, 2, 4, 1, 1); }  \
+        if (wide2) CD_SP(K, 1, 8, 1, 2);                             \
         if (mb == 8) CD_SP(K, 1, 8, 1, 1);                           \
         if (two) CD_SP(K, 1, 4, 1, 2);                               \
         CD_SP(K, 1, 4, 1, 1);                                        \

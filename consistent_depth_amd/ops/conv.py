@@ -90,6 +90,10 @@ def _save_tune_cache():
         pass
 
 
+# launch-shape hints the tuners try (CD_AMD_CONV_SHAPE32=0: without round 6's 8-tile / two-chunk shape -- A/B measurements)
+_TILE_HINTS = (4, 8, 16, 32) if os.environ.get("CD_AMD_CONV_SHAPE32", "1") != "0" else (4, 8, 16)
+
+
 def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=False, stats=False, accumulate=False,
                  x_ctot=None, y_ctot=None, iters=3):
     """(tile_rows, co_tiles) of the fastest launch shape for this convolution, measured once per distinct
@@ -113,9 +117,9 @@ def tuned_config(ks, Cin, Cout, N, H, W, device, *, affine_in=False, relu_in=Fal
     max_cot = _native.lib().cd_conv2d_packed_co_tiles(Cout, ks)
     best, best_t = None, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for ty in (4, 8, 16):
+    for ty in _TILE_HINTS:        # (32: 8 row tiles + two channel chunks per round, split-bf16 k x k kernels only -- refused elsewhere)
         for cot in (1, 2, 4, 8, 16):
-            if cot > max_cot or (cot == 16 and ty > 4) or (cot == 8 and ty > 8):
+            if cot > max_cot or (cot == 16 and ty > 4) or (cot == 8 and ty > 8) or (ty == 32 and cot > 1):
                 continue
 
             def run():
@@ -213,9 +217,13 @@ def tuned_multi(members, single_cfgs, iters=3):
     # (round 4 compared every later shape with 0.97 x the best MERGED time: a shape 1-2 % faster than the accepted one was rejected)
     single_t = timed(singles)
     best, best_t = None, float("inf")
-    for ty in (4, 8, 16):
+    for ty in _TILE_HINTS:
         for cot in (1, 2):
+            if ty == 32 and cot > 1:
+                continue
             if not conv2d_multi(members, (ty, cot)):
+                if ty == 32:        # (that shape exists for 32 output channels per column tile only)
+                    continue
                 _TUNED[key] = None
                 return None
             t = timed(lambda: conv2d_multi(members, (ty, cot)))

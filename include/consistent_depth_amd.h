@@ -263,7 +263,8 @@ int cd_conv2d_fwd(const float* x, int x_ctot, int x_coff, int Cin, const float* 
                   const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                   float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
                   int N, int H, int W, int ks, void* stream);
-/* The same with the launch shape chosen by the caller: tile_rows in {4, 8, 16} output rows per workgroup and
+/* The same with the launch shape chosen by the caller: tile_rows in {4, 8, 16, 32} (32, ABI 9: a shape of the split-bf16 k x k kernels
+ * with 32 output channels per column tile only -- 8 row tiles AND two channel chunks per barrier round; CD_ERR_UNSUPPORTED elsewhere) and
  * co_tiles in {1, 2, 4, 8, 16} 16-wide output-channel slices per workgroup (clamped to cd_conv2d_packed_co_tiles; 8 and
  * 16 exist for 1x1 filters only, with at most 8 / 4 tile rows: one workgroup then computes up to 256 channels);
  * 0 = built-in heuristic.  The result does not depend on the choice (the order of accumulation is fixed), only the

@@ -193,14 +193,19 @@ def test_launch_shapes_are_bit_identical(N, Cin, Cout, H, W, ks, pipe):
     outs = []
     try:
         lib.cd_debug_set_conv_pipeline(pipe)
-        for ty in (4, 8, 16):
+        for ty in (4, 8, 16, 32):
             for cot in (1, 2, 4, 8, 16):
-                if cot > max_cot or (cot == 16 and ty > 4) or (cot == 8 and ty > 8):
+                if cot > max_cot or (cot == 16 and ty > 4) or (cot == 8 and ty > 8) or (ty == 32 and cot > 1):
                     continue
                 out = base.clone()
                 stats = layers.new_stats(Cout + 3, "cuda")
-                conv.conv2d(x, pk, Cin, Cout, ks, bias=b, x_coff=2, out=out, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True,
-                            stats=stats, accumulate=True, cfg=(ty, cot))
+                try:
+                    conv.conv2d(x, pk, Cin, Cout, ks, bias=b, x_coff=2, out=out, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True,
+                                stats=stats, accumulate=True, cfg=(ty, cot))
+                except RuntimeError:
+                    if ty != 32:        # (hint 32 is a shape of the split-bf16 k x k kernels with > 16 output channels only: refused elsewhere)
+                        raise
+                    continue
                 outs.append(((ty, cot), out, stats.sum(0)))
     finally:
         lib.cd_debug_set_conv_pipeline(1)
@@ -216,7 +221,7 @@ def test_launch_shapes_are_bit_identical(N, Cin, Cout, H, W, ks, pipe):
 def test_autotuner_returns_a_valid_cached_launch_shape():
     from consistent_depth_amd.ops import conv
     cfg = conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True)
-    assert cfg is not None and cfg[0] in (4, 8, 16) and cfg[1] in (1, 2, 4)
+    assert cfg is not None and cfg[0] in (4, 8, 16, 32) and cfg[1] in (1, 2, 4)
     assert conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True) is cfg or \
         conv.tuned_config(3, 32, 64, 2, 24, 32, "cuda", affine_in=True, relu_in=True, stats=True) == cfg
 
@@ -315,7 +320,7 @@ def test_weight_gradients_of_many_convolutions_in_one_launch_per_class(arith):
 
 @pytest.mark.parametrize("N,H,W,cin,cout,kss", [(8, 24, 14, 32, 64, (7, 5, 3)), (8, 48, 28, 64, 64, (11, 7, 3)), (4, 96, 56, 32, 32, (7, 5, 3)),
                                                  (2, 40, 72, 64, 32, (11, 7, 3)), (2, 33, 47, 24, 40, (5, 3)), (2, 40, 72, 64, 16, (11, 7, 3)), (4, 48, 64, 32, 16, (11, 7, 3))])
-@pytest.mark.parametrize("cfg", [(4, 1), (8, 1), (16, 1), (4, 2), (16, 2)])
+@pytest.mark.parametrize("cfg", [(4, 1), (8, 1), (16, 1), (4, 2), (16, 2), (32, 1)])
 def test_branches_of_an_inception_in_one_dispatch(arith, N, H, W, cin, cout, kss, cfg):
     """cd_conv2d_fwd_multi: the k x k branches of an inception (different filter sizes, different input slices of ONE buffer, adjacent
     output slices, producer's BatchNorm applied on load, batch statistics in the epilogue) in one dispatch vs one launch each -- outputs
@@ -323,6 +328,8 @@ def test_branches_of_an_inception_in_one_dispatch(arith, N, H, W, cin, cout, kss
     import torch
     from consistent_depth_amd import _native
     from consistent_depth_amd.ops import conv
+    if cfg[0] == 32 and (arith == "fp32" or cout <= 16):
+        pytest.skip("launch shape 32 (8 row tiles + two chunks per round): split-bf16 kernels with 32 output channels per column tile only")
     g = torch.Generator(device="cuda").manual_seed(11)
     nb = len(kss)
     P = torch.randn(N, nb * cin + nb * cout, H, W, device="cuda", generator=g)

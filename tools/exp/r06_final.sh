@@ -31,3 +31,8 @@ find gpurun_out -type d -name "trace" -prune -exec rm -rf {} + 2>/dev/null
 find gpurun_out -type d -name "pmc_*" -prune -exec rm -rf {} + 2>/dev/null
 head -30 gpurun_out/step_breakdown_serial_r06.txt; head -12 gpurun_out/prof_r06/summary.txt; cat gpurun_out/loss_bench_r06.txt
 du -sh gpurun_out
+# pack tables with 64 instead of 16 workgroups per descriptor (A/B, four alternations)
+for rep in 1 2 3 4; do for v in base p64; do
+  L=""; [ $v != base ] && L=$PWD/tools/exp/variants/libcd_amd_$v.so
+  CD_AMD_LIB=$L python bench.py $B --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'])"
+done; done | tee gpurun_out/p64_variants.txt
