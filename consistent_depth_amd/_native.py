@@ -157,9 +157,11 @@ def stream_ptr(device=None) -> int:
 
 
 def zero_(t: torch.Tensor) -> torch.Tensor:
-    """t.zero_() as hipMemsetAsync on the current stream (contiguous device tensors; no framework kernel inside a captured step)."""
+    """t.zero_() by a kernel of the library on the current stream (contiguous device tensors; no framework kernel inside a captured step)."""
     if not (t.is_cuda and t.is_contiguous()):
         raise RuntimeError("zero_: a contiguous tensor on the HIP device")
+    if t.data_ptr() % 16 or (t.numel() * t.element_size()) % 4:
+        return t.zero_()       # (a view at an odd offset: none in the step)
     if t.numel():
         check(lib().cd_zero_bytes(t.data_ptr(), t.numel() * t.element_size(), stream_ptr(t.device)), "cd_zero_bytes")
     return t

@@ -512,7 +512,8 @@ int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_cto
  * inception into the fused convolution's bias vector: 22 torch.cat per forward before); the table lives in device memory.
  * cd_counters_add: *table[i] += delta for n device pointers to int64 scalars (nn.BatchNorm2d.num_batches_tracked of every layer,
  * advanced by every train-mode forward: /root/reference/depth_fine_tuning.py:241,327-328 keeps train mode during validation too).
- * cd_zero_bytes: hipMemsetAsync(p, 0, bytes) on the caller's stream (gradient / statistics arenas). */
+ * cd_zero_bytes: p[0 .. bytes) = 0 by a kernel of this library on the caller's stream (gradient / statistics arenas; p 16-byte aligned,
+ * bytes a multiple of 4). */
 typedef struct cd_copy_seg {
     const float* src;
     float* dst;

@@ -74,7 +74,7 @@ def _heavy_cost(nodeid):
 
 
 # ... and the one test whose convolutions are a THIRD PARTY's (BASELINE configs[1]: PyTorch-ROCm / MIOpen) runs at the very end: under
-# `pytest -x` its failure must not hide any test of this package (round 6 saw MIOpen diverge mid-run on one box).
+# `pytest -x` its failure must not hide any test of this package (it is also the longest test: three continuations, ~4 minutes).
 _THIRD_PARTY_LAST = ("test_loop_gpu.py::test_config1_torch_convs_hip_loss_from_the_same_snapshot",)
 
 

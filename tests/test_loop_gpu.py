@@ -198,7 +198,7 @@ def _curves(title, rows, z, extra=None, direct=None):
             f.write(text + "\n")
 
 
-def _check_direct(rows_direct, z, final_direct, slack=1.5, late_floor=1e-3, n_outright=14):
+def _check_direct(rows_direct, z, final_direct, slack=1.5, late_floor=1e-3, n_outright=14, late_scatter=1.0):
     """Product vs the reference's OWN fp32 run (the path BASELINE.json names), measured in round 6 (profiles/parity_direct_r06.txt): the two
     fp32 evaluations of one run are NOT closer to each other than each is to the fp64 truth -- depth maps 1.55e-2 apart after 20 epochs
     (1.60e-2 / 1.60e-2 from fp64), 3.6e-4 after the first compared epoch; their errors against fp64 are half correlated at EVERY epoch
@@ -215,8 +215,15 @@ def _check_direct(rows_direct, z, final_direct, slack=1.5, late_floor=1e-3, n_ou
             if name == "perpair_max":
                 continue
             env[name] = max(env.get(name, 0.0), y.get(name, 0.0))
-            if not v <= max(floor, slack * env[name]):
-                bad.append((e, name, v, max(floor, slack * env[name])))
+            scat = late_scatter if (i >= n_outright and name in ("mean", "perpair")) else 1.0      # (as _check_full_length)
+            if not v <= max(scat * floor, slack * env[name]):
+                bad.append((e, name, v, max(scat * floor, slack * env[name])))
+    late = [e for e in rows_direct][n_outright:]
+    if late_scatter > 1.0 and late:
+        for name in ("mean", "perpair"):
+            med = float(np.median([rows_direct[e][name] for e in late]))
+            if not med <= max(late_floor, slack * float(np.median([(_yardstick(z, e) or {}).get(name, 0.0) for e in late]))):
+                bad.append(("late median", name, med, late_floor))
     for name, (v, yv) in final_direct.items():
         if not v <= max(1e-3, slack * yv):
             bad.append(("final", name, v, max(1e-3, slack * yv)))
@@ -227,7 +234,7 @@ def _check_direct(rows_direct, z, final_direct, slack=1.5, late_floor=1e-3, n_ou
     assert rows_direct[e0]["evaldepth"] <= 1e-3 and rows_direct[e0]["ckpt"] <= 1e-3, rows_direct[e0]
 
 
-def _check_full_length(spec, rows, z, res_final, coverage, slack=1.5, late_floor=1e-3, n_outright=15):
+def _check_full_length(spec, rows, z, res_final, coverage, slack=1.5, late_floor=1e-3, n_outright=15, late_scatter=1.0):
     """The bounds of the full-length parity tests, in one place.  Measured (profiles/parity_20ep_r05.txt): over 200 steps the
     round-off of ANY float32 evaluation of this training run is amplified -- the reference's own arithmetic (fp32 on the CPU, continued
     from the same state) ends 1.5e-2 from its fp64 self in the depth maps and 1.8e-2 in the weights, on the clip whose masks leave
@@ -246,9 +253,19 @@ def _check_full_length(spec, rows, z, res_final, coverage, slack=1.5, late_floor
             # (how far the reference's own arithmetic HAS been off by now) is the envelope -- epoch-by-epoch ratios of two such
             # realisations scatter by 2x (configs[1], epoch 22: 1.06e-3 against 5.6e-4, after the reference's 1.45e-3 at epoch 21)
             env[name] = max(env.get(name, 0.0), y.get(name, 0.0))
-            bound = max(floor, slack * env[name])
+            # late_scatter (configs[1] only): a LOSS of a late epoch may scatter up to late_scatter x the floor in a single epoch as long
+            # as the MEDIAN over the late epochs keeps the floor (below) -- the per-epoch value of a chaotic quantity is bounded as a
+            # statistic, not run by run (round 5 widened this bound three times after single excursions)
+            scat = late_scatter if (i >= n_outright and name in ("mean", "perpair")) else 1.0
+            bound = max(scat * floor, slack * env[name])
             if not v <= bound:
                 bad.append((e, name, v, bound, y.get(name)))
+    late = [e for e in rows][n_outright:]
+    if late_scatter > 1.0 and late:
+        for name in ("mean", "perpair"):
+            med = float(np.median([rows[e][name] for e in late]))
+            if not med <= max(late_floor, slack * float(np.median([(_yardstick(z, e) or {}).get(name, 0.0) for e in late]))):
+                bad.append(("late median", name, med, late_floor, None))
     for name, (v, yv) in res_final.items():
         bound = max(1e-3, slack * yv)
         if not v <= bound:
@@ -358,53 +375,60 @@ def test_config1_torch_convs_hip_loss_from_the_same_snapshot(tmp_path, monkeypat
     del ft0
     torch.cuda.empty_cache()
     monkeypatch.setenv("CD_AMD_MC_BACKEND", "torch")
-    # MIOpen configuration: immediate-mode selection (no find).  Round 6 also PINNED it to deterministic solvers (torch passes
-    # MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC) -- one box ran the 20 epochs inside the product path's bounds, the next one DIVERGED from
-    # the 3rd compared epoch on (weights 5e-2 -> 33 from fp64, losses 1e-1: profiles/parity_20ep_r06.txt, second block) after two clean
-    # epochs: the library switched to another solver mid-run.  The pin is off again (round 5's configuration: seven runs, all sane).
+    # MIOpen configuration: immediate-mode selection (no find), atomics-based weight gradients: this configuration is NOT reproducible run
+    # to run, every run is another realisation of the amplified round-off (the HIP path's runs are bitwise repeats).  Round 5 fitted its
+    # bounds to six single runs, one excursion at a time.  Round 6: the test makes RUNS = 3 continuations from the
+    # same snapshot (the first one compiles MIOpen's kernels: ~150 s; the others ~25 s each) and bounds the per-epoch MEDIAN over the runs
+    # with the bounds round 5 ended with (2 x the yardstick's running maximum, 1e-3 outright for the losses of the first 12 compared epochs,
+    # 2e-3 beyond; a late epoch's loss may scatter to 3 x that in one epoch while the median over the late epochs keeps it).
+    # (History of this test in round 6, so that nobody repeats it: a first build zeroed FlatAdam's gradient buffer with hipMemsetAsync
+    # instead of a kernel -- configs[1], whose gradients torch's autograd ACCUMULATES into that buffer, then diverged in half of its runs,
+    # on any box, with or without deterministic MIOpen solvers; 0 of 8 runs since cd_zero_bytes is a kernel.  The HIP engine never
+    # noticed: its first gradient contribution overwrites.  gpurun_out/config1_bisect*.txt -> HISTORY.md.)
     monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
-    path = str(tmp_path / "torch" / "clip")
-    range_dir, _ = msd.write_dataset(path, **S["clip"])
-    params = Video3dParamsParser().parse(["--path", path, "--num_epochs", str(K + T), "--batch_size", "4", "--print_freq", "0"])
-    ft = DepthFineTuner(range_dir, list(range(S["clip"]["n_frames"])), params)
-    assert ft.model.backend == "torch" and ft.model._engine is None
     n_pairs = len(z["pair_order"])
-    with pytest.raises(ValueError, match="exp_avg_sq must hold exactly"):       # (a moment dict that does not cover the parameters: a clear error)
-        ft.resume_from(snap["state"], snap["m1"], {k: v for i, (k, v) in enumerate(snap["m2"].items()) if i}, snap["k"], epoch=K, total_iters=K * n_pairs)
-    ft.resume_from(snap["state"], snap["m1"], snap["m2"], snap["k"], epoch=K, total_iters=K * n_pairs)
     want_plans = json.loads(str(z["plans"]))
     pair_id = {tuple(p): i for i, p in enumerate(z["pair_order"].tolist())}
-    ft.epoch_plan = lambda e: [[pair_id[tuple(p)] for p in batch] for batch in want_plans[str(e)]]
-    ft.fine_tune()
-    assert [list(map(int, pr)) for pr in ft.store.pair_indices()] == z["pair_order"].tolist()
-    got = G.collect(ft.out_dir, n_pairs, K, T)
-    assert [int(e) for e in got["epochs"]] == epochs
-    rows = G.distances(got, z, epochs)
-    direct = G.distances(got, z, epochs, prefix="ref32_") if "ref32_ckpt_sample" in z.files else None
-    _curves(f"configs[1] (MIOpen convolutions + HIP loss) continued from clip 'a' snapshot, epochs {epochs[0]}..{epochs[-1]}", rows, z,
-            {"burn_in_state_bitwise": same_state, "miopen_deterministic": bool(torch.backends.cudnn.deterministic)}, direct=direct)
-    assert epochs and len(epochs) >= 2
+    RUNS = int(os.environ.get("CD_AMD_TEST_CONFIG1_RUNS", "3"))
+    all_rows, all_direct = [], []
+    for run in range(RUNS):
+        path = str(tmp_path / f"torch{run}" / "clip")
+        range_dir, _ = msd.write_dataset(path, **S["clip"])
+        params = Video3dParamsParser().parse(["--path", path, "--num_epochs", str(K + T), "--batch_size", "4", "--print_freq", "0"])
+        ft = DepthFineTuner(range_dir, list(range(S["clip"]["n_frames"])), params)
+        assert ft.model.backend == "torch" and ft.model._engine is None
+        if run == 0:
+            with pytest.raises(ValueError, match="exp_avg_sq must hold exactly"):       # (a moment dict that does not cover the parameters: a clear error)
+                ft.resume_from(snap["state"], snap["m1"], {k: v for i, (k, v) in enumerate(snap["m2"].items()) if i}, snap["k"], epoch=K,
+                               total_iters=K * n_pairs)
+        ft.resume_from(snap["state"], snap["m1"], snap["m2"], snap["k"], epoch=K, total_iters=K * n_pairs)
+        ft.epoch_plan = lambda e: [[pair_id[tuple(p)] for p in batch] for batch in want_plans[str(e)]]
+        ft.fine_tune()
+        assert [list(map(int, pr)) for pr in ft.store.pair_indices()] == z["pair_order"].tolist()
+        got = G.collect(ft.out_dir, n_pairs, K, T)
+        assert [int(e) for e in got["epochs"]] == epochs
+        all_rows.append(G.distances(got, z, epochs))
+        all_direct.append(G.distances(got, z, epochs, prefix="ref32_") if "ref32_ckpt_sample" in z.files else None)
+        _curves(f"configs[1] (MIOpen convolutions + HIP loss) continued from clip 'a' snapshot, run {run + 1} of {RUNS}, epochs {epochs[0]}..{epochs[-1]}",
+                all_rows[-1], z, {"burn_in_state_bitwise": same_state}, direct=all_direct[-1])
+        del ft
+        torch.cuda.empty_cache()
+
+    def median_rows(runs):
+        return {e: {c: float(np.median([r[e][c] for r in runs])) for c in runs[0][e]} for e in epochs}
+    rows = median_rows(all_rows)
+    direct = median_rows(all_direct) if all_direct[0] is not None else None
+    _curves(f"configs[1]: per-epoch MEDIAN over {RUNS} runs", rows, z, {"runs": RUNS}, direct=direct)
     worst = {c: max(r[c] for r in rows.values()) for c in ("mean", "perpair", "evaldepth", "ckpt")}
-    report(f"loop_384x224_config1[K{K},T{T}]", burn_in_state_bitwise=same_state, **{"worst_" + k: v for k, v in worst.items()})
-    # MIOpen's weight gradients use atomics and its algorithm choice differs from box to box: this configuration is not run-to-run
-    # reproducible, every run is ANOTHER realisation of the amplified round-off (the HIP path's runs are bitwise repeats).  Six runs of one
-    # afternoon: four inside the product path's bounds; one with the last epoch's mean loss at 1.32e-3 against the yardstick's running
-    # maximum 8.7e-4, one with epoch 18's at 1.06e-3 where the yardstick had reached 3.6e-4.  So for THIS configuration: the envelope is
-    # 2 x (1.5 x for the bit-reproducible product path), the first 12 compared epochs must meet 1e-3 outright (15 for the product path;
-    # epoch 18 is the 15th), and beyond them the floor is 2e-3 (the reference's own fp32 arithmetic is at 1.45e-3 by epoch 21).
-    # A run that starts inside the bounds (the resumed state, the HIP loss and the loop are right: the first two compared epochs are checked
-    # on their own) and then leaves them by an ORDER OF MAGNITUDE is the convolution library changing its arithmetic under the run
-    # (observed once in round 6, see above) -- not a property of this package, whose own convolutions run the same epochs in
-    # test_full_length_run_vs_fp64_and_vs_the_reference_fp32_run: reported as an expected failure of the third party, with the numbers.
-    first = {e: rows[e] for e in epochs[:2]}
-    _check_full_length(spec, first, z, {}, None, slack=2.0, late_floor=2e-3, n_outright=12)
+    single = {c: max(r[e][c] for r in all_rows for e in epochs) for c in ("mean", "perpair", "evaldepth", "ckpt")}
+    report(f"loop_384x224_config1[K{K},T{T},runs{RUNS}]", burn_in_state_bitwise=same_state, **{"median_worst_" + k: v for k, v in worst.items()},
+           **{"single_run_worst_" + k: v for k, v in single.items()})
+    _check_full_length(spec, rows, z, {}, None, slack=2.0, late_floor=2e-3, n_outright=12, late_scatter=3.0)
+    if direct:      # ... and against the reference's own fp32 run, same envelope
+        _check_direct(direct, z, {}, slack=2.0, late_floor=2e-3, n_outright=12, late_scatter=3.0)
+    # no single run may leave the envelope by an order of magnitude (what a broken step looks like: weights 5e-2 ... 33 from fp64)
     env = 0.0
     for e in epochs:
         env = max(env, (_yardstick(z, e) or {}).get("ckpt", 0.0))
-        if rows[e]["ckpt"] > 10 * max(2e-3, 2.0 * env):
-            pytest.xfail(f"PyTorch-ROCm / MIOpen convolutions diverged mid-run: checkpoint {rows[e]['ckpt']:.2e} from fp64 at epoch {e} "
-                         f"(envelope {max(2e-3, 2.0 * env):.2e}) after clean epochs {epochs[0]}-{epochs[1]}; the HIP engine's run of the same epochs is "
-                         f"asserted by the full-length test")
-    _check_full_length(spec, rows, z, {}, None, slack=2.0, late_floor=2e-3, n_outright=12)
-    if direct:      # ... and against the reference's own fp32 run, same envelope
-        _check_direct(direct, z, {}, slack=2.0, late_floor=2e-3, n_outright=12)
+        for r in all_rows:
+            assert r[e]["ckpt"] <= 5 * max(2e-3, 2.0 * env) and r[e]["mean"] <= 2e-2, (e, r[e])
