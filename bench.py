@@ -494,8 +494,8 @@ def main():
                            "1 / (2/3 / 157.3 + 1/3 / 416.7) = 198.4 TFLOP/s the fraction is frac x 0.793"
                            if args.model == "midas2" and args.backend == "hip" else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)")),
             "frac_of_fp32_mfma_peak": round(ach_tf / MFMA_FP32_PEAK_TFLOPS, 4),
-            "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r04.txt (SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES per kernel family), "
-                                "profiles/conv_roofline_r04.txt (per launch)"}
+            "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r06.txt (SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES per kernel family), "
+                                "profiles/conv_roofline_r06.txt (per launch)"}
         in_step_ms = float(np.mean(ms_step)) if len(ms_step) else None
         if in_step_ms:
             ach = LOSS_BYTES_PER_PAIR_PX * px * B / (in_step_ms * 1e-3) / 1e9
