@@ -54,9 +54,23 @@ __global__ __launch_bounds__(kBlock) void loss_main_kernel(
             float vin[VEC], fx[VEC], fy[VEC], m[VEC];
             using V = typename VecT<VEC>::type;
             *reinterpret_cast<V*>(vin) = *reinterpret_cast<const V*>(v_ref + p0);
-            *reinterpret_cast<V*>(fx) = *reinterpret_cast<const V*>(fl + p0);
-            *reinterpret_cast<V*>(fy) = *reinterpret_cast<const V*>(fl + HW + p0);
-            *reinterpret_cast<V*>(m) = *reinterpret_cast<const V*>(mk + p0);
+            // flow / mask are read once per call: non-temporal (round 6: as in the row sweep, loss_sweep_core.h); the depth plane is
+            // also the other direction's gather target: default policy
+            typedef float nt_t __attribute__((ext_vector_type(VEC)));
+#ifndef CD_V1_NT
+#define CD_V1_NT 1
+#endif
+            if (CD_V1_NT) {
+                const nt_t a = __builtin_nontemporal_load(reinterpret_cast<const nt_t*>(fl + p0));
+                const nt_t b2 = __builtin_nontemporal_load(reinterpret_cast<const nt_t*>(fl + HW + p0));
+                const nt_t c = __builtin_nontemporal_load(reinterpret_cast<const nt_t*>(mk + p0));
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { fx[i] = a[i]; fy[i] = b2[i]; m[i] = c[i]; }
+            } else {
+                *reinterpret_cast<V*>(fx) = *reinterpret_cast<const V*>(fl + p0);
+                *reinterpret_cast<V*>(fy) = *reinterpret_cast<const V*>(fl + HW + p0);
+                *reinterpret_cast<V*>(m) = *reinterpret_cast<const V*>(mk + p0);
+            }
             const int y = p0 / W;  // the VEC pixels share a row (W % VEC == 0)
             const int x0 = p0 - y * W;
             const float yf = (float)y;

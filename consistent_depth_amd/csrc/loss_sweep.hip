@@ -228,7 +228,7 @@ __device__ __forceinline__ PairReq pair_constants_request(const PairPrep& pp, co
     if (t < 2 * NS) {
         const int j = t / NS;
         unit_sample_xy(H, W, t % NS, &q.sx, &q.sy);
-        unit_sample_load_own(q.ul, depth_p + (j ? HW : 0), j ? fb : ff, j ? mb : mf, H, W, q.sx, q.sy);
+        unit_sample_load_own(q.ul, depth_p + (j ? HW : 0), depth_p + (j ? 0 : HW), j ? fb : ff, j ? mb : mf, H, W, q.sx, q.sy);
     }
     if (t < kBlock && t < B)
         for (int k = 0; k < 2; ++k) { q.f0[k] = pp.intr[(t * 2 + k) * 4 + 0]; q.f1[k] = pp.intr[(t * 2 + k) * 4 + 1]; }
@@ -238,7 +238,7 @@ __device__ __forceinline__ PairReq pair_constants_request(const PairPrep& pp, co
     }
     return q;
 }
-// Part 2: the sampled depths (their positions need no camera: requested first), then the arithmetic in its old order -- same numbers.
+// Part 2: the arithmetic (round 6: no second read step -- the unit samples need one memory latency, loss_sweep_core.h).
 template <int MODE>
 __device__ __forceinline__ void pair_constants(WgState& st, float* scratch, const PairPrep& pp, PairReq& q, const float* __restrict__ depth_p,
                                                int B, int H, int W) {
@@ -246,7 +246,6 @@ __device__ __forceinline__ void pair_constants(WgState& st, float* scratch, cons
     static_assert(NS == kBlock, "fbar is reduced like prep_kernel does: 256 threads, 4 wave sums added in order");
     const int t = threadIdx.x, lane = t & (kWave - 1), wid = t / kWave;
     const int HW = H * W;
-    if (t < 2 * NS) unit_sample_load_taps(q.ul, depth_p + (t / NS ? 0 : HW), H, W, q.sx, q.sy);
     if (t >= 2 * NS && t < 2 * NS + 34) st.prep_in[t - 2 * NS] = q.pin;
     const float* f0 = q.f0; const float* f1 = q.f1;
     const UnitLoads& ul = q.ul;

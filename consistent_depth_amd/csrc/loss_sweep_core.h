@@ -269,25 +269,21 @@ constexpr int kUnitGrid = 16;
 
 struct UnitSample { float direct, scatter; int valid; };
 
-// one sample source (x, y) of direction j, in two steps: what it READS (mask, flow, own depth, the four sampled depths -- the tap
-// positions need no camera: sx, sy are W / (W - 1), H / (H - 1)) and what it COMPUTES from them with the pair's PairCam.  The kernel
-// issues the reads of all samples before the pair's constants exist (their two dependent memory latencies then overlap the
-// constants' own chain); the host emulation calls them back to back.  vj / vk: the raw depth planes of its frame / the other frame.
-struct UnitLoads { float m, fx, fy, vj, v00, v01, v10, v11; Taps t; };
-// (the reads in their two dependent steps: the sample's own pixel, then -- from its flow -- the four sampled depths)
-CD_HD void unit_sample_load_own(UnitLoads& l, const float* vj, const float* fl, const float* mk, int H, int W, int x, int y) {
+// one sample source (x, y) of direction j, in two steps: what it READS (mask, flow, its own depth and the OTHER frame's depth at the
+// same pixel) and what it COMPUTES from them with the pair's PairCam.  The kernel issues the reads of all samples at its very top, before
+// the pair's constants exist.  vj / vk: the raw depth planes of its frame / the other frame.
+// Round 6: the scatter magnitude used to come from the four depths the sample's FLOW points at -- a second, dependent memory latency
+// per workgroup behind 57 KB of window rows (`vmcnt` retires in order: the constants were ready 13 us after kernel entry, 8 % of a
+// 256-pair call).  The estimate only fixes a power of two: the other frame's depth at the sample's own pixel stands in for the sampled
+// depth (the flow moves it by a few pixels of a smooth map), one latency, no tap arithmetic.
+struct UnitLoads { float m, fx, fy, vj, vk0; };
+CD_HD void unit_sample_load_own(UnitLoads& l, const float* vj, const float* vk, const float* fl, const float* mk, int H, int W, int x, int y) {
     const int HW = H * W, p = y * W + x;
-    l.m = mk[p]; l.fx = fl[p]; l.fy = fl[HW + p]; l.vj = vj[p];
-}
-CD_HD void unit_sample_load_taps(UnitLoads& l, const float* vk, int H, int W, int x, int y) {
-    l.t = tap_coords((float)x, (float)y, l.fx, l.fy, (float)W / (float)(W - 1), (float)H / (float)(H - 1), W, H);   // (= PairCam::sx, sy)
-    l.v00 = vk[l.t.ya * W + l.t.xa]; l.v01 = vk[l.t.ya * W + l.t.xb];
-    l.v10 = vk[l.t.yb * W + l.t.xa]; l.v11 = vk[l.t.yb * W + l.t.xb];
+    l.m = mk[p]; l.fx = fl[p]; l.fy = fl[HW + p]; l.vj = vj[p]; l.vk0 = vk[p];
 }
 CD_HD UnitLoads unit_sample_load(const float* vj, const float* vk, const float* fl, const float* mk, int H, int W, int x, int y) {
     UnitLoads l;
-    unit_sample_load_own(l, vj, fl, mk, H, W, x, y);
-    unit_sample_load_taps(l, vk, H, W, x, y);
+    unit_sample_load_own(l, vj, vk, fl, mk, H, W, x, y);
     return l;
 }
 template <int MODE>
@@ -296,10 +292,7 @@ CD_HD UnitSample unit_sample_eval(const PairCam& c, const UnitLoads& l, int x, i
     u.direct = u.scatter = 0.f; u.valid = 0;
     const float m = l.m;
     if (m == 0.f) return u;
-    const float d = to_depth<MODE>(l.vj);
-    const Taps& t = l.t;
-    const float d00 = to_depth<MODE>(l.v00), d01 = to_depth<MODE>(l.v01);
-    const float d10 = to_depth<MODE>(l.v10), d11 = to_depth<MODE>(l.v11);
+    const float d = to_depth<MODE>(l.vj), dk = to_depth<MODE>(l.vk0);
     const float r0 = ((float)x - c.cx_r) * c.ifx_r, r1 = -((float)y - c.cy_r) * c.ify_r;
     const float a0 = c.M[0] * r0 + c.M[1] * r1 - c.M[2], a1 = c.M[3] * r0 + c.M[4] * r1 - c.M[5], a2 = c.M[6] * r0 + c.M[7] * r1 - c.M[8];
     const float X = d * a0 + c.c[0], Y = d * a1 + c.c[1], Z = d * a2 + c.c[2];
@@ -308,11 +301,9 @@ CD_HD UnitSample unit_sample_eval(const PairCam& c, const UnitLoads& l, int x, i
     const float e2 = ex * ex + ey * ey;
     const float ie = e2 > 0.f ? 1.f / sqrtf(e2) : 0.f;
     const float dpx = c.fx_t * iZ * (X * a2 * iZ - a0), dpy = c.fy_t * iZ * (a1 - Y * a2 * iZ);
-    const float zs = -(d00 * t.w00 + d01 * t.w01 + d10 * t.w10 + d11 * t.w11);
-    const float izs = 1.f / zs;
+    const float izs = 1.f / dk;       // (|1 / zs| with zs = -(sampled depth) ~ -dk)
     const float direct = (fabsf(c.gr * m * (ex * dpx + ey * dpy) * ie) + fabsf(c.gb * m * a2 * iZ * iZ)) * fabsf(depth_jac<MODE>(d));
-    const float scat = fabsf(c.gb * m * izs * izs) * (t.w00 * fabsf(depth_jac<MODE>(d00)) + t.w01 * fabsf(depth_jac<MODE>(d01)) +
-                                                        t.w10 * fabsf(depth_jac<MODE>(d10)) + t.w11 * fabsf(depth_jac<MODE>(d11)));
+    const float scat = fabsf(c.gb * m * izs * izs) * fabsf(depth_jac<MODE>(dk));
     if (!(direct < INFINITY) || !(scat < INFINITY)) return u;   // NaN / inf: not a sample (such inputs end on the exact paths anyway)
     u.direct = direct; u.scatter = scat; u.valid = 1;
     return u;
