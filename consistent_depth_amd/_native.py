@@ -95,6 +95,7 @@ SIGNATURES = {
     "cd_maxpool3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_maxpool3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "cd_add_slice": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "cd_debug_set_layers_mode": (c_i, [c_i]),
     "cd_copy_segments": (c_i, [c_p, c_i, c_p]),
     "cd_counters_add": (c_i, [c_p, c_i, ctypes.c_longlong, c_p]),
     "cd_zero_bytes": (c_i, [c_p, c_sz, c_p]),

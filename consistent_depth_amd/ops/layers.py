@@ -139,6 +139,11 @@ def add_slice(src, s_coff, dst, d_coff, C, accumulate):
     _native.check(rc, "cd_add_slice")
 
 
+def set_layers_mode(bits):
+    """Test / measurement hook (cd_debug_set_layers_mode): bit 0 = the scalar streaming kernels of rounds 1-5."""
+    _native.check(_native.lib().cd_debug_set_layers_mode(int(bits)), "cd_debug_set_layers_mode")
+
+
 def channel_sum(src, coff, C, out, accumulate=False):
     N, ctot, H, W = src.shape
     rc = _native.lib().cd_channel_sum(_p(src), ctot, coff, C, N, H, W, _p(out), int(accumulate), _s(src))

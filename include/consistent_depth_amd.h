@@ -48,7 +48,8 @@ typedef enum cd_depth_mode {
  * (6: cd_conv2d_fwd_grouped / cd_conv2d_wgrad_grouped / cd_conv2d_wgrad_desc / cd_conv2d_wgrad_table /
  * cd_conv2d_fwd_multi added, cd_bn_relu_bwd's last
  * argument became a flags bitfield, cd_debug_set_loss_variant(2) is refused;
- * 9: cd_consistency_loss_workspace_init added -- a loss workspace must be initialised once before its first use).
+ * 9: cd_consistency_loss_workspace_init added -- a loss workspace must be initialised once before its first use; cd_copy_segments,
+ *    cd_counters_add, cd_zero_bytes, cd_debug_set_layers_mode added).
  * The loader (consistent_depth_amd/_native.py) refuses a library whose cd_abi_version() differs from this constant. */
 #define CD_ABI_VERSION 9
 int cd_abi_version(void);
@@ -507,6 +508,9 @@ int cd_maxpool3s2_bwd(const float* dy, const unsigned char* argmax, float* dx, i
 /* dst[:, d_coff:+C] (+)= src[:, s_coff:+C]  -- gradient fan-in of a tensor with several consumers. */
 int cd_add_slice(const float* src, int s_ctot, int s_coff, float* dst, int d_ctot, int d_coff, int C, int N,
                  int H, int W, int accumulate, void* stream);
+/* Test / measurement hook for the streaming layers above (avgpool2, upsample2x, add_slice): bit 0 selects the scalar kernels of rounds
+ * 1-5 instead of the 16-byte / LDS-band kernels of round 6.  Both give the same bits (tests/test_layers_gpu.py); 0 = normal. */
+int cd_debug_set_layers_mode(int bits);
 /* ABI 9.  Host-side chores of a step as ONE launch each (they were framework launches inside the captured step):
  * cd_copy_segments: table[i] = {src, dst, n}: n floats copied per entry (the biases of the four branch-entry 1x1 convolutions of every
  * inception into the fused convolution's bias vector: 22 torch.cat per forward before); the table lives in device memory.

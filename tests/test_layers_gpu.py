@@ -173,3 +173,61 @@ def test_pool_upsample_add_and_adjoints():
     s = torch.zeros(C).cuda()
     layers.channel_sum(do.float().cuda(), 0, C, s)
     np.testing.assert_allclose(s.cpu().numpy(), do.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,C,h,w", [(2, 3, 192, 112), (1, 2, 96, 56), (2, 2, 48, 28), (1, 3, 24, 14), (1, 2, 12, 7), (2, 2, 7, 12), (1, 2, 5, 4),
+                                     (1, 2, 4, 5), (1, 1, 67, 33), (1, 2, 3, 3), (1, 1, 2, 2), (1, 1, 1, 6), (1, 2, 192, 192), (1, 1, 130, 250)])
+def test_streaming_layer_kernels_give_the_bits_of_the_scalar_ones(N, C, h, w):
+    """Round 6: 16-byte forms of AvgPool2d(2) / UpsamplingBilinear2d(2)+add and their adjoints, an LDS-band form of the bilinear adjoint
+    (csrc/layers.hip::upsample2x_bwd_band_kernel) and equal-trip-count grids for the fan-in add.  Every one must give the bits of the
+    scalar kernel it replaces (cd_debug_set_layers_mode(1)): the hourglass step's bit-reproducibility and the goldens of
+    tests/test_loop_gpu.py rest on it.  Sizes: the four pyramid levels of 384x224, odd / tiny / degenerate planes (the band kernel's
+    fallbacks), planes wider than its LDS budget; channel offsets into wider buffers; with and without accumulate / skip tensor /
+    producer affine."""
+    import torch
+    from consistent_depth_amd.ops import layers
+    g = torch.Generator().manual_seed(100 * h + w)
+    H, W = 2 * h, 2 * w
+    lo = torch.randn(N, C + 2, h, w, generator=g).cuda()
+    hi = torch.randn(N, C + 1, H, W, generator=g).cuda()
+    do = torch.randn(N, C + 3, H, W, generator=g).cuda()
+    dlo0 = torch.randn(N, C + 1, h, w, generator=g).cuda()
+    sc, sh = (torch.rand(C + 2, generator=g) + 0.5).cuda(), (torch.randn(C + 2, generator=g) * 0.2).cuda()
+    hsc, hsh = (torch.rand(C + 1, generator=g) + 0.5).cuda(), (torch.randn(C + 1, generator=g) * 0.2).cuda()
+
+    def run_all():
+        res = []
+        for affine in (False, True):
+            for with_hi in (True, False):
+                out = torch.full((N, C + 1, H, W), 7.0, device="cuda")
+                layers.upsample2x_add_fwd(lo, 1, C, out, 1, hi=hi if with_hi else None, hi_coff=1 if with_hi else 0, lo_relu=affine, hi_relu=with_hi and affine,
+                                          lo_scale=sc[1:] if affine else None, lo_shift=sh[1:] if affine else None,
+                                          hi_scale=hsc[1:] if affine and with_hi else None, hi_shift=hsh[1:] if affine and with_hi else None)
+                res.append(out)
+        for acc in (False, True):
+            dlo = dlo0.clone()
+            layers.upsample2x_bwd(do, 2, dlo, 1, C, accumulate=acc)
+            res.append(dlo)
+            dhi = hi.clone()
+            layers.add_slice(do, 2, dhi, 1, C, accumulate=acc)
+            res.append(dhi)
+            dx = hi.clone()
+            layers.avgpool2_bwd(lo, 1, dx, 1, C, accumulate=acc)
+            res.append(dx)
+        for affine in (False, True):
+            y = torch.full((N, C + 2, h, w), 3.0, device="cuda")
+            layers.avgpool2_fwd(hi, 1, C, y, 2, in_relu=affine, in_scale=hsc[1:] if affine else None, in_shift=hsh[1:] if affine else None)
+            res.append(y)
+        torch.cuda.synchronize()
+        return res
+
+    try:
+        layers.set_layers_mode(1)
+        want = run_all()
+    finally:
+        layers.set_layers_mode(0)
+    got = run_all()
+    assert len(got) == len(want) == 12
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (i, (a - b).abs().max().item())
+

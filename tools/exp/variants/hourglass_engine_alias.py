@@ -503,18 +503,16 @@ class HourglassEngine:
     def _channels(self, plan, steps, mod: HG.Channels, x: Act, N, H, W) -> Act:
         sides = list(mod.list)
         up_side = 0 if isinstance(sides[0][-1], torch.nn.UpsamplingBilinear2d) else 1
-        # Both sides read x and both add into its gradient.  The backward passes of the two sides run concurrently (the full-resolution
-        # side on the level's stream); x's gradient gets the full-resolution side's contribution first (its last kernel, the first
-        # writer: it overwrites) and the pooled side's LAST kernel -- the adjoint of the AvgPool2d the side starts with -- waits for
-        # the other stream and accumulates (_run_backward).  Rounds 1-5 gave the full-resolution side an alias of x with its own gradient
-        # buffer and added the two at the join: a 528 MB pass at 384x224 (0.2 ms of a 22 ms step) for the sake of overlapping one
-        # 60 us kernel.  Same sum, same order as the single-stream C engine (csrc/hourglass.hip): bit-identical.
+        # the full-resolution side reads x through an alias with its OWN gradient buffer, so the two sides can run
+        # their backward passes concurrently; the alias' gradient is added into x's at the join
+        x_alias = Act(x.buf, x.coff, x.C, relu=x.relu, scale=x.scale, shift=x.shift, needs_grad=x.gbuf is not None)
         flat_steps, up_steps = [], []
-        flat, _, _, _ = self._sequence(plan, flat_steps, sides[1 - up_side], x, N, H, W)
+        flat, _, _, _ = self._sequence(plan, flat_steps, sides[1 - up_side], x_alias, N, H, W)
         lo, h, w, pending = self._sequence(plan, up_steps, sides[up_side], x, N, H, W)
-        assert pending and up_steps[0].kind == "pool" and up_steps[0].src is x
+        assert pending
         out = Act(self._new(N, flat.C, H, W), 0, flat.C)
-        steps.append(_Node("channels", level=mod.level, flat=flat_steps, up=up_steps, lo=lo, hi=flat, out=out, x=x))
+        steps.append(_Node("channels", level=mod.level, flat=flat_steps, up=up_steps, lo=lo, hi=flat, out=out, x=x,
+                           x_alias=x_alias))
         return out
 
     def _build(self, N, H, W):
@@ -630,10 +628,8 @@ class HourglassEngine:
                                      hi_relu=hi.relu, lo_scale=lo.scale, lo_shift=lo.shift, hi_scale=hi.scale,
                                      hi_shift=hi.shift)
 
-    def _run_backward(self, steps, before_last=None):
-        for i, step in enumerate(reversed(steps)):
-            if before_last is not None and i == len(steps) - 1:
-                before_last()
+    def _run_backward(self, steps):
+        for step in reversed(steps):
             if step.kind == "conv":
                 step.unit.backward(step.gbuf, step.g_coff)
             elif step.kind == "inception":
@@ -653,10 +649,12 @@ class HourglassEngine:
                 lo, hi, o = step.lo, step.hi, step.out
                 L.add_slice(o.gbuf, 0, hi.gbuf, hi.coff, hi.C, accumulate=hi.grad_mode())
                 L.upsample2x_bwd(o.gbuf, 0, lo.gbuf, lo.coff, lo.C, accumulate=lo.grad_mode())
-                # the full-resolution side is the first writer of x's gradient; the pooled side's last kernel (the AvgPool2d adjoint into
-                # x) is enqueued behind the join and accumulates
                 done = self._on_side(step.level, lambda: self._run_backward(step.flat))
-                self._run_backward(step.up, before_last=lambda: self._join(done))
+                self._run_backward(step.up)
+                self._join(done)
+                x, xa = step.x, step.x_alias
+                if x.gbuf is not None:
+                    L.add_slice(xa.gbuf, xa.coff, x.gbuf, x.coff, x.C, accumulate=x.grad_mode())
 
     @torch.no_grad()
     def _forward(self, x: torch.Tensor, need_grad: bool) -> torch.Tensor:
