@@ -303,6 +303,236 @@ static int launch_1x1_t(const float* x, int x_ctot, int x_coff, int Cin, const f
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------- the same GEMM for filters too large to stay in LDS (round 6)
+// Dense 1x1 convolutions with 512...2048 channels on small images (the ResNeXt-101 encoder of MiDaS v2, BASELINE configs[4]: 46 of its
+// 1x1 convolutions are 1024 x 1024 on 24 x 24 pixels) ran on the staged fp32-MFMA kernel at 44 TFLOP/s: a 64 x 1024 filter slice is
+// 393 KB of bf16 planes.  Here the slice travels through LDS in CHUNKS of 4 K-steps (64 input channels, 48 KB for 128 output
+// channels), double-buffered: a chunk is fetched into registers before the 96 MFMAs of the current one and written to the other
+// buffer after them, one barrier per chunk.  Everything else is the kernel above: activations straight from global memory into the A
+// fragment through a 4-deep register ring, six products per K-step, the same epilogue.  Pixel tiles are 32 consecutive pixels of the
+// FLATTENED (image, y, x) index (H*W % 4 == 0: a quad of a lane's outputs never straddles two images) -- 12 x 12 and 24 x 24 planes
+// waste no lanes, which row tiles would (37 % / 75 % occupancy).  One tile per wave, NW waves and NT x 32 output channels per
+// workgroup (launched with NW = 8, NT = 4).
+// The order of accumulation is K-step by K-step, as above: the result does not depend on NW.
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void conv1x1_split_kc_kernel(
+    const float* __restrict__ x, int x_ctot, int x_coff, int Cin,
+    const u32x4* __restrict__ wsp, int col_tiles, const float* __restrict__ bias,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_relu,
+    float* __restrict__ y, int y_ctot, int y_coff, int Cout,
+    double* __restrict__ stats, int accumulate, int HW, int P_total, int tiles_total, int slices, int ngroups) {
+    constexpr int DEPTH = 4, KC = 4, CHUNK = KC * 3 * NT * 64;   // u32x4 per chunk
+    constexpr int FQ = (CHUNK + NW * 64 - 1) / (NW * 64);
+    extern __shared__ __attribute__((aligned(16))) unsigned char p1_smem[];
+    const int ksteps_real = (Cin + 15) / 16, ksteps = (ksteps_real + KC - 1) / KC * KC;
+    u32x4* s_w = reinterpret_cast<u32x4*>(p1_smem);                                        // [2][KC][split][NT][64 lanes]
+    float* s_aff = reinterpret_cast<float*>(p1_smem + (size_t)2 * CHUNK * 16);               // [2][ksteps * 16]
+    double* s_red = reinterpret_cast<double*>(p1_smem);                                     // [NW][NT * 32][2], over the filter buffers after the loop
+
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int slice = jx % slices, grp = (jx / slices) * 8 + xcd;
+    if (grp >= ngroups) return;   // block-uniform
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int li = lane & 31, g = lane >> 5;
+    const unsigned hw32 = (unsigned)HW;
+
+    for (int i = threadIdx.x; i < ksteps * 16; i += NW * 64) {
+        s_aff[i] = (in_scale && i < Cin) ? in_scale[i] : (i < Cin ? 1.f : 0.f);
+        s_aff[ksteps * 16 + i] = (in_shift && i < Cin) ? in_shift[i] : 0.f;
+    }
+    // filter chunk `c` (K-steps 4c .. 4c + 3) of this block's NT column tiles: global -> registers, registers -> LDS buffer
+    u32x4 wreg[FQ];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int i = q * (NW * 64) + threadIdx.x;
+            const int ln = i & 63, t = (i >> 6) % NT, sp = (i / (64 * NT)) % 3, ksl = i / (64 * NT * 3);
+            const int gt = slice * NT + t, ks = c * KC + ksl;
+            const bool live = i < CHUNK && gt < col_tiles && ks < ksteps_real;
+            const size_t src = live ? (((size_t)gt * ksteps_real + ks) * 3 + sp) * 64 + ln : 0;
+            u32x4 v = wsp[src];                                   // (unconditional load, masked: see load_raw)
+            const unsigned keep = live ? 0xffffffffu : 0u;
+            v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+            wreg[q] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int i = q * (NW * 64) + threadIdx.x;
+            if (i < CHUNK) s_w[buf * CHUNK + i] = wreg[q];
+        }
+    };
+    fetch(0);
+    commit(0);
+
+    // this lane's pixel
+    const int tile = grp * NW + wid;
+    const int P = tile * 32 + li;
+    const bool ok = tile < tiles_total && P < P_total;
+    const int pn = ok ? P / HW : 0, pp = ok ? P - pn * HW : 0;
+    const unsigned px = (unsigned)(((size_t)pn * x_ctot + x_coff) * HW + (size_t)pp);
+    auto load_raw = [&](float (&dst)[8], int ks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = ks * 16 + g * 8 + e;
+            const unsigned cc = (unsigned)(ci < Cin ? ci : Cin - 1);
+            const unsigned keep = (ok && ci < Cin) ? 0xffffffffu : 0u;
+            dst[e] = __uint_as_float(__float_as_uint(x[px + cc * hw32]) & keep);
+        }
+    };
+    float r[DEPTH][8];
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j) load_raw(r[j], j);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    __syncthreads();
+
+    int buf = 0;
+#pragma unroll 1
+    for (int ks = 0; ks < ksteps; ks += KC) {
+        const bool more = ks + KC < ksteps;
+        if (more) fetch(ks / KC + 1);
+        const u32x4* sw = s_w + buf * CHUNK;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const int sn = ks + j + DEPTH - 1;
+            load_raw(r[(j + DEPTH - 1) % DEPTH], sn < ksteps ? sn : ksteps - 1);   // (past the end: a harmless reload, never used)
+            {
+                const float (&raw)[8] = r[j];
+                const int kk = ks + j;
+                float v[8];
+                if (in_scale) {
+                    const float4 sc0 = *reinterpret_cast<const float4*>(s_aff + kk * 16 + g * 8), sc1 = *reinterpret_cast<const float4*>(s_aff + kk * 16 + g * 8 + 4);
+                    const float4 sh0 = *reinterpret_cast<const float4*>(s_aff + ksteps * 16 + kk * 16 + g * 8), sh1 = *reinterpret_cast<const float4*>(s_aff + ksteps * 16 + kk * 16 + g * 8 + 4);
+                    const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w}, sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ok ? __fmaf_rn(raw[e], sc[e], sh[e]) : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = raw[e];
+                }
+                if (in_relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                u32x4 hh, mm, ll;
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    unsigned h, mi, l;
+                    p1_split_pair(v[2 * c2], v[2 * c2 + 1], h, mi, l);
+                    hh[c2] = h; mm[c2] = mi; ll[c2] = l;
+                }
+                const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, hh), __builtin_bit_cast(bf16x8, mm), __builtin_bit_cast(bf16x8, ll)};
+                bf16x8 b[NT][3];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) b[t][sp] = __builtin_bit_cast(bf16x8, sw[((j * 3 + sp) * NT + t) * 64 + lane]);
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, smallest first (as above)
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[p]], b[t][PB[p]], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();   // the next chunk is in LDS, and nobody reads `buf` any more
+        buf ^= 1;
+    }
+
+    // ---- epilogue: bias, store, statistics partials (the layout of the kernel above; the pixel quad of (q, g) is 4 consecutive
+    // flattened pixels of one image)
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
+    const int co_base = slice * NT * 32;
+    if (tile < tiles_total) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co = co_base + t * 32 + li;
+            if (co >= Cout) continue;
+            const float bv = bias != nullptr ? bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int P0 = tile * 32 + 8 * q + 4 * g;
+                if (P0 >= P_total) continue;
+                const int n = P0 / HW, p0 = P0 - n * HW;
+                float* dst = y + ((size_t)n * y_ctot + y_coff + co) * HW + p0;
+                float e4[4] = {acc[t][4 * q] + bv, acc[t][4 * q + 1] + bv, acc[t][4 * q + 2] + bv, acc[t][4 * q + 3] + bv};
+                if (accumulate) {
+                    const float4 o4 = *reinterpret_cast<const float4*>(dst);
+                    e4[0] += o4.x; e4[1] += o4.y; e4[2] += o4.z; e4[3] += o4.w;
+                }
+                *reinterpret_cast<float4*>(dst) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                if (stats != nullptr) {
+                    const double a0 = e4[0], a1 = e4[1], a2 = e4[2], a3 = e4[3];
+                    s1[t] += (a0 + a1) + (a2 + a3);
+                    s2[t] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {   // block-uniform
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double a = s1[t], b = s2[t];
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            if (lane < 32) { s_red[((wid * NT + t) * 32 + lane) * 2] = a; s_red[((wid * NT + t) * 32 + lane) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        if (threadIdx.x < NT * 32) {
+            const int co = co_base + threadIdx.x;
+            if (co < Cout) {
+                double a = 0.0, b = 0.0;
+                for (int w2 = 0; w2 < NW; ++w2) { a += s_red[((w2 * NT) * 32 + threadIdx.x) * 2]; b += s_red[((w2 * NT) * 32 + threadIdx.x) * 2 + 1]; }
+                const int slot = grp & (CD_BN_STAT_SLOTS - 1);
+                double* st = stats + ((size_t)slot * y_ctot + y_coff + co) * 2;
+                atomicAdd(st, a);
+                atomicAdd(st + 1, b);
+            }
+        }
+    }
+}
+
+template <int NT, int NW>
+static int launch_1x1_kc_t(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
+                           const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
+                           int H, int W, hipStream_t s) {
+    const int ksteps = ((Cin + 15) / 16 + 3) / 4 * 4;
+    const size_t lds = (size_t)2 * 4 * 3 * NT * 1024 + (size_t)2 * ksteps * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv1x1_split_kc_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int col_tiles = (Cout + 31) / 32, slices = (col_tiles + NT - 1) / NT;
+    const int P_total = N * H * W, tiles_total = (P_total + 31) / 32, ngroups = (tiles_total + NW - 1) / NW;
+    hipLaunchKernelGGL((conv1x1_split_kc_kernel<NT, NW>), dim3((unsigned)((ngroups + 7) / 8) * 8u * (unsigned)slices), dim3(NW * 64), lds, s, x, x_ctot,
+                       x_coff, Cin, reinterpret_cast<const u32x4*>(wsplit), col_tiles, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout,
+                       stats, accumulate, H * W, P_total, tiles_total, slices, ngroups);
+    return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
+}
+
+// wide filters / small planes: see conv1x1_split_kc_kernel.  H*W % 4 == 0 and N*H*W < 2^26 (the caller checks the element count)
+bool conv1x1_split_kc_ok(int Cin, int Cout, int N, int H, int W) {
+    return Cin >= 64 && Cout >= 64 && ((H * W) & 3) == 0 && (long long)N * H * W < (1LL << 26) && (size_t)((Cin + 63) / 64 * 64) * 2 * 4 <= 48 * 1024;
+}
+int launch_conv1x1_split_kc(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
+                            const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate,
+                            int N, int H, int W, hipStream_t s) {
+    if (!conv1x1_split_kc_ok(Cin, Cout, N, H, W)) return CD_ERR_UNSUPPORTED;
+    // One shape: 8 waves x 128 output channels (216 registers: two waves per SIMD).  A 12-wave workgroup would balance the 24 x 24 planes
+    // of MiDaS' layer3 better (288 pixel tiles x 8 slices = 288 workgroups of 8 waves take two rounds on 256 CUs, 192 of 12 waves one
+    // round of 1.5x the length) but needs 168 registers per wave and spills 156 bytes -- measured first, not shipped.
+    return launch_1x1_kc_t<4, 8>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s);
+}
+
 int launch_conv1x1_split(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                          const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
                          int H, int W, hipStream_t s) {

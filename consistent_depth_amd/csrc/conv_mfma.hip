@@ -494,6 +494,8 @@ static int initial_conv_arith() {
     return 2;
 }
 static int g_conv_arith = initial_conv_arith();
+// CD_AMD_CONV1X1_KC=0: wide 1x1 filters (>= 512 channels) back on the staged fp32 kernel (A/B of conv1x1_split_kc_kernel, round 6)
+static const bool g_conv1x1_kc = [] { const char* e = getenv("CD_AMD_CONV1X1_KC"); return !(e && e[0] == '0'); }();
 }
 
 extern "C" {
@@ -577,10 +579,16 @@ int cd_conv2d_fwd_cfg(const float* x, int x_ctot, int x_coff, int Cin, const flo
     if (!(tile_rows == 0 || tile_rows == 4 || tile_rows == 8 || tile_rows == 16 || tile_rows == 32)) return CD_ERR_INVALID_ARG;
     if (!(co_tiles == 0 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4 || co_tiles == 8 || co_tiles == 16)) return CD_ERR_INVALID_ARG;
     // (small images -- fewer 32-pixel tiles than the chip has waves -- stay on the staged fp32 kernel: measured equal or faster there)
-    if (cd::g_conv_arith == 2 && cd::split_1x1_supported(ks, Cout, Cin) && (size_t)N * x_ctot * H * W < ((size_t)1 << 30) &&
+    if (cd::g_conv_arith == 2 && cd::split_1x1_supported(ks, Cout, Cin) && cd::split_1x1_resident(Cin) && (size_t)N * x_ctot * H * W < ((size_t)1 << 30) &&
         (long long)N * H * ((W + 31) / 32) >= 4096)   // one launch shape: the hints are not used
         return cd::launch_conv1x1_split(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift, in_relu,
                                         y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s);
+    // wide filters (>= 512 channels on either side: the ResNeXt-101 encoder of MiDaS; the hourglass has none, its small-image 1x1
+    // convolutions keep the staged fp32 kernel and their bits): the chunked split-bf16 kernel, any image size
+    if (cd::g_conv_arith == 2 && cd::split_1x1_supported(ks, Cout, Cin) && (Cin >= 512 || Cout >= 512) && cd::g_conv1x1_kc &&
+        (size_t)N * x_ctot * H * W < ((size_t)1 << 30) && (size_t)N * y_ctot * H * W < ((size_t)1 << 30) && cd::conv1x1_split_kc_ok(Cin, Cout, N, H, W))
+        return cd::launch_conv1x1_split_kc(x, x_ctot, x_coff, Cin, packed_w + cd::fp32_packed_floats(Cout, Cin, ks), bias, in_scale, in_shift, in_relu,
+                                           y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s);
     if (cd::g_conv_arith >= 1 && cd::split_supported(ks) && Cin >= 8) {   // (the 3-channel stem would pad K 8/3-fold: fp32 kernel)
         // launch-shape hints: tile_rows <= 4 -> 4 M-tiles per block, else 8; co_tiles >= 2 -> two 32-column tiles per block (then 4
         // M-tiles).  Unhinted: 4 M-tiles, two column tiles when the filter has them and the image is large (conv_split_bench)

@@ -36,11 +36,17 @@ __host__ __device__ inline size_t fp32_packed_floats(int OC, int IC, int ks) {
 
 // 1x1 filters (conv1x1_split.hip; forward / input gradient only): more than 16 output and at least 32 input channels, and the
 // block's filter slice (64 output channels x all input channels x 6 bytes) must fit the LDS
-__host__ __device__ constexpr bool split_1x1_supported(int ks, int OC, int IC) { return ks == 1 && OC > 16 && IC >= 32 && IC <= 384; }
+// (IC <= 384: the filter slice stays in LDS, conv1x1_split_kernel; up to 2048 since round 6: the chunked kernel conv1x1_split_kc_kernel)
+__host__ __device__ constexpr bool split_1x1_supported(int ks, int OC, int IC) { return ks == 1 && OC > 16 && IC >= 32 && IC <= 2048; }
+__host__ __device__ constexpr bool split_1x1_resident(int IC) { return IC <= 384; }
 size_t split_1x1_packed_floats(int OC, int IC);
 int launch_pack_1x1_table(const void* table_dev, int n, hipStream_t s);
 int launch_pack_1x1(const float* w, int Cout, int Cin, int transposed, float* packed_split, hipStream_t s);
 int launch_conv1x1_split(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
+                         const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
+                         int H, int W, hipStream_t s);
+bool conv1x1_split_kc_ok(int Cin, int Cout, int N, int H, int W);
+int launch_conv1x1_split_kc(const float* x, int x_ctot, int x_coff, int Cin, const float* wsplit, const float* bias, const float* in_scale,
                          const float* in_shift, int in_relu, float* y, int y_ctot, int y_coff, int Cout, double* stats, int accumulate, int N,
                          int H, int W, hipStream_t s);
 

@@ -1,5 +1,6 @@
 // Interface between conv_wgrad.hip (layout, dispatch, unpack) and wgrad_split.hip (the split-bf16 weight gradient).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "wgrad_stage_map.h"   // wgrad_split_tile_rows, WsCfg, the staging map (host-testable)
 
@@ -35,10 +36,18 @@ int launch_wgrad_split_table(const void* table_dev, int n, int klass, int total_
 constexpr int WGRAD1X1_COB = 64, WGRAD1X1_CIB = 128;
 // usable with >= 96 output channels, when H * W is a multiple of 16 (whole 16-pixel steps inside an image), the tensors have < 2^30 elements per image set and
 // the image is large enough to give every wave several steps
+// CD_AMD_CONV1X1_KC=0: wide 1x1 filters (>= 512 channels) back on the staged fp32 kernels (A/B switch of round 6, read once)
+inline bool wide_1x1_enabled() {
+    static const bool on = [] { const char* e = getenv("CD_AMD_CONV1X1_KC"); return !(e && e[0] == '0'); }();
+    return on;
+}
 inline bool wgrad1x1_split_ok(int Cout, int Cin, int N, int H, int W, int x_ctot, int dy_ctot) {
     const long long hw = (long long)H * W;
+    // few pixels: the staged fp32 kernel, EXCEPT the wide filters of MiDaS' encoder (round 6: 1024 x 1024 on 24 x 24 x 16 pixels is 128
+    // patches x 16 pixel splits = 512 workgroups of 36 K-steps; the hourglass has no such filter and keeps its bits)
+    const bool enough_pixels = (long long)N * hw >= 20000 || (wide_1x1_enabled() && Cout >= 512 && Cin >= 512 && (long long)N * hw >= 2048);
     return Cout >= 96 && Cin >= 32 &&   // (fewer output channels: a single half-empty 64 x 128 patch -- the staged kernel is faster)
-           hw % 16 == 0 && (long long)N * hw >= 20000 && hw * (x_ctot > dy_ctot ? x_ctot : dy_ctot) < (1LL << 30);
+           hw % 16 == 0 && enough_pixels && hw * (x_ctot > dy_ctot ? x_ctot : dy_ctot) < (1LL << 30);
 }
 void wgrad1x1_split_shape(int Cout, int Cin, int* cogs, int* cigs, int* pg, int* sub, int* groups);
 int wgrad1x1_split_blocks(int Cout, int Cin, long long steps);   // grid.x; slices of the packed result = blocks * sub

@@ -127,6 +127,58 @@ def test_pointwise_convolution_at_dispatch_size(N, Cin, Cout, H, W, arith):
     assert torch.equal(out3, out2)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1024, 1024, 24, 24), (3, 512, 512, 48, 48), (1, 2048, 2048, 12, 12), (2, 1024, 2048, 12, 12), (2, 256, 512, 48, 48),
+                                            (1, 2048, 512, 6, 10), (2, 520, 136, 10, 10), (1, 72, 600, 14, 18), (2, 512, 256, 96, 96)])
+def test_pointwise_convolution_with_wide_filters(N, Cin, Cout, H, W, arith):
+    """Dense 1x1 filters with >= 512 channels on one side (the ResNeXt-101 encoder of MiDaS v2, BASELINE configs[4]): under "split" this is
+    conv1x1_split.hip::conv1x1_split_kc_kernel (round 6: the filter slice streamed through LDS in double-buffered 64-channel chunks,
+    pixel tiles over the flattened (image, y, x) index) -- the shapes of layer2 / 3 / 4 at 384x384, planes that are not a multiple of 32
+    pixels, tiles that straddle two images, odd channel counts, channel slices of wider buffers, the fused input transform, the
+    statistics epilogue and gradient accumulation; under the other modes the same call is the staged fp32 kernel (same bounds)."""
+    import torch
+    from consistent_depth_amd.ops import conv, layers
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, Cin + 5, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), torch.randn(Cin, generator=g).cuda()
+    base = torch.randn(N, Cout + 3, H, W, generator=g).cuda()
+    pk = conv.pack_weights(w)
+    act = torch.relu(x[:, 2:2 + Cin].double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    ref = torch.einsum("nchw,oc->nohw", act, w.double().view(Cout, Cin)) + b.double().view(1, -1, 1, 1)
+    out = base.clone()
+    conv.conv2d(x, pk, Cin, Cout, 1, bias=b, x_coff=2, out=out, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True, accumulate=True)
+    got = (out[:, 1:1 + Cout] - base[:, 1:1 + Cout]).double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert torch.equal(out[:, :1], base[:, :1]) and torch.equal(out[:, 1 + Cout:], base[:, 1 + Cout:])
+    out2 = torch.full_like(base, 7.0)
+    stats = layers.new_stats(Cout + 3, "cuda")
+    conv.conv2d(x, pk, Cin, Cout, 1, bias=b, x_coff=2, out=out2, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True, stats=stats)
+    err2 = (out2[:, 1:1 + Cout].double() - ref).abs().max().item() / ref.abs().max().item()
+    st = stats.sum(0)
+    # plain input (no transform, no bias): the encoder's own call
+    xin = x[:, 2:2 + Cin].contiguous()
+    out4 = conv.conv2d(xin, pk, Cin, Cout, 1)
+    ref4 = torch.einsum("nchw,oc->nohw", xin.double(), w.double().view(Cout, Cin))
+    err4 = (out4.double() - ref4).abs().max().item() / ref4.abs().max().item()
+    # the input gradient: the same kernel on the transposed packing
+    pkT = conv.pack_weights(w, transposed=True)
+    dy = torch.randn(N, Cout, H, W, generator=g).cuda()
+    dx = conv.conv2d(dy, pkT, Cout, Cin, 1)
+    refd = torch.einsum("nohw,oc->nchw", dy.double(), w.double().view(Cout, Cin))
+    errd = (dx.double() - refd).abs().max().item() / refd.abs().max().item()
+    report("conv_pointwise_wide", arith=arith, shape=f"{N}x{Cin}->{Cout}x{H}x{W}", accumulate_err=f"{err:.2e}", plain_err=f"{err2:.2e}", raw_err=f"{err4:.2e}",
+           dgrad_err=f"{errd:.2e}")
+    assert err < 3e-6 and err2 < 2e-6 and err4 < 2e-6 and errd < 2e-6
+    assert (out2[:, :1] == 7).all() and (out2[:, 1 + Cout:] == 7).all()
+    torch.testing.assert_close(st[1:1 + Cout, 0], ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(st[1:1 + Cout, 1], (ref ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-2)
+    assert (st[:1] == 0).all() and (st[1 + Cout:] == 0).all()
+    out3 = torch.full_like(base, 7.0)          # bit-reproducible
+    conv.conv2d(x, pk, Cin, Cout, 1, bias=b, x_coff=2, out=out3, y_coff=1, in_scale=sc, in_shift=sh, in_relu=True)
+    assert torch.equal(out3, out2)
+
+
 def test_conv_channel_slices_fused_input_and_stats():
     """Reads a channel slice, applies the producer's BN-apply+ReLU on load, writes into a slice of a
     concat buffer and accumulates the batch statistics of the raw output."""

@@ -39,6 +39,30 @@ def test_wgrad_matches_autograd(N, Cin, Cout, H, W, ks, arith):
     assert (dw.cpu().double() - 2 * ref).abs().max().item() < 6e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(4, 1024, 1024, 24, 24), (16, 2048, 512, 12, 12), (5, 520, 1000, 20, 24), (2, 512, 2048, 48, 24)])
+def test_1x1_wgrad_of_wide_filters_on_small_planes(N, Cin, Cout, H, W, arith):
+    """The 1x1 weight gradient of >= 512 x 512 filters on a few thousand pixels (layer3 / layer4 of MiDaS' ResNeXt-101 encoder at
+    384x384): under "split" wgrad1x1_split.hip since round 6 (csrc/wgrad_split.h::wgrad1x1_split_ok; the staged fp32 kernel before),
+    under "fp32" the staged kernel -- against fp64, channel slices and the fused input transform included, two launches bit for bit."""
+    import torch
+    from consistent_depth_amd.ops import conv
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin + 3, H, W, generator=g)
+    dy = torch.randn(N, Cout + 5, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    act = torch.relu(x[:, 2:2 + Cin].double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    ref = torch.einsum("nohw,nihw->oi", dy[:, 1:1 + Cout].double(), act).reshape(Cout, Cin, 1, 1)
+    ws = conv.wgrad_workspace(Cout, Cin, 1, "cuda")
+    got = []
+    for _ in range(2):
+        dw = torch.empty(Cout, Cin, 1, 1, device="cuda")
+        conv.conv2d_wgrad(x.cuda(), dy.cuda(), Cin, Cout, 1, dw, ws, x_coff=2, dy_coff=1, in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True)
+        got.append(dw)
+    assert torch.equal(got[0], got[1])
+    scale = ref.abs().max().item()
+    assert (got[0].cpu().double() - ref).abs().max().item() < 3e-5 * scale
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [
     (2, 128, 208, 130, 128),   # 14 x 8 channel tiles (13 live), odd number of 2-row tiles
     (2, 256, 160, 128, 100),   # 10 x 16, W % 4 == 0 but not a multiple of the 32-pixel tile
