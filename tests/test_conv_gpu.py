@@ -128,7 +128,8 @@ def test_pointwise_convolution_at_dispatch_size(N, Cin, Cout, H, W, arith):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1024, 1024, 24, 24), (3, 512, 512, 48, 48), (1, 2048, 2048, 12, 12), (2, 1024, 2048, 12, 12), (2, 256, 512, 48, 48),
-                                            (1, 2048, 512, 6, 10), (2, 520, 136, 10, 10), (1, 72, 600, 14, 18), (2, 512, 256, 96, 96)])
+                                            (1, 2048, 512, 6, 10), (2, 520, 136, 10, 10), (1, 72, 600, 14, 18), (2, 512, 256, 96, 96),
+                                            (16, 1024, 1024, 24, 24), (16, 520, 1000, 24, 24)])   # (the last two: 36 pixel groups x 8 slices, two rounds on the chip)
 def test_pointwise_convolution_with_wide_filters(N, Cin, Cout, H, W, arith):
     """Dense 1x1 filters with >= 512 channels on one side (the ResNeXt-101 encoder of MiDaS v2, BASELINE configs[4]): under "split" this is
     conv1x1_split.hip::conv1x1_split_kc_kernel (round 6: the filter slice streamed through LDS in double-buffered 64-channel chunks,
