@@ -203,16 +203,12 @@ LOSS_WARM_CALLS = 100
 
 
 def midas_path_note():
-    """What the configs[4] line ran on (the two A/B switches of the midas2 plugin)."""
-    gemm = os.environ.get("CD_AMD_MIDAS_1X1", "hip") == "gemm"
-    aten = os.environ.get("CD_AMD_MIDAS_BLOCKS", "hip") == "aten"
-    return ("k >= 3 convolutions incl. the grouped 32x8d 3x3 (1/3 of the multiply-adds): hand-written split-bf16 HIP kernels, forward / input "
-            "gradient / weight gradient; dense 1x1 convolutions (2/3 of the multiply-adds): "
-            + ("fp32 GEMMs of the library (rocBLAS / hipBLASLt through torch.matmul / bmm; CD_AMD_MIDAS_1X1=gemm)" if gemm else
-               "hand-written too (the staged fp32-MFMA 1x1 kernels at 12x12 .. 48x48, the split-bf16 1x1 kernels at 96x96; no library GEMM)")
-            + "; BatchNorm (+ identity) (+ ReLU), ReLU, adds, max-pool: "
-            + ("ATen / MIOpen (CD_AMD_MIDAS_BLOCKS=aten)" if aten else "hand-written blocks (csrc/bn_block.hip)")
-            + "; bilinear x2: hand-written gather kernels; stride 2 (k >= 3) = stride 1 + sub-sampling; loss + Adam: hand-written HIP)")
+    """What the configs[4] line ran on."""
+    return ("every convolution on hand-written HIP kernels, forward / input gradient / weight gradient: k >= 3 incl. the grouped 32x8d 3x3 (1/3 of "
+            "the multiply-adds) and the dense 1x1 (2/3 of the multiply-adds; >= 512 channels: the chunked kernel conv1x1_split_kc_kernel and "
+            "wgrad1x1_split, 96x96 planes: the LDS-resident 1x1 kernel) in split-bf16 arithmetic, the RGB stem and the 1-channel head on the fp32 "
+            "matrix instruction; no library GEMM; BatchNorm (+ identity) (+ ReLU), ReLU, adds, max-pool: hand-written blocks (csrc/bn_block.hip); "
+            "bilinear x2: hand-written kernels; stride 2 (k >= 3) = stride 1 + sub-sampling; loss + Adam: hand-written HIP)")
 
 
 def loss_microbench(lib, B, H, W, iters, device, warm=LOSS_WARM_CALLS):
@@ -481,18 +477,16 @@ def main():
         px = H * W
         flops_per_pair = 2 * 3 * 2 * macs_per_image            # 2 images x (forward + input gradient + weight gradient) x 2 flop/MAC
         ach_tf = flops_per_pair * pairs_per_s / world / 1e12  # per GPU
-        split = args.backend == "hip" and args.model == "mc" and lib.cd_get_conv_arith() >= 1
+        # (midas2 since round 6: its dense 1x1 convolutions run on the split-operand kernels too -- every convolution but the RGB stem and the
+        # 1-channel head is priced against the split roof)
+        split = args.backend == "hip" and args.model in ("mc", "midas2") and lib.cd_get_conv_arith() >= 2
         peak_tf = MFMA_BF16_PEAK_TFLOPS / 6 if split else MFMA_FP32_PEAK_TFLOPS
         out["roofline_conv"] = {
             "bound": "mfma", "achieved": round(ach_tf, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4),
             "flops_per_pair": flops_per_pair, "per": "GPU, whole step time (BatchNorm, loss, Adam and launch gaps included: a lower bound "
                                                      "of what the convolution kernels reach while they run)",
             "peak_note": ("fp32-equivalent roof of the split-operand kernels = dense BF16 peak 2500 / 6 products" if split else
-                          ("a MIXTURE for midas2, priced against the LOWER of its two roofs (which flatters the fraction): 2/3 of the flops are "
-                           "dense 1x1 convolutions on the fp32 matrix instruction (hand-written staged kernel, or the library's fp32 GEMMs under "
-                           "CD_AMD_MIDAS_1X1=gemm: roof 157.3), 1/3 run on the split-operand kernels (roof 416.7); against the flop-weighted roof "
-                           "1 / (2/3 / 157.3 + 1/3 / 416.7) = 198.4 TFLOP/s the fraction is frac x 0.793"
-                           if args.model == "midas2" and args.backend == "hip" else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)")),
+                          "fp32 matrix instruction (v_mfma_f32_16x16x4_f32)"),
             "frac_of_fp32_mfma_peak": round(ach_tf / MFMA_FP32_PEAK_TFLOPS, 4),
             "mfma_busy_source": "profiles/rocprofv3_bench_pmc_r06.txt (SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES per kernel family), "
                                 "profiles/conv_roofline_r06.txt (per launch)"}

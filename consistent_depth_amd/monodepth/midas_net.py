@@ -13,17 +13,18 @@ key.  "Parity unpinned" (no source, no weights, no golden vectors in /root/refer
 
 Convolutions: `backend="hip"` (default) builds the network from ops.conv_layer.HipConv2d -- EVERY convolution (the dense 1x1
 bottleneck entries / exits, the grouped 32 x 8d 3x3, strided stem / down-samples, decoder) forward, input gradient and weight
-gradient on the hand-written gfx950 MFMA kernels (end of round 5: the dense 1x1 too; `CD_AMD_MIDAS_1X1=gemm` sends them to the GEMM
-library as before, for A/B) -- and the five bilinear x2 up-samplings on ops.layers.bilinear_up2 (gather kernels, no atomics in the
-backward), every BatchNorm (+ identity) (+ ReLU) as ONE hand-written block (ops.blocks.bn_act: batch statistics, apply, and the
-backward's reduce / apply -- csrc/bn_block.hip), the decoder's ReLUs and adds and the stem's max-pool on the same file's kernels
-(`CD_AMD_MIDAS_BLOCKS=aten` keeps the ATen / MIOpen ops, for A/B); `backend="torch"` keeps nn.Conv2d (PyTorch-ROCm / MIOpen),
-F.interpolate and the ATen modules.  What is left to the framework in the hip back end: autograd's own gradient accumulation where a
-tensor has two consumers, the bias gradients' sums, tensor allocation.  Loss, optimiser and data parallelism are the HIP/RCCL path.
+gradient on the hand-written gfx950 MFMA kernels (no library GEMM: the torch.matmul route of rounds 3-5 and its switch are gone since
+round 6, the wide 1x1 filters run on csrc/conv1x1_split.hip::conv1x1_split_kc_kernel) -- and the five bilinear x2 up-samplings on
+ops.layers.bilinear_up2 (gather kernels, no atomics in the backward), every BatchNorm (+ identity) (+ ReLU) as ONE hand-written block
+(ops.blocks.bn_act: batch statistics, apply, and the backward's reduce / apply -- csrc/bn_block.hip), the decoder's ReLUs and adds and
+the stem's max-pool on the same file's kernels.  `backend="torch"` is the TWIN the tests compare with (tests/test_midas_gpu.py) and the
+shape of BASELINE configs[1] ("convs still PyTorch-ROCm"): nn.Conv2d (PyTorch-ROCm / MIOpen), F.interpolate and the ATen modules.  What is
+left to the framework in the hip back end: autograd's own gradient accumulation where a tensor has two consumers, the bias gradients' sums,
+tensor allocation, and eval-mode BatchNorm (running statistics: inference before / after the fine-tuning, not the step).  Loss, optimiser
+and data parallelism are the HIP/RCCL path.
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.nn as nn
@@ -172,9 +173,8 @@ class MidasNet(nn.Module):
                     self._pack_pool.register(m)
                 if isinstance(m, (FeatureFusionBlock, _Interpolate)):
                     m.hip_up = True
-                if os.environ.get("CD_AMD_MIDAS_BLOCKS", "hip") != "aten" and isinstance(
-                        m, (Bottleneck, _Layer1, _Relu, ResidualConvUnit, FeatureFusionBlock)):
-                    m.hip_blocks = True      # BatchNorm / ReLU / adds / max-pool on ops.blocks (A/B: CD_AMD_MIDAS_BLOCKS=aten)
+                if isinstance(m, (Bottleneck, _Layer1, _Relu, ResidualConvUnit, FeatureFusionBlock)):
+                    m.hip_blocks = True      # BatchNorm / ReLU / adds / max-pool on ops.blocks
         if path:
             self.load_state_dict(torch.load(path, map_location="cpu"))
 

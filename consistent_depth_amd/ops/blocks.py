@@ -80,9 +80,11 @@ class _BnAct(torch.autograd.Function):
 
 
 def bn_act(x, bn, relu, res=None):
-    """act(bn(x) [+ res]) with act = ReLU (relu=True) or identity.  Training mode on the HIP device: the hand-written block; otherwise ATen."""
-    if bn.training and x.is_cuda and x.dtype == torch.float32:
+    """act(bn(x) [+ res]) with act = ReLU (relu=True) or identity.  Training mode: the hand-written block (HIP device only: a CPU tensor raises); eval mode: ATen on the device."""
+    _need_device(x, "bn_act")
+    if bn.training and x.dtype == torch.float32:
         return _BnAct.apply(x, bn.weight, bn.bias, res, bn, relu)
+    # eval mode (running statistics: inference before / after the fine-tuning, never the step) and non-fp32 tensors: the framework's ops
     y = bn(x)
     if res is not None:
         y = y + res
@@ -116,12 +118,20 @@ class _Eltwise(torch.autograd.Function):
         return dx, None, None
 
 
+def _need_device(x, what):
+    """The blocks of the hip back end have no CPU path (the twin for CPU work is MidasNet(backend="torch"))."""
+    if not x.is_cuda:
+        raise RuntimeError(f"ops.blocks.{what}: the hand-written block needs a tensor on the HIP device, got {x.device}")
+
+
 def relu(x):
-    return _Eltwise.apply(x, None, 0) if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) else F.relu(x)
+    _need_device(x, "relu")
+    return _Eltwise.apply(x, None, 0) if (x.dtype == torch.float32 and x.dim() == 4) else F.relu(x)
 
 
 def add(a, b):
-    ok = a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.shape == b.shape
+    _need_device(a, "add")
+    ok = a.dtype == torch.float32 and a.dim() == 4 and a.shape == b.shape
     return _Eltwise.apply(a, b, 1) if ok else a + b
 
 
@@ -151,4 +161,5 @@ class _MaxPool3s2(torch.autograd.Function):
 
 
 def maxpool3s2(x):
-    return _MaxPool3s2.apply(x) if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) else F.max_pool2d(x, 3, 2, 1)
+    _need_device(x, "maxpool3s2")
+    return _MaxPool3s2.apply(x) if (x.dtype == torch.float32 and x.dim() == 4) else F.max_pool2d(x, 3, 2, 1)

@@ -12,13 +12,11 @@ Same parameters and state_dict keys as nn.Conv2d (a checkpoint loads unchanged).
   * stride 2: the stride-1 "same" output sampled at even positions (identical values; 4x the MACs of a strided kernel --
     only the stem, 3 bottlenecks and 3 down-sample 1x1 of ResNeXt-101 are strided).
   * 1x1, dense (the bottleneck entry / exit convolutions: 2/3 of ResNeXt-101's multiply-adds, at 12x12 .. 96x96 images with
-    256 .. 2048 channels): a plain GEMM  Y[n] = W [Cout x Cin] . X[n] [Cin x HW]  -- not a stencil.  Rounds 3-4 sent them to the GEMM
-    library (rocBLAS / hipBLASLt through torch.matmul / torch.bmm); measured at the end of round 5 the hand-written 1x1 kernels (the
-    staged fp32-MFMA kernel `conv_fwd_kernel<1, ...>` / `conv_wgrad_kernel<1, ...>` at these small images -- ~118 TFLOP/s = 75 % of the
-    fp32 matrix instruction's peak --, the split-bf16 1x1 kernels at 96x96) ran the configs[4] step 6 % slower than the library
-    (54.0 vs 57.6 pairs/s) and are the DEFAULT now: no library GEMM on the path (with the launch shape for >= 512 output channels and the
-    hand-written layer blocks the step is at 60.8 pairs/s).  `CD_AMD_MIDAS_1X1=gemm` restores the library route
-    (A/B; stride-2 1x1 sub-sample first there).
+    256 .. 2048 channels): a plain GEMM  Y[n] = W [Cout x Cin] . X[n] [Cin x HW]  -- not a stencil.  On the hand-written kernels like
+    everything else (no library GEMM on the path; rounds 3-5 carried a torch.matmul / bmm route behind CD_AMD_MIDAS_1X1=gemm, removed in
+    round 6): >= 512 channels on the chunked split-bf16 kernel csrc/conv1x1_split.hip::conv1x1_split_kc_kernel (~100 TFLOP/s
+    fp32-equivalent where the staged fp32-MFMA kernel reached 40-77) and wgrad1x1_split, 96x96 planes with <= 384 input channels on
+    the LDS-resident 1x1 kernel.
 Filters are re-packed once per forward (weights move under the optimiser): a `PackPool` shared by the layers of a network
 packs EVERY filter of the network, forward and transposed layouts, in ONE table launch (round 2: two launches of 16 workgroups
 per layer and pass -- 53 ms of a 211 ms MiDaS step); a layer outside a pool packs its own filters.
@@ -28,7 +26,6 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-import os
 
 from .. import _native
 from . import conv as C
@@ -145,11 +142,9 @@ class HipConv2d(torch.nn.Conv2d):
                 and self.dilation == (1, 1) and self.padding_mode == "zeros"):
             raise ValueError(f"HipConv2d: unsupported geometry kernel {k} stride {s} padding {p}")
         self._pk = self._pkT = self._table = self._tableT = self._wptr = self._ws = self._pool = None
-        # dense 1x1: a GEMM (see the module docstring)
-        self._gemm = k[0] == 1 and self.groups == 1 and os.environ.get("CD_AMD_MIDAS_1X1", "hip") == "gemm"
 
     def _uses_packed(self):
-        return not self._gemm
+        return True
 
     def _build(self, weight, transposed):
         """Packed buffers of every group (zeroed once: padding elements are never written) + the pack table."""
@@ -202,50 +197,4 @@ class HipConv2d(torch.nn.Conv2d):
         return self._ws
 
     def forward(self, x):
-        if self._gemm:
-            if not x.is_cuda:
-                raise RuntimeError("HipConv2d: no CPU path")
-            return _Gemm1x1Fn.apply(x, self.weight, self.bias, self.stride[0])
         return _HipConvFn.apply(x, self.weight, self.bias, self)
-
-
-class _Gemm1x1Fn(torch.autograd.Function):
-    """1x1 convolution as GEMMs on the library (rocBLAS / hipBLASLt): Y[n] = W X[n]; dX[n] = W^T dY[n]; dW = sum_n dY[n] X[n]^T."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, stride):
-        ctx.in_hw = tuple(x.shape[2:])
-        if stride > 1:
-            x = x[:, :, ::stride, ::stride]
-        x = x.contiguous()
-        N, Cin, H, W = x.shape
-        Cout = weight.shape[0]
-        y = torch.matmul(weight.view(Cout, Cin), x.view(N, Cin, H * W)).view(N, Cout, H, W)
-        if bias is not None:
-            y = y + bias.view(1, -1, 1, 1)
-        ctx.save_for_backward(x, weight)
-        ctx.stride, ctx.has_bias = stride, bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        N, Cin, H, W = x.shape
-        Cout = weight.shape[0]
-        dy = dy.contiguous()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.matmul(weight.view(Cout, Cin).t(), dy.view(N, Cout, H * W)).view(N, Cin, H, W)
-            if ctx.stride > 1:
-                s = ctx.stride
-                full = torch.zeros((N, Cin) + ctx.in_hw, dtype=dx.dtype, device=dx.device)   # adjoint of the sub-sampling
-                full[:, :, ::s, ::s] = dx
-                dx = full
-        if ctx.needs_input_grad[1]:
-            # per-image products dY[n] X[n]^T as ONE strided-batched GEMM on the tensors as they lie in memory, then a sum over
-            # the images (a [N, Cout, Cin] temporary: <= 134 MB for 2048 x 1024 at 16 images).  Concatenating the images along K
-            # instead needs both operands transposed in memory: those copies were 23 ms of a 155 ms step.
-            dw = torch.bmm(dy.view(N, Cout, H * W), x.view(N, Cin, H * W).transpose(1, 2)).sum(0).view_as(weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3))
-        return dx, dw, db, None
