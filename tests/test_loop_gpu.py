@@ -17,6 +17,7 @@ REFERENCE'S OWN LOOP.
 import glob
 import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -388,31 +389,47 @@ def test_config1_torch_convs_hip_loss_from_the_same_snapshot(tmp_path, monkeypat
     monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
     n_pairs = len(z["pair_order"])
     want_plans = json.loads(str(z["plans"]))
-    pair_id = {tuple(p): i for i, p in enumerate(z["pair_order"].tolist())}
     RUNS = int(os.environ.get("CD_AMD_TEST_CONFIG1_RUNS", "3"))
     all_rows, all_direct = [], []
-    for run in range(RUNS):
-        path = str(tmp_path / f"torch{run}" / "clip")
-        range_dir, _ = msd.write_dataset(path, **S["clip"])
-        params = Video3dParamsParser().parse(["--path", path, "--num_epochs", str(K + T), "--batch_size", "4", "--print_freq", "0"])
-        ft = DepthFineTuner(range_dir, list(range(S["clip"]["n_frames"])), params)
-        assert ft.model.backend == "torch" and ft.model._engine is None
-        if run == 0:
-            with pytest.raises(ValueError, match="exp_avg_sq must hold exactly"):       # (a moment dict that does not cover the parameters: a clear error)
-                ft.resume_from(snap["state"], snap["m1"], {k: v for i, (k, v) in enumerate(snap["m2"].items()) if i}, snap["k"], epoch=K,
-                               total_iters=K * n_pairs)
-        ft.resume_from(snap["state"], snap["m1"], snap["m2"], snap["k"], epoch=K, total_iters=K * n_pairs)
-        ft.epoch_plan = lambda e: [[pair_id[tuple(p)] for p in batch] for batch in want_plans[str(e)]]
-        ft.fine_tune()
-        assert [list(map(int, pr)) for pr in ft.store.pair_indices()] == z["pair_order"].tolist()
-        got = G.collect(ft.out_dir, n_pairs, K, T)
+    # a moment dict that does not cover the parameters is a clear error (checked here, on a tuner that never trains)
+    path0 = str(tmp_path / "torch_check" / "clip")
+    range_dir, _ = msd.write_dataset(path0, **S["clip"])
+    params = Video3dParamsParser().parse(["--path", path0, "--num_epochs", str(K + T), "--batch_size", "4", "--print_freq", "0"])
+    ft = DepthFineTuner(range_dir, list(range(S["clip"]["n_frames"])), params)
+    assert ft.model.backend == "torch" and ft.model._engine is None
+    with pytest.raises(ValueError, match="exp_avg_sq must hold exactly"):
+        ft.resume_from(snap["state"], snap["m1"], {k: v for i, (k, v) in enumerate(snap["m2"].items()) if i}, snap["k"], epoch=K,
+                       total_iters=K * n_pairs)
+    del ft
+    torch.cuda.empty_cache()
+    # The continuations run in a CHILD process (tests/config1_worker.py says why: one SIGABRT inside torch.cuda.synchronize() in ~10
+    # full-suite runs, third-party half of the configuration, not reproducible): a child killed by a signal is reported and repeated once.
+    cpu = lambda d: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in d.items()}  # noqa: E731
+    snap_cpu = {"state": cpu(snap["state"]), "m1": cpu(snap["m1"]), "m2": cpu(snap["m2"]), "k": snap["k"]}
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config1_worker.py")
+    killed, out_dirs = 0, []
+    for attempt in range(2):
+        todo = RUNS - len(out_dirs)
+        if todo == 0:
+            break
+        job = str(tmp_path / f"job{attempt}.pt")
+        torch.save({"snap": snap_cpu, "clip": S["clip"], "paths": [str(tmp_path / f"torch{attempt}_{i}" / "clip") for i in range(todo)], "K": K, "T": T,
+                    "n_pairs": n_pairs, "plans": want_plans, "pair_order": z["pair_order"].tolist()}, job)
+        proc = subprocess.run([sys.executable, worker, job], capture_output=True, text=True, timeout=2000, env=dict(os.environ, CD_AMD_MC_BACKEND="torch"))
+        out_dirs += [ln[len("OUT_DIR="):] for ln in proc.stdout.splitlines() if ln.startswith("OUT_DIR=")]
+        if proc.returncode < 0 and attempt == 0:       # killed by a signal (the abort described above): the unfinished runs once more
+            killed += 1
+            print(f"configs[1]: child ended with signal {-proc.returncode} after {len(out_dirs)} runs; stderr tail: {proc.stderr[-600:]}")
+            continue
+        assert proc.returncode == 0, f"configs[1] child failed (rc {proc.returncode}):\n{proc.stdout[-1500:]}\n{proc.stderr[-3000:]}"
+    assert len(out_dirs) == RUNS
+    for run, out_dir in enumerate(out_dirs):
+        got = G.collect(out_dir, n_pairs, K, T)
         assert [int(e) for e in got["epochs"]] == epochs
         all_rows.append(G.distances(got, z, epochs))
         all_direct.append(G.distances(got, z, epochs, prefix="ref32_") if "ref32_ckpt_sample" in z.files else None)
         _curves(f"configs[1] (MIOpen convolutions + HIP loss) continued from clip 'a' snapshot, run {run + 1} of {RUNS}, epochs {epochs[0]}..{epochs[-1]}",
                 all_rows[-1], z, {"burn_in_state_bitwise": same_state}, direct=all_direct[-1])
-        del ft
-        torch.cuda.empty_cache()
 
     def median_rows(runs):
         return {e: {c: float(np.median([r[e][c] for r in runs])) for c in runs[0][e]} for e in epochs}
@@ -421,7 +438,8 @@ def test_config1_torch_convs_hip_loss_from_the_same_snapshot(tmp_path, monkeypat
     _curves(f"configs[1]: per-epoch MEDIAN over {RUNS} runs", rows, z, {"runs": RUNS}, direct=direct)
     worst = {c: max(r[c] for r in rows.values()) for c in ("mean", "perpair", "evaldepth", "ckpt")}
     single = {c: max(r[e][c] for r in all_rows for e in epochs) for c in ("mean", "perpair", "evaldepth", "ckpt")}
-    report(f"loop_384x224_config1[K{K},T{T},runs{RUNS}]", burn_in_state_bitwise=same_state, **{"median_worst_" + k: v for k, v in worst.items()},
+    report(f"loop_384x224_config1[K{K},T{T},runs{RUNS}]", burn_in_state_bitwise=same_state, children_killed_by_a_signal=killed,
+           **{"median_worst_" + k: v for k, v in worst.items()},
            **{"single_run_worst_" + k: v for k, v in single.items()})
     _check_full_length(spec, rows, z, {}, None, slack=2.0, late_floor=2e-3, n_outright=12, late_scatter=3.0)
     if direct:      # ... and against the reference's own fp32 run, same envelope
