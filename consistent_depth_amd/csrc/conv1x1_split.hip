@@ -341,30 +341,38 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void conv1x1_split_kc_kernel
         s_aff[ksteps * 16 + i] = (in_shift && i < Cin) ? in_shift[i] : 0.f;
     }
     // filter chunk `c` (K-steps 4c .. 4c + 3) of this block's NT column tiles: global -> registers, registers -> LDS buffer
+    // (fetch only ISSUES the loads -- unconditional, on a clamped address -- and commit masks the dead elements: a use of the loaded
+    // value inside fetch, even the masking AND, makes the compiler wait for it there with vmcnt(0), which also drains the activation
+    // ring at the top of every chunk: measured as 42 % matrix-core utilisation in the first version of this kernel)
     u32x4 wreg[FQ];
+    auto chunk_src = [&](int c, int q, bool& live) -> size_t {
+        const int i = q * (NW * 64) + threadIdx.x;
+        const int ln = i & 63, t = (i >> 6) % NT, sp = (i / (64 * NT)) % 3, ksl = i / (64 * NT * 3);
+        const int gt = slice * NT + t, ks = c * KC + ksl;
+        live = i < CHUNK && gt < col_tiles && ks < ksteps_real;
+        return live ? (((size_t)gt * ksteps_real + ks) * 3 + sp) * 64 + ln : 0;
+    };
     auto fetch = [&](int c) {
 #pragma unroll
         for (int q = 0; q < FQ; ++q) {
-            const int i = q * (NW * 64) + threadIdx.x;
-            const int ln = i & 63, t = (i >> 6) % NT, sp = (i / (64 * NT)) % 3, ksl = i / (64 * NT * 3);
-            const int gt = slice * NT + t, ks = c * KC + ksl;
-            const bool live = i < CHUNK && gt < col_tiles && ks < ksteps_real;
-            const size_t src = live ? (((size_t)gt * ksteps_real + ks) * 3 + sp) * 64 + ln : 0;
-            u32x4 v = wsp[src];                                   // (unconditional load, masked: see load_raw)
-            const unsigned keep = live ? 0xffffffffu : 0u;
-            v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
-            wreg[q] = v;
+            bool live;
+            wreg[q] = wsp[chunk_src(c, q, live)];
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int c, int buf) {
 #pragma unroll
         for (int q = 0; q < FQ; ++q) {
             const int i = q * (NW * 64) + threadIdx.x;
-            if (i < CHUNK) s_w[buf * CHUNK + i] = wreg[q];
+            bool live;
+            (void)chunk_src(c, q, live);
+            const unsigned keep = live ? 0xffffffffu : 0u;
+            u32x4 v = wreg[q];
+            v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+            if (i < CHUNK) s_w[buf * CHUNK + i] = v;
         }
     };
     fetch(0);
-    commit(0);
+    commit(0, 0);
 
     // this lane's pixel
     const int tile = grp * NW + wid;
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void conv1x1_split_kc_kernel
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) commit(buf ^ 1);
+        if (more) commit(ks / KC + 1, buf ^ 1);
         __syncthreads();   // the next chunk is in LDS, and nobody reads `buf` any more
         buf ^= 1;
     }
