@@ -67,6 +67,7 @@ class Act:
     def __init__(self, buf, coff, C, relu=False, scale=None, shift=None, needs_grad=True):
         self.buf, self.coff, self.C, self.relu, self.scale, self.shift = buf, coff, C, relu, scale, shift
         self.gbuf = torch.empty_like(buf) if needs_grad else None
+        self.gcoff = coff           # channel offset of the gradient inside gbuf (= coff unless gbuf is another activation's buffer)
         self.grad_written = False
         if Act.registry is not None:
             Act.registry.append(self)
@@ -114,7 +115,7 @@ class ConvUnit:
 
     def dgrad_member(self, gbuf, g_coff, accumulate):
         s = self.src
-        return dict(x=gbuf, packed_w=self.pkT, Cin=self.cout, Cout=self.cin, ks=self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
+        return dict(x=gbuf, packed_w=self.pkT, Cin=self.cout, Cout=self.cin, ks=self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.gcoff,
                     accumulate=accumulate)
 
     def forward(self, training):
@@ -148,7 +149,7 @@ class ConvUnit:
                 s.buf, gbuf, self.cin, self.cout, self.ks, None, self.wgrad_ws, x_coff=s.coff, dy_coff=g_coff, in_scale=s.scale,
                 in_shift=s.shift, in_relu=s.relu, prezeroed=True))
         if s.gbuf is not None and not self.dgrad_merged:
-            C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.coff,
+            C.conv2d(gbuf, self.pkT, self.cout, self.cin, self.ks, x_coff=g_coff, out=s.gbuf, y_coff=s.gcoff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
 
 
@@ -203,7 +204,7 @@ class PointwiseGroup:
             s.buf, self.Pg, self.cin, self.ctot, 1, None, self.wgrad_ws, x_coff=s.coff, dy_coff=0, in_scale=s.scale,
             in_shift=s.shift, in_relu=s.relu, prezeroed=True))
         if s.gbuf is not None:
-            C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.coff,
+            C.conv2d(self.Pg, self.eng._pack.view(self._filtT), self.ctot, self.cin, 1, x_coff=0, out=s.gbuf, y_coff=s.gcoff,
                      accumulate=s.grad_mode(), cfg=self.cfg_d)
 
 
@@ -513,7 +514,11 @@ class HourglassEngine:
         flat, _, _, _ = self._sequence(plan, flat_steps, sides[1 - up_side], x, N, H, W)
         lo, h, w, pending = self._sequence(plan, up_steps, sides[up_side], x, N, H, W)
         assert pending and up_steps[0].kind == "pool" and up_steps[0].src is x
-        out = Act(self._new(N, flat.C, H, W), 0, flat.C)
+        # out = up(lo) + hi.  Its gradient IS hi's gradient: out's consumers write it straight into hi's slice of the concat gradient
+        # buffer (rounds 1-5 gave `out` its own gradient buffer and copied it: a 176 MB pass at 384x224); the bilinear adjoint reads
+        # it there before the full-resolution side's BatchNorm backward overwrites it in place (same stream order as before).
+        out = Act(self._new(N, flat.C, H, W), 0, flat.C, needs_grad=False)
+        out.gbuf, out.gcoff = flat.gbuf, flat.gcoff
         steps.append(_Node("channels", level=mod.level, flat=flat_steps, up=up_steps, lo=lo, hi=flat, out=out, x=x))
         return out
 
@@ -648,11 +653,13 @@ class HourglassEngine:
                 step.group.backward()
             elif step.kind == "pool":
                 s = step.src
-                L.avgpool2_bwd(step.out.gbuf, 0, s.gbuf, s.coff, s.C, accumulate=s.grad_mode())
+                L.avgpool2_bwd(step.out.gbuf, step.out.gcoff, s.gbuf, s.gcoff, s.C, accumulate=s.grad_mode())
             elif step.kind == "channels":
                 lo, hi, o = step.lo, step.hi, step.out
-                L.add_slice(o.gbuf, 0, hi.gbuf, hi.coff, hi.C, accumulate=hi.grad_mode())
-                L.upsample2x_bwd(o.gbuf, 0, lo.gbuf, lo.coff, lo.C, accumulate=lo.grad_mode())
+                # d(up(lo) + hi) / d hi is the identity: the sum's gradient was written straight into hi's gradient slice (_channels)
+                assert o.gbuf is hi.gbuf and o.gcoff == hi.gcoff
+                hi.grad_written = True
+                L.upsample2x_bwd(o.gbuf, o.gcoff, lo.gbuf, lo.gcoff, lo.C, accumulate=lo.grad_mode())
                 # the full-resolution side is the first writer of x's gradient; the pooled side's last kernel (the AvgPool2d adjoint into
                 # x) is enqueued behind the join and accumulates
                 done = self._on_side(step.level, lambda: self._run_backward(step.flat))
