@@ -73,7 +73,9 @@ __global__ void pack_1x1_table_kernel(const PackDesc* __restrict__ table) {
 size_t split_1x1_packed_floats(int OC, int IC) { return (size_t)((OC + 31) / 32) * ((IC + 15) / 16) * 3 * 64 * 4; }
 
 int launch_pack_1x1_table(const void* table_dev, int n, hipStream_t s) {
-    hipLaunchKernelGGL(pack_1x1_table_kernel, dim3(8, n), dim3(256), 0, s, (const PackDesc*)table_dev);
+    // (64 workgroups per descriptor since the end of round 6: with the 512...2048-channel filters of MiDaS in this layout 8 were a latency
+    // chain of 1.5 ms per step at the top of every forward)
+    hipLaunchKernelGGL(pack_1x1_table_kernel, dim3(64, n), dim3(256), 0, s, (const PackDesc*)table_dev);
     return hipGetLastError() == hipSuccess ? CD_OK : CD_ERR_LAUNCH;
 }
 
