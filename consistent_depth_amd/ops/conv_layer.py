@@ -70,6 +70,20 @@ class PackPool:
         self.fresh = False
 
 
+_WGRAD_SIDE = {}
+
+
+def _wgrad_side_stream(device):
+    """The side stream of the weight gradients (one per device), or None under CD_AMD_MIDAS_WGRAD_STREAM=0."""
+    import os
+    if os.environ.get("CD_AMD_MIDAS_WGRAD_STREAM", "1") == "0":
+        return None
+    key = torch.device(device).index
+    if key not in _WGRAD_SIDE:
+        _WGRAD_SIDE[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_SIDE[key]
+
+
 class _HipConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, layer):
@@ -109,6 +123,22 @@ class _HipConvFn(torch.autograd.Function):
         else:
             dyf = dy.contiguous()
         dx = dw = db = None
+        # The weight gradient and the input gradient of a layer are independent: the weight gradient is enqueued on a side stream forked
+        # here and joined before this function returns, so that its workgroups fill the compute units the input gradient's last round of
+        # workgroups leaves idle (288 workgroups of the 24x24 planes on 256 CUs).  Round 6, two alternations on one box: 72.9 / 73.1 ->
+        # 73.6 / 73.7 pairs/s on BASELINE configs[4] (CD_AMD_MIDAS_WGRAD_STREAM=0: one stream).  Same results either way.
+        side = _wgrad_side_stream(x.device) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None
+        if side is not None:
+            dw = torch.empty_like(weight)
+            ws, ws_stride = layer._wgrad_workspace(cout_g, cin_g, ks, x.device)
+            cur = torch.cuda.current_stream(x.device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                rc = lib.cd_conv2d_wgrad_grouped(_native.dev_ptr(x, "x"), Cin, 0, cin_g, dyf.data_ptr(), Cout, 0, cout_g, G, dw.data_ptr(), 0,
+                                                 ws.data_ptr(), ws_stride, N, H, W, ks, _native.stream_ptr(x.device))
+                _native.check(rc, "cd_conv2d_wgrad_grouped")
         if ctx.needs_input_grad[0]:
             _, pkT = layer._packed(weight, transposed_too=True)
             dx = torch.empty_like(x)
@@ -120,7 +150,11 @@ class _HipConvFn(torch.autograd.Function):
                 full = torch.zeros((N, Cin) + ctx.full_hw, dtype=dx.dtype, device=dx.device)
                 full[:, :, ::st, ::st] = dx
                 dx = full
-        if ctx.needs_input_grad[1]:
+        if side is not None:
+            done = torch.cuda.Event()
+            done.record(side)
+            torch.cuda.current_stream(x.device).wait_event(done)
+        elif ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws, ws_stride = layer._wgrad_workspace(cout_g, cin_g, ks, x.device)
             rc = lib.cd_conv2d_wgrad_grouped(_native.dev_ptr(x, "x"), Cin, 0, cin_g, dyf.data_ptr(), Cout, 0, cout_g, G, dw.data_ptr(), 0,
