@@ -70,6 +70,16 @@ class PackPool:
         self.fresh = False
 
 
+def _dense_cfg(groups, ks, Cin, Cout, N, H, W, device):
+    """(tile_rows, co_tiles) of the fastest launch shape of a DENSE k x k convolution (ops.conv.tuned_config: timed once per shape on
+    scratch tensors, cached; the result does not depend on it), or None: grouped / 1x1 / tuning disabled (CD_AMD_MIDAS_CONV_TUNE=0) ->
+    the library's rule.  Round 6: configs[4]'s decoder 3x3 convolutions had run on the rule's shape only."""
+    import os
+    if groups != 1 or ks < 3 or Cin < 8 or os.environ.get("CD_AMD_MIDAS_CONV_TUNE", "1") == "0":
+        return None
+    return C.tuned_config(ks, Cin, Cout, N, H, W, device)
+
+
 _WGRAD_SIDE = {}
 
 
@@ -100,9 +110,13 @@ class _HipConvFn(torch.autograd.Function):
         pk, _ = layer._packed(weight)
         y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
         bptr = _native.dev_ptr(bias, "bias") if bias is not None else None
-        rc = lib.cd_conv2d_fwd_grouped(_native.dev_ptr(x, "x"), Cin, 0, cin_g, pk[0].data_ptr(), layer._pack_stride, bptr, y.data_ptr(), Cout, 0,
-                                       cout_g, G, 0, N, H, W, ks, stream)
-        _native.check(rc, "cd_conv2d_fwd_grouped")
+        cfg = _dense_cfg(G, ks, Cin, Cout, N, H, W, x.device)
+        if cfg is not None:     # dense k x k (the decoder): the launch shape timed once per shape, like the hourglass engine does
+            C.conv2d(x, pk[0], Cin, Cout, ks, bias=bias, out=y, cfg=cfg)
+        else:
+            rc = lib.cd_conv2d_fwd_grouped(_native.dev_ptr(x, "x"), Cin, 0, cin_g, pk[0].data_ptr(), layer._pack_stride, bptr, y.data_ptr(), Cout, 0,
+                                           cout_g, G, 0, N, H, W, ks, stream)
+            _native.check(rc, "cd_conv2d_fwd_grouped")
         ctx.layer, ctx.hw, ctx.s = layer, (H, W), s
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -142,9 +156,13 @@ class _HipConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, pkT = layer._packed(weight, transposed_too=True)
             dx = torch.empty_like(x)
-            rc = lib.cd_conv2d_fwd_grouped(dyf.data_ptr(), Cout, 0, cout_g, pkT[0].data_ptr(), layer._pack_strideT, None, dx.data_ptr(), Cin, 0,
-                                           cin_g, G, 0, N, H, W, ks, stream)
-            _native.check(rc, "cd_conv2d_fwd_grouped (dgrad)")
+            cfg = _dense_cfg(G, ks, Cout, Cin, N, H, W, x.device)
+            if cfg is not None:
+                C.conv2d(dyf, pkT[0], Cout, Cin, ks, out=dx, cfg=cfg)
+            else:
+                rc = lib.cd_conv2d_fwd_grouped(dyf.data_ptr(), Cout, 0, cout_g, pkT[0].data_ptr(), layer._pack_strideT, None, dx.data_ptr(), Cin, 0,
+                                               cin_g, G, 0, N, H, W, ks, stream)
+                _native.check(rc, "cd_conv2d_fwd_grouped (dgrad)")
             if ctx.full_hw is not None:      # (strided 1x1: the input was sub-sampled first)
                 st = layer.stride[0]
                 full = torch.zeros((N, Cin) + ctx.full_hw, dtype=dx.dtype, device=dx.device)
