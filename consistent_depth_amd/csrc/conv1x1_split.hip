@@ -539,7 +539,7 @@ int launch_conv1x1_split_kc(const float* x, int x_ctot, int x_coff, int Cin, con
     if (!conv1x1_split_kc_ok(Cin, Cout, N, H, W)) return CD_ERR_UNSUPPORTED;
     // One shape: 8 waves x 128 output channels (216 registers: two waves per SIMD).  A 12-wave workgroup would balance the 24 x 24 planes
     // of MiDaS' layer3 better (288 pixel tiles x 8 slices = 288 workgroups of 8 waves take two rounds on 256 CUs, 192 of 12 waves one
-    // round of 1.5x the length) but needs 168 registers per wave and spills 156 bytes -- measured first, not shipped.
+    // round of 1.5x the length) but needs 168 registers per wave and spills 156 bytes: measured 210 us against 183 for 1024 x 1024, not shipped.
     // (NT = 5 -- 160 output channels per workgroup, 250 registers, no spill -- makes the 1024 x 1024 convolutions on 288 pixel tiles ONE round of
     // 252 workgroups: measured 215 us against 194 for the two rounds of NT = 4, the longer workgroup loses more than the round saves.)
     return launch_1x1_kc_t<4, 8>(x, x_ctot, x_coff, Cin, wsplit, bias, in_scale, in_shift, in_relu, y, y_ctot, y_coff, Cout, stats, accumulate, N, H, W, s);
